@@ -1,0 +1,212 @@
+/*
+ * whisper_amd.h - C-ABI of the MI355X read-verification path.
+ *
+ * This is the drop-in boundary for Whisper 2.0.2's verification stage
+ * (SURVEY.md section 8b).  The reference has no FFI: its boundary is a set of
+ * per-thread, one-candidate-per-call C++ objects.  Every entry point below
+ * names the reference interface (file:line under /root/reference/src) whose
+ * work it performs for a whole batch of candidates.
+ *
+ * Conventions
+ *   - plain pointers and sizes, no C++/torch types, no exceptions;
+ *   - every function returns a wamd_status (0 = WAMD_OK);
+ *   - "*_dev" entry points take DEVICE pointers and a hipStream_t passed as
+ *     void*; they are asynchronous on that stream and allocate nothing;
+ *   - the other entry points take HOST pointers, stage through the context's
+ *     pinned buffers and return when the results are in the caller's memory;
+ *   - symbol codes are the reference's: A 0, C 1, G 2, T 3, N_read 4,
+ *     N_ref 5 (common/defs.h:55-60); the genome is the reference's own
+ *     packed layout: two 4-bit symbols per byte, even position in the HIGH
+ *     nibble (index/ref_seq.cpp:248-281, common/reference.cpp:33-55).
+ */
+#ifndef WHISPER_AMD_H
+#define WHISPER_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WAMD_API __attribute__((visibility("default")))
+
+typedef enum wamd_status {
+    WAMD_OK = 0,
+    WAMD_ERR_INVALID_ARG = 1,   /* null pointer, bad enum, inconsistent sizes            */
+    WAMD_ERR_HIP = 2,           /* a HIP runtime call failed; see wamd_last_error()       */
+    WAMD_ERR_NO_DEVICE = 3,     /* no gfx950 device / HIP runtime unavailable            */
+    WAMD_ERR_TOO_LONG = 4,      /* read longer than WAMD_MAX_READ_LEN                     */
+    WAMD_ERR_TEXT_LEN = 5,      /* max_distance_in_ref == 0 or > max_text_len: the        */
+                                /* reference throws std::runtime_error here               */
+                                /* (LevMyers64.cpp:244-252, LevMyers256.hpp:102-110)      */
+    WAMD_ERR_RANGE = 6,         /* a task's window leaves the packed genome              */
+    WAMD_ERR_NO_MEMORY = 7,
+    WAMD_ERR_CAPACITY = 8       /* no-alloc entry point: batch beyond its static scratch */
+} wamd_status;
+
+/* Verifier variants.  AUTO follows the reference's choice by read length:
+ * len < 128 -> M128, len < 256 -> M256, else M64
+ * (mapper/mapping_core_sa.cpp:207-210, mapper/sam_matching.cpp:331-338, 691-694).
+ * The three differ in column range, tie-break and early exit, so end positions
+ * are only bit-exact when the variant matches the reference's. */
+enum {
+    WAMD_VARIANT_AUTO = 0,
+    WAMD_VARIANT_M64 = 1,   /* LevMyers64::dynamicProgramming   LevMyers64.cpp:223-389   */
+    WAMD_VARIANT_M128 = 2,  /* LevMyers128<>::dynamicProgramming LevMyers128.hpp:80-234  */
+    WAMD_VARIANT_M256 = 3   /* LevMyers256<>::dynamicProgramming LevMyers256.hpp:83-249  */
+};
+
+/* Read encodings accepted by wamd_reads_upload. */
+enum {
+    WAMD_READS_NIBBLE = 0,  /* 4-bit codes, first symbol in the high nibble:            */
+                            /* what LevMyers::preprocess / CEditDist::LevDiag /          */
+                            /* CIndelMatching::Preprocess take in the mapping stage      */
+    WAMD_READS_ASCII = 1    /* 'A','C','G','T','N' (anything else -> code 6):           */
+                            /* what preprocessRawSeq takes in post-processing            */
+};
+
+#define WAMD_MAX_READ_LEN 1024u        /* symbols; 16 x 64-bit words per bit-vector      */
+#define WAMD_TASK_FLAG_REV_COMP 1u     /* genome_t::rev_comp orientation of the read     */
+#define WAMD_LAST_SYMBOL_FROM_READ (-1)
+
+/* scoring_t (common/types.h:574-612); defaults: match 1, mismatch -5,
+ * gap open -5 / extend -0.4 (ins and del), clipping -6 (mapper/params.h:111-192). */
+typedef struct wamd_scoring {
+    double match;
+    double mismatch;
+    double gap_ins_open;
+    double gap_ins_extend;
+    double gap_del_open;
+    double gap_del_extend;
+    double clipping;
+} wamd_scoring;
+
+/* One LevMyers::dynamicProgramming call (LevMyers.h:51):
+ * dynamicProgramming(ref_pos, max_distance_in_ref, max_mate_edit_distance, pos, ed)
+ * on the read read_idx of a wamd_reads batch, preprocessed in the orientation
+ * given by flags (preprocess / preprocessRawSeq, LevMyers64.cpp:167-220). */
+typedef struct wamd_dist_task {
+    uint32_t read_idx;
+    uint32_t ref_pos;              /* raw genome position of the window start          */
+    uint32_t max_distance_in_ref;  /* W: window length                                  */
+    uint16_t max_ed;               /* k: max_mate_edit_distance / max_mismatches        */
+    uint8_t variant;               /* WAMD_VARIANT_*                                    */
+    uint8_t flags;                 /* WAMD_TASK_FLAG_*                                  */
+} wamd_dist_task;
+
+/* What dynamicProgramming hands back: edit_distance is always the minimum seen
+ * before the variant's early exit (so values > k are reproduced as well);
+ * pos is the 1-based end column, 0 when edit_distance > k (return false). */
+typedef struct wamd_dist_result {
+    uint32_t edit_distance;
+    uint32_t pos;
+} wamd_dist_result;
+
+/* One CEditDist::LevDiag call (mapper/edit_dist.h:50-51, edit_dist.cpp:106-344):
+ * LevDiag(pattern, pattern_len, position_in_text, fixed_left, fixed_right,
+ *         max_mismatches, dir_gen_flag) -> errors, or max_mismatches + 1. */
+typedef struct wamd_levdiag_task {
+    uint32_t read_idx;
+    uint32_t position_in_text;
+    uint16_t fixed_left;
+    uint16_t fixed_right;
+    uint16_t max_mismatches;
+    uint16_t dir_gen_flag;
+} wamd_levdiag_task;
+
+/* Result of dynamicProgramming + getExtCigar (+ refine_ext_cigar):
+ * LevMyers.h:62-63, LevMyers64.cpp:392-520, LevMyers128.hpp:238-367,
+ * LevMyers256.hpp:253-384, sam_matching.cpp:858-924. */
+typedef struct wamd_align_result {
+    double affine_score;      /* after refinement when refined != 0                    */
+    uint32_t ok;              /* dynamicProgramming's bool                              */
+    uint32_t edit_distance;   /* as returned by dynamicProgramming (not refined)        */
+    uint32_t end_pos;         /* pos                                                    */
+    uint32_t begin_pos;       /* getExtCigar's return value                             */
+    uint32_t num_events;      /* gap opens (+1 when refined)                            */
+    uint32_t cigar_len;       /* bytes of ext-CIGAR, NUL not counted                    */
+    uint32_t refined;         /* refine_ext_cigar returned true                         */
+    uint32_t reserved;
+} wamd_align_result;
+
+typedef struct wamd_ctx wamd_ctx;       /* one per (process, device)                  */
+typedef struct wamd_reads wamd_reads;   /* a device-resident batch of reads           */
+
+/* ---- library ----------------------------------------------------------- */
+WAMD_API const char* wamd_version(void);
+WAMD_API const char* wamd_last_error(void);   /* thread-local text of the last failure */
+WAMD_API int wamd_device_count(void);
+
+/* ---- context: replaces setReference() on every verifier ---------------- *
+ * LevMyers::setReference (LevMyers64.cpp:83-89), CEditDist::SetReference
+ * (edit_dist.cpp:98-103), CIndelMatching::SetReference (indels.cpp:116-121).
+ * genome: packed reference bytes as CReference::GetData() returns them,
+ * genome_bytes of them; ref_size / cur_offset as passed to SetReference.
+ * The genome is uploaded once and stays resident in HBM. */
+WAMD_API int wamd_ctx_create(int device, const uint8_t* genome, uint64_t genome_bytes,
+                             uint32_t ref_size, uint32_t cur_offset, wamd_ctx** out);
+/* Same, for a genome already resident on the device (not copied, not owned). */
+WAMD_API int wamd_ctx_create_dev(int device, const uint8_t* d_genome, uint64_t genome_bytes,
+                                 uint32_t ref_size, uint32_t cur_offset, wamd_ctx** out);
+WAMD_API int wamd_ctx_destroy(wamd_ctx* ctx);
+WAMD_API int wamd_ctx_set_scoring(wamd_ctx* ctx, const wamd_scoring* scoring);
+/* LevMyers constructor argument max_text_len (LevMyers.h:45): tasks with
+ * max_distance_in_ref above it fail with WAMD_ERR_TEXT_LEN.  Default 16384
+ * (mapper/sam.cpp:190). */
+WAMD_API int wamd_ctx_set_max_text_len(wamd_ctx* ctx, uint32_t max_text_len);
+WAMD_API void* wamd_ctx_stream(wamd_ctx* ctx);   /* the context's own hipStream_t */
+WAMD_API int wamd_ctx_synchronize(wamd_ctx* ctx);
+
+/* ---- reads: replaces preprocess()/preprocessRawSeq() ------------------- *
+ * Uploads n reads and builds, per read and orientation, the pattern-match
+ * bit-vectors (LevMyers64.cpp:167-220).  data/offsets: read i starts at byte
+ * offsets[i] of data and has lens[i] symbols.  orientations: bit 0 direct,
+ * bit 1 rev_comp. */
+WAMD_API int wamd_reads_upload(wamd_ctx* ctx, const uint8_t* data, const uint64_t* offsets,
+                               const uint32_t* lens, uint32_t n, int encoding,
+                               int orientations, wamd_reads** out);
+WAMD_API int wamd_reads_free(wamd_reads* reads);
+WAMD_API uint32_t wamd_reads_count(const wamd_reads* reads);
+
+/* ---- verification: edit distance only (mapping stages) ----------------- *
+ * Replaces the per-candidate calls at mapping_core_sa.cpp:237/289/399/401/448/450
+ * and mapping_core_dp.cpp:137/139/165/167.
+ * last_symbol: WAMD_LAST_SYMBOL_FROM_READ after preprocess() (mapping stage), or the
+ * value the object's last preprocess() left behind when the read came through
+ * preprocessRawSeq() (0 in CSamGenerator) - only the M256 tie-break reads it
+ * (LevMyers256.hpp:191-196). */
+WAMD_API int wamd_verify_distance(wamd_ctx* ctx, const wamd_reads* reads,
+                                  const wamd_dist_task* tasks, uint32_t n, int last_symbol,
+                                  wamd_dist_result* results);
+WAMD_API int wamd_verify_distance_dev(wamd_ctx* ctx, const wamd_reads* reads,
+                                      const wamd_dist_task* d_tasks, uint32_t n,
+                                      int last_symbol, wamd_dist_result* d_results,
+                                      void* stream);
+
+WAMD_API int wamd_levdiag(wamd_ctx* ctx, const wamd_reads* reads,
+                          const wamd_levdiag_task* tasks, uint32_t n, uint32_t* results);
+WAMD_API int wamd_levdiag_dev(wamd_ctx* ctx, const wamd_reads* reads,
+                              const wamd_levdiag_task* d_tasks, uint32_t n,
+                              uint32_t* d_results, void* stream);
+
+/* ---- verification with alignment (post-processing) --------------------- *
+ * dynamicProgramming + getExtCigar (+ refine_ext_cigar when refine != 0) as in
+ * fill_cigar_with_lev (sam_matching.cpp:689-752) and find_pairs<LevMyers>
+ * (sam_matching.cpp:401-426).  ext-CIGARs are written NUL-terminated at
+ * cigars + i * cigar_stride; cigar_stride >= 2 * max read length + 2. */
+WAMD_API int wamd_align(wamd_ctx* ctx, const wamd_reads* reads, const wamd_dist_task* tasks,
+                        uint32_t n, int last_symbol, int refine,
+                        wamd_align_result* results, uint8_t* cigars, uint32_t cigar_stride);
+/* d_workspace: wamd_align_workspace_bytes(...) bytes of device scratch. */
+WAMD_API int wamd_align_dev(wamd_ctx* ctx, const wamd_reads* reads,
+                            const wamd_dist_task* d_tasks, uint32_t n, int last_symbol,
+                            int refine, wamd_align_result* d_results, uint8_t* d_cigars,
+                            uint32_t cigar_stride, void* d_workspace,
+                            uint64_t workspace_bytes, void* stream);
+WAMD_API uint64_t wamd_align_workspace_bytes(const wamd_reads* reads, uint32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WHISPER_AMD_H */

@@ -1,0 +1,141 @@
+"""ctypes bindings for the two CHECKERS: oracle/libwv_oracle.so (our CPU restatement)
+and oracle/_ref/libwhisper_ref.so (the reference's own classes behind ref_shim.cpp).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  Nothing under whisper_amd/ imports this module.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(_HERE, "libwv_oracle.so")
+REF_SO = os.path.join(_HERE, "_ref", "libwhisper_ref.so")
+
+# numpy views of the C-ABI structs (include/whisper_amd.h)
+DIST_TASK = np.dtype([("read_idx", "<u4"), ("ref_pos", "<u4"), ("max_distance_in_ref", "<u4"),
+                      ("max_ed", "<u2"), ("variant", "u1"), ("flags", "u1")])
+DIST_RESULT = np.dtype([("edit_distance", "<u4"), ("pos", "<u4")])
+LEVDIAG_TASK = np.dtype([("read_idx", "<u4"), ("position_in_text", "<u4"), ("fixed_left", "<u2"),
+                         ("fixed_right", "<u2"), ("max_mismatches", "<u2"),
+                         ("dir_gen_flag", "<u2")])
+ALIGN_RESULT = np.dtype([("affine_score", "<f8"), ("ok", "<u4"), ("edit_distance", "<u4"),
+                         ("end_pos", "<u4"), ("begin_pos", "<u4"), ("num_events", "<u4"),
+                         ("cigar_len", "<u4"), ("refined", "<u4"), ("reserved", "<u4")])
+assert DIST_TASK.itemsize == 16 and LEVDIAG_TASK.itemsize == 16 and ALIGN_RESULT.itemsize == 40
+
+
+class Scoring(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("match", "mismatch", "gap_ins_open", "gap_ins_extend",
+                                           "gap_del_open", "gap_del_extend", "clipping")]
+
+
+def default_scoring():
+    # mapper/params.h:145-154
+    return Scoring(1.0, -5.0, -5.0, -0.4, -5.0, -0.4, -6.0)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _c(a, dtype=None):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    return a
+
+
+class _Lib:
+    path = None
+
+    def __init__(self):
+        if not os.path.exists(self.path):
+            raise FileNotFoundError(self.path + " (run `make -C oracle`)")
+        self.lib = C.CDLL(self.path)
+
+
+class Oracle(_Lib):
+    """Our CPU restatement (oracle/wv_oracle.c)."""
+    path = ORACLE_SO
+
+    def distance(self, genome, reads, offsets, lens, encoding, tasks, last_symbol=-1,
+                 max_text_len=16384):
+        tasks = _c(tasks)
+        res = np.zeros(len(tasks), DIST_RESULT)
+        rc = self.lib.wo_distance_batch(_p(genome), _p(reads), _p(offsets), _p(lens),
+                                        C.c_int(encoding), _p(tasks), C.c_uint32(len(tasks)),
+                                        C.c_int(last_symbol), C.c_uint32(max_text_len), _p(res))
+        return rc, res
+
+    def levdiag(self, genome, ref_size, cur_offset, reads, offsets, lens, tasks):
+        tasks = _c(tasks)
+        res = np.zeros(len(tasks), np.uint32)
+        rc = self.lib.wo_levdiag_batch(_p(genome), C.c_uint32(ref_size), C.c_uint32(cur_offset),
+                                       _p(reads), _p(offsets), _p(lens), _p(tasks),
+                                       C.c_uint32(len(tasks)), _p(res))
+        return rc, res
+
+    def align(self, genome, reads, offsets, lens, encoding, tasks, last_symbol=0, refine=1,
+              max_text_len=16384, scoring=None, cigar_stride=1024):
+        tasks = _c(tasks)
+        sc = scoring or default_scoring()
+        res = np.zeros(len(tasks), ALIGN_RESULT)
+        cig = np.zeros((len(tasks), cigar_stride), np.uint8)
+        rc = self.lib.wo_align_batch(_p(genome), _p(reads), _p(offsets), _p(lens),
+                                     C.c_int(encoding), _p(tasks), C.c_uint32(len(tasks)),
+                                     C.c_int(last_symbol), C.c_int(refine),
+                                     C.c_uint32(max_text_len), C.byref(sc), _p(res), _p(cig),
+                                     C.c_uint32(cigar_stride))
+        return rc, res, cig
+
+
+class Reference(_Lib):
+    """The reference's own objects (oracle/_ref/libwhisper_ref.so)."""
+    path = REF_SO
+
+    def __init__(self):
+        super().__init__()
+        self.lib.ref_version.restype = C.c_char_p
+
+    def version(self):
+        return self.lib.ref_version().decode()
+
+    def distance(self, genome, ref_size, reads, offsets, lens, encoding, tasks, last_symbol=-1,
+                 max_query_len=1024, max_text_len=16384, nthreads=1):
+        tasks = _c(tasks)
+        res = np.zeros(len(tasks), DIST_RESULT)
+        rc = self.lib.ref_distance_batch(_p(genome), C.c_uint32(ref_size), _p(reads), _p(offsets),
+                                         _p(lens), C.c_int(encoding), _p(tasks),
+                                         C.c_uint32(len(tasks)), C.c_int(last_symbol),
+                                         C.c_uint32(max_query_len), C.c_uint32(max_text_len),
+                                         _p(res), C.c_int(nthreads))
+        return rc, res
+
+    def levdiag(self, genome, ref_size, cur_offset, reads, offsets, lens, tasks,
+                max_query_len=1024, max_ed=16, nthreads=1):
+        tasks = _c(tasks)
+        res = np.zeros(len(tasks), np.uint32)
+        rc = self.lib.ref_levdiag_batch(_p(genome), C.c_uint32(ref_size), C.c_uint32(cur_offset),
+                                        _p(reads), _p(offsets), _p(lens), _p(tasks),
+                                        C.c_uint32(len(tasks)), C.c_uint32(max_query_len),
+                                        C.c_uint32(max_ed), _p(res), C.c_int(nthreads))
+        return rc, res
+
+    def align(self, genome, ref_size, reads, offsets, lens, encoding, tasks, last_symbol=0,
+              refine=1, max_query_len=1024, max_text_len=16384, scoring=None, cigar_stride=1024,
+              nthreads=1):
+        tasks = _c(tasks)
+        sc = scoring or default_scoring()
+        res = np.zeros(len(tasks), ALIGN_RESULT)
+        cig = np.zeros((len(tasks), cigar_stride), np.uint8)
+        rc = self.lib.ref_align_batch(_p(genome), C.c_uint32(ref_size), _p(reads), _p(offsets),
+                                      _p(lens), C.c_int(encoding), _p(tasks),
+                                      C.c_uint32(len(tasks)), C.c_int(last_symbol),
+                                      C.c_int(refine), C.c_uint32(max_query_len),
+                                      C.c_uint32(max_text_len), C.byref(sc), _p(res), _p(cig),
+                                      C.c_uint32(cigar_stride), C.c_int(nthreads))
+        return rc, res, cig
+
+
+def have_reference():
+    return os.path.exists(REF_SO)

@@ -1,0 +1,299 @@
+/*
+ * ref_shim.cpp - C entry points around the REFERENCE's own verifier classes.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is ours; every algorithm it runs is the
+ * reference's, compiled by oracle/Makefile from the sources where they lie
+ * under /root/reference/src (nothing is copied into the repository).  The
+ * resulting oracle/_ref/libwhisper_ref.so is used to
+ *   - pin oracle/wv_oracle.c (tests/test_oracle_vs_reference.py),
+ *   - generate the fixtures under tests/golden/ (tests/golden/make_golden.py),
+ *   - time the reference's AVX2 verifier as bench.py's cpu_baseline
+ *     (kind "reference").
+ * The drivers below only do what the reference's callers do around a verifier
+ * call (mapping_core_sa.cpp:207-241, sam_matching.cpp:689-735): pick the object
+ * by read length, preprocess, call, unpack sequences for getExtCigar.
+ */
+#include <algorithm>
+#include <atomic>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <thread>
+#include <vector>
+
+/* compiled with -fno-access-control: CSamGenerator's helpers are private */
+#include "mapper/sam.h"
+
+#include "mapper/LevMyers.h"
+#include "mapper/LevMyers128.h"
+#include "mapper/LevMyers256.h"
+#include "mapper/edit_dist.h"
+#include "common/types.h"
+
+#include "../include/whisper_amd.h"
+
+#define REF_API extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+scoring_t make_scoring(const wamd_scoring* s)
+{
+    /* scoring_t(match, error, mismatch, ins_open, ins_ext, del_open, del_ext, clipping) */
+    return scoring_t(s->match, s->mismatch, s->mismatch, s->gap_ins_open, s->gap_ins_extend,
+                     s->gap_del_open, s->gap_del_extend, s->clipping);
+}
+
+/* The set of verifier objects one worker thread owns (mapping_core.cpp:154-191,
+ * sam.cpp:190-224). */
+struct Verifiers {
+    std::unique_ptr<LevMyers> m64, m128, m256;
+    std::unique_ptr<CEditDist> lev_diag;
+    uint32_t max_query_len, max_text_len;
+
+    Verifiers(uint32_t max_query_len_, uint32_t max_text_len_, uint32_t max_ed,
+              uint8_t* genome, uint32_t ref_size, uint32_t cur_offset)
+        : max_query_len(max_query_len_), max_text_len(max_text_len_)
+    {
+        m64.reset(new LevMyers64(max_query_len, max_text_len, 0));
+        m128.reset(new LevMyers128<instruction_set_t::avx2>(max_text_len, 0));
+        m256.reset(new LevMyers256<instruction_set_t::avx2>(max_text_len, 0));
+        lev_diag.reset(new CEditDist(max_query_len, max_text_len, max_ed));
+        m64->setReference(genome, ref_size, cur_offset);
+        m128->setReference(genome, ref_size, cur_offset);
+        m256->setReference(genome, ref_size, cur_offset);
+        lev_diag->SetReference(genome, ref_size, cur_offset);
+    }
+
+    LevMyers* pick(int variant, uint32_t len)
+    {
+        if (variant == WAMD_VARIANT_AUTO) /* mapping_core_sa.cpp:207-210 */
+            return (len < 256) ? ((len < 128) ? m128.get() : m256.get()) : m64.get();
+        if (variant == WAMD_VARIANT_M64)
+            return m64.get();
+        return variant == WAMD_VARIANT_M128 ? m128.get() : m256.get();
+    }
+};
+
+/* Leave `code` in the object's last_symbol the only way the reference can:
+ * preprocess() of a read ending in it (LevMyers64.cpp:182). */
+void plant_last_symbol(LevMyers* lm, int code)
+{
+    uint8_t one = (uint8_t)(code << 4);
+    lm->preprocess(&one, 1, genome_t::direct);
+}
+
+int last_code_of(const uint8_t* seq, uint32_t len, int encoding, bool rev)
+{
+    static const int rc[16] = {3, 2, 1, 0, 4, 5, 6, 7, 7, 7, 7, 7, 7, 7, 7, 7};
+    if (encoding == WAMD_READS_NIBBLE) {
+        uint32_t i = rev ? 0 : len - 1;
+        int c = (i & 1) ? (seq[i >> 1] & 15) : (seq[i >> 1] >> 4);
+        return rev ? rc[c] : c;
+    }
+    uint8_t ch = rev ? seq[0] : seq[len - 1];
+    switch (ch) {
+    case 'A': return rev ? 3 : 0;
+    case 'C': return rev ? 2 : 1;
+    case 'G': return rev ? 1 : 2;
+    case 'T': return rev ? 0 : 3;
+    case 'N': return 4;
+    default: return 6;
+    }
+}
+
+void prepare(LevMyers* lm, const uint8_t* seq, uint32_t len, int encoding, bool rev,
+             int last_symbol)
+{
+    genome_t dir = rev ? genome_t::rev_comp : genome_t::direct;
+    if (encoding == WAMD_READS_NIBBLE) {
+        if (last_symbol == WAMD_LAST_SYMBOL_FROM_READ) {
+            lm->preprocess(const_cast<uint8_t*>(seq), len, dir);
+        } else {
+            /* stale last_symbol with a nibble read: plant the symbol, then build the
+             * PM table through preprocessRawSeq, which leaves last_symbol alone
+             * (codes 0..4 only: the ASCII path cannot express the others) */
+            plant_last_symbol(lm, last_symbol);
+            std::vector<uint8_t> ascii(len);
+            static const char dec[] = "ACGTNNXXXXXXXXXX";
+            for (uint32_t i = 0; i < len; ++i) {
+                int c = (i & 1) ? (seq[i >> 1] & 15) : (seq[i >> 1] >> 4);
+                ascii[i] = (uint8_t)dec[c];
+            }
+            lm->preprocessRawSeq(ascii.data(), len, dir);
+        }
+    } else {
+        int code = last_symbol == WAMD_LAST_SYMBOL_FROM_READ
+                       ? last_code_of(seq, len, encoding, rev)
+                       : last_symbol;
+        plant_last_symbol(lm, code);
+        lm->preprocessRawSeq(const_cast<uint8_t*>(seq), len, dir);
+    }
+}
+
+/* copy_direct / convert_to_rev_comp / ref_copy_direct are CSamGenerator members
+ * that touch no member data (sam.cpp:2296-2375): call the reference's own code
+ * on storage that is never constructed. */
+struct SamGenBox {
+    alignas(CSamGenerator) unsigned char raw[sizeof(CSamGenerator)];
+    CParams params;
+    CSamGenerator* get() { return reinterpret_cast<CSamGenerator*>(raw); }
+    SamGenBox()
+    {
+        memset(raw, 0, sizeof(raw));
+        get()->params = &params;
+    }
+};
+
+template <class F> void parallel_for(uint32_t n, int nthreads, F f)
+{
+    if (nthreads <= 1) {
+        f(0, 0u, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    std::atomic<uint32_t> next(0);
+    const uint32_t chunk = 4096;
+    for (int t = 0; t < nthreads; ++t)
+        th.emplace_back([&, t]() {
+            for (;;) {
+                uint32_t b = next.fetch_add(chunk);
+                if (b >= n)
+                    break;
+                f(t, b, std::min(n, b + chunk));
+            }
+        });
+    for (auto& x : th)
+        x.join();
+}
+
+} // namespace
+
+REF_API const char* ref_version() { return MAPPER_VERSION; }
+
+REF_API int ref_distance_batch(const uint8_t* genome, uint32_t ref_size, const uint8_t* reads,
+                               const uint64_t* offsets, const uint32_t* lens, int encoding,
+                               const wamd_dist_task* tasks, uint32_t n, int last_symbol,
+                               uint32_t max_query_len, uint32_t max_text_len,
+                               wamd_dist_result* results, int nthreads)
+{
+    std::atomic<int> rc(0);
+    parallel_for(n, nthreads, [&](int, uint32_t b, uint32_t e) {
+        Verifiers v(max_query_len, max_text_len, 0, const_cast<uint8_t*>(genome), ref_size, 0);
+        uint32_t prev_read = ~0u;
+        uint8_t prev_flags = 0;
+        LevMyers* prev_lm = nullptr;
+        for (uint32_t i = b; i < e; ++i) {
+            const wamd_dist_task& t = tasks[i];
+            LevMyers* lm = v.pick(t.variant, lens[t.read_idx]);
+            /* a read is preprocessed once for all its candidates
+             * (mapping_core_sa.cpp:212-213) */
+            if (t.read_idx != prev_read || t.flags != prev_flags || lm != prev_lm) {
+                prepare(lm, reads + offsets[t.read_idx], lens[t.read_idx], encoding,
+                        t.flags & WAMD_TASK_FLAG_REV_COMP, last_symbol);
+                prev_read = t.read_idx;
+                prev_flags = t.flags;
+                prev_lm = lm;
+            }
+            try {
+                ref_pos_t pos = 0;
+                uint32_t ed = 0;
+                lm->dynamicProgramming(t.ref_pos, t.max_distance_in_ref, t.max_ed, pos, ed);
+                results[i].pos = pos;
+                results[i].edit_distance = ed;
+            } catch (const std::runtime_error&) {
+                rc = WAMD_ERR_TEXT_LEN;
+                return;
+            }
+        }
+    });
+    return rc;
+}
+
+REF_API int ref_levdiag_batch(const uint8_t* genome, uint32_t ref_size, uint32_t cur_offset,
+                              const uint8_t* reads, const uint64_t* offsets,
+                              const uint32_t* lens, const wamd_levdiag_task* tasks, uint32_t n,
+                              uint32_t max_query_len, uint32_t max_ed, uint32_t* results,
+                              int nthreads)
+{
+    parallel_for(n, nthreads, [&](int, uint32_t b, uint32_t e) {
+        CEditDist ed(max_query_len, max_query_len + 2 * max_ed + 2, max_ed);
+        ed.SetReference(const_cast<uint8_t*>(genome), ref_size, cur_offset);
+        for (uint32_t i = b; i < e; ++i) {
+            const wamd_levdiag_task& t = tasks[i];
+            results[i] = ed.LevDiag(const_cast<uint8_t*>(reads + offsets[t.read_idx]),
+                                    lens[t.read_idx], t.position_in_text, t.fixed_left,
+                                    t.fixed_right, t.max_mismatches, t.dir_gen_flag != 0);
+        }
+    });
+    return 0;
+}
+
+REF_API int ref_align_batch(const uint8_t* genome, uint32_t ref_size, const uint8_t* reads,
+                            const uint64_t* offsets, const uint32_t* lens, int encoding,
+                            const wamd_dist_task* tasks, uint32_t n, int last_symbol,
+                            int refine, uint32_t max_query_len, uint32_t max_text_len,
+                            const wamd_scoring* sc, wamd_align_result* results,
+                            uint8_t* cigars, uint32_t cigar_stride, int nthreads)
+{
+    std::atomic<int> rc(0);
+    if (encoding != WAMD_READS_ASCII)
+        return WAMD_ERR_INVALID_ARG; /* the reference only aligns raw (ASCII) reads */
+    parallel_for(n, nthreads, [&](int, uint32_t b, uint32_t e) {
+        Verifiers v(max_query_len, max_text_len, 0, const_cast<uint8_t*>(genome), ref_size, 0);
+        SamGenBox box;
+        box.params.mismatch_score = sc->mismatch;
+        box.params.gap_ins_open = sc->gap_ins_open;
+        box.params.gap_del_open = sc->gap_del_open;
+        scoring_t scoring = make_scoring(sc);
+        std::vector<uint8_t> read_codes(max_query_len + 8), ref_codes(max_text_len + 8);
+        for (uint32_t i = b; i < e; ++i) {
+            const wamd_dist_task& t = tasks[i];
+            wamd_align_result& r = results[i];
+            uint8_t* ec = cigars + (size_t)i * cigar_stride;
+            const uint32_t m = lens[t.read_idx];
+            const bool rev = t.flags & WAMD_TASK_FLAG_REV_COMP;
+            uint8_t* seq = const_cast<uint8_t*>(reads + offsets[t.read_idx]);
+            memset(&r, 0, sizeof(r));
+            ec[0] = 0;
+            LevMyers* lm = v.pick(t.variant, m);
+            prepare(lm, seq, m, encoding, rev, last_symbol);
+            ref_pos_t end_pos = 0;
+            uint32_t ed = 0;
+            bool ok;
+            try {
+                ok = lm->dynamicProgramming(t.ref_pos, t.max_distance_in_ref, t.max_ed, end_pos, ed);
+            } catch (const std::runtime_error&) {
+                rc = WAMD_ERR_TEXT_LEN;
+                return;
+            }
+            r.ok = ok;
+            r.edit_distance = ed;
+            r.end_pos = end_pos;
+            if (!ok)
+                continue;
+            /* sam_matching.cpp:706-735 */
+            if (!rev)
+                box.get()->copy_direct(read_codes.data() + 1, seq, m);
+            else
+                box.get()->convert_to_rev_comp(read_codes.data() + 1, seq, m);
+            box.get()->ref_copy_direct(ref_codes.data(), const_cast<uint8_t*>(genome), t.ref_pos,
+                                       t.max_distance_in_ref);
+            double score = 0;
+            uint32_t events = 0;
+            r.begin_pos = lm->getExtCigar(ec, ref_codes.data(), read_codes.data(), nullptr,
+                                          end_pos, ed, m,
+                                          rev ? genome_t::rev_comp : genome_t::direct, scoring,
+                                          score, events);
+            if (refine) {
+                uint32_t ed2 = ed;
+                r.refined = box.get()->refine_ext_cigar(ec, ref_codes.data() + r.begin_pos, ed2,
+                                                        events, score);
+            }
+            r.affine_score = score;
+            r.num_events = events;
+            r.cigar_len = (uint32_t)strlen((const char*)ec);
+        }
+    });
+    return rc;
+}

@@ -1,0 +1,95 @@
+/*
+ * wv_oracle.h - CPU restatement of Whisper 2.0.2's read-verification path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under whisper_amd/ may include, link or
+ * load this; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg use it, and only as the checker.
+ *
+ * Parity pin: every function here is checked, on seeded random tasks and on the
+ * committed fixtures under tests/golden/, against the reference's own objects
+ * compiled from /root/reference/src into oracle/_ref/libwhisper_ref.so
+ * (oracle/Makefile, oracle/ref_shim.cpp; tests/test_oracle_vs_reference.py,
+ * tests/golden/make_golden.py).
+ */
+#ifndef WV_ORACLE_H
+#define WV_ORACLE_H
+
+#include <stdint.h>
+#include "../include/whisper_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WO_MAX_WORDS 16 /* 1024 symbols */
+
+/* Pattern-match table of one preprocessed read: LevMyers64's bp_PM
+ * (LevMyers.h:80-82) plus the two scalars the DP reads. */
+typedef struct wo_pattern {
+    uint64_t pm[16][WO_MAX_WORDS];
+    uint32_t seq_len;
+    uint8_t last_symbol;
+} wo_pattern;
+
+/* Bit-vector matrix of one dynamicProgramming call, column-major and UNSKEWED:
+ * cell [col * words + w], col = 0..n_cols.  The skewed variants store lane w of
+ * iteration j = col + w (LevMyers256.hpp:276); this layout holds the same values. */
+typedef struct wo_cell {
+    uint64_t D0, VP, VN, HN, HP;
+} wo_cell;
+
+void wo_pattern_init(wo_pattern* p);
+/* LevMyers64::preprocess, LevMyers64.cpp:167-196 (nibble-packed read). */
+void wo_preprocess(wo_pattern* p, const uint8_t* seq, uint32_t seq_len, int rev_comp);
+/* LevMyers64::preprocessRawSeq, LevMyers64.cpp:199-220 (ASCII read; last_symbol untouched). */
+void wo_preprocess_raw(wo_pattern* p, const uint8_t* seq, uint32_t seq_len, int rev_comp);
+
+/* variant by read length, mapping_core_sa.cpp:207-210. */
+int wo_variant_for_len(uint32_t seq_len);
+
+/* dynamicProgramming of the three variants.  matrix may be NULL; otherwise it
+ * must hold (W + 2) * words cells, words = (seq_len - 1) / 64 + 1.
+ * Returns 1/0 like the reference's bool, -1 when the reference would throw. */
+int wo_myers_dp(const wo_pattern* p, int variant, const uint8_t* genome, uint32_t ref_pos,
+                uint32_t W, uint32_t k, uint32_t max_text_len, uint32_t* pos, uint32_t* ed,
+                wo_cell* matrix);
+
+/* getExtCigar, LevMyers64.cpp:392-520 (identical in the 128/256 variants up to
+ * the matrix addressing).  read_codes is 1-based (guard at [0]), ref_codes 0-based. */
+uint32_t wo_ext_cigar(const wo_cell* matrix, uint32_t words, uint8_t* ext_cigar,
+                      const uint8_t* ref_codes, const uint8_t* read_codes, uint32_t pos,
+                      uint32_t edit_dist, uint32_t seq_len, const wamd_scoring* sc,
+                      double* affine_score, uint32_t* num_events);
+
+/* CSamGenerator::refine_ext_cigar, sam_matching.cpp:858-924. */
+int wo_refine_ext_cigar(uint8_t* ext_cigar, const uint8_t* ref_codes, uint32_t* edit_distance,
+                        uint32_t* num_events, double* score, const wamd_scoring* sc);
+
+/* copy_direct / convert_to_rev_comp / ref_copy_direct, sam.cpp:2296-2375. */
+void wo_read_codes(uint8_t* dest, const uint8_t* ascii, uint32_t len, int rev_comp);
+void wo_ref_codes(uint8_t* dest, const uint8_t* genome, uint32_t pos, uint32_t len);
+
+/* CEditDist::LevDiag, edit_dist.cpp:106-344. */
+uint32_t wo_levdiag(const uint8_t* genome, uint32_t ref_size, uint32_t cur_offset,
+                    const uint8_t* pattern, uint32_t pattern_len, uint32_t position_in_text,
+                    uint32_t fixed_left, uint32_t fixed_right, uint32_t max_mismatches,
+                    int dir_gen_flag);
+
+/* ---- batch drivers over the C-ABI task structs (one verifier "object" per call) ---- */
+/* reads: data/offsets/lens as wamd_reads_upload takes them. */
+int wo_distance_batch(const uint8_t* genome, const uint8_t* reads, const uint64_t* offsets,
+                      const uint32_t* lens, int encoding, const wamd_dist_task* tasks,
+                      uint32_t n, int last_symbol, uint32_t max_text_len,
+                      wamd_dist_result* results);
+int wo_levdiag_batch(const uint8_t* genome, uint32_t ref_size, uint32_t cur_offset,
+                     const uint8_t* reads, const uint64_t* offsets, const uint32_t* lens,
+                     const wamd_levdiag_task* tasks, uint32_t n, uint32_t* results);
+int wo_align_batch(const uint8_t* genome, const uint8_t* reads, const uint64_t* offsets,
+                   const uint32_t* lens, int encoding, const wamd_dist_task* tasks, uint32_t n,
+                   int last_symbol, int refine, uint32_t max_text_len, const wamd_scoring* sc,
+                   wamd_align_result* results, uint8_t* cigars, uint32_t cigar_stride);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
