@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""bench.py - verified candidates / second of the MI355X read-verification path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One "step" = one pass of the hot path over one batch of synthetic candidates that are
+already resident in HBM: N_TASKS LevMyers256 distance verifications of shape S1
+(m = 150, k = 12, W = 174 - the sensitive stages of the 150 bp configs,
+BASELINE.json configs[1]).  For N > 1 every rank verifies its own shard (read bins
+shard naturally) and the accepted candidates are gathered to rank 0 as
+mapping records over RCCL - the path's only exchange step - inside the timed region.
+
+Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on the
+stream the kernel runs on; `cpu_baseline` times the reference's own AVX2 verifier
+(oracle/_ref, kind "reference") or, where that library is absent, our CPU restatement
+(kind "port") on a bounded sample of the same tasks on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from whisper_amd import api, synth  # noqa: E402
+
+M, K_ERR = 150, 12
+W = M + 2 * K_ERR
+# algorithmic VALU work of one S1 task = n_cols x (words x 40 + 8) 32-bit lane-ops
+WORDS = (M - 1) // 64 + 1
+N_COLS = W + 1
+LANE_OPS_PER_TASK = N_COLS * (WORDS * 40 + 8)
+# algorithmic bytes per task: 2-bit read + 2-bit window + 16 B task + 4 B result
+BYTES_PER_TASK = (M + 3) // 4 + (W + 3 + 3) // 4 + 16 + 4
+# MI355X: 256 CUs x 4 SIMD x 32 lanes/clk x 2.4 GHz (MI355X_MICROARCH.md: SIMD-32, 2400 MHz)
+PEAK_VALU_LANEOPS = 256 * 4 * 32 * 2.4e9
+PEAK_HBM = 8.0e12
+
+
+def env_int(name, default):
+    try:
+        return int(os.environ.get(name, default))
+    except ValueError:
+        return default
+
+
+def build_workload(device, n_tasks, genome_symbols, seed):
+    """Genome, reads and tasks of shape S1, generated on the GPU; returns host copies of
+    what the upload entry points take plus the device task array."""
+    codes = synth.make_genome(genome_symbols, seed=0xC0FFEE, device=device)
+    packed = synth.pack_nibbles(codes)
+    rd = synth.make_reads(codes, n_tasks, M, K_ERR, seed, chunk=1 << 17)
+    blob, off, lens = synth.pack_reads(rd["codes"], 0)
+    tasks = synth.distance_tasks(rd, M, K_ERR)
+    ref_size = codes.numel()
+    del codes, rd
+    return packed, ref_size, blob.cpu().numpy(), off.cpu().numpy().astype(np.uint64), \
+        lens.cpu().numpy().astype(np.uint32), tasks
+
+
+def cpu_baseline(packed_host, ref_size, blob, off, lens, tasks, sample, threads):
+    """Reference (or port) on the host cores, bounded sample of the same tasks."""
+    from oracle import bindings
+    t = tasks[:sample]
+    if bindings.have_reference():
+        try:
+            ref = bindings.Reference()
+            ref.distance(packed_host, ref_size, blob, off, lens, 0, t[:4096], -1, max_query_len=255,
+                         max_text_len=M + 2 * K_ERR + 2, nthreads=threads)
+            t0 = time.perf_counter()
+            rc, res = ref.distance(packed_host, ref_size, blob, off, lens, 0, t, -1,
+                                   max_query_len=255, max_text_len=M + 2 * K_ERR + 2,
+                                   nthreads=threads)
+            dt = time.perf_counter() - t0
+            assert rc == 0
+            return dict(value=len(t) / dt, unit="candidates/s", cores=threads, kind="reference",
+                        sample="first %d of the step's S1 tasks, LevMyers256<avx2> preprocess + "
+                               "dynamicProgramming per task, %d threads, %.2f s" % (len(t), threads, dt)), res
+        except Exception as e:  # e.g. no AVX2 on this host
+            sys.stderr.write("reference baseline unavailable (%s); timing the port\n" % e)
+    from concurrent.futures import ThreadPoolExecutor
+    orc = bindings.Oracle()
+    t = t[: max(1, sample // 4)]
+    chunks = np.array_split(np.arange(len(t)), threads * 4)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        parts = list(ex.map(lambda ix: orc.distance(packed_host, blob, off, lens, 0, t[ix], -1)[1], chunks))
+    dt = time.perf_counter() - t0
+    return dict(value=len(t) / dt, unit="candidates/s", cores=threads, kind="port",
+                sample="first %d of the step's S1 tasks, scalar C restatement, %d threads, %.2f s"
+                       % (len(t), threads, dt)), np.concatenate(parts)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--tasks", type=int, default=1 << 24, help="candidates per GPU and step")
+    ap.add_argument("--genome-symbols", type=int, default=1 << 28)
+    ap.add_argument("--cpu-sample", type=int, default=1 << 24)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = env_int("RANK", 0)
+    world = env_int("WORLD_SIZE", 1)
+    local = env_int("LOCAL_RANK", 0)
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        sys.stderr.write("bench.py: --gpus %d needs torch.distributed.run; running 1 rank\n" % args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the verification path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group("nccl", device_id=device)
+
+    n = args.tasks
+    packed, ref_size, blob, off, lens, tasks = build_workload(device, n, args.genome_symbols,
+                                                              seed=1234 + rank)
+    ctx = api.Context(packed, ref_size=ref_size, cur_offset=0, device=local)   # genome borrowed on device
+    ctx.set_max_text_len(M + 2 * K_ERR + 2)   # mapping_core.cpp:158-160
+    reads = ctx.upload_reads(blob, off, lens, api.READS_NIBBLE, orientations=3)
+    d_tasks = torch.from_numpy(tasks.view(np.uint8)).to(device)
+    d_results = torch.zeros(n * 2, dtype=torch.int32, device=device)
+    stream = torch.cuda.ExternalStream(ctx.stream(), device=device)
+    torch.cuda.synchronize()
+
+    def verify():
+        ctx.dynamic_programming_dev(reads, d_tasks, n, d_results, last_symbol=-1)
+
+    def gather_records():
+        """Mapping records of the accepted candidates -> rank 0 (results.cpp:161-217:
+        4 B position + 1 B direction/type/errors); the path's only exchange step."""
+        with torch.cuda.stream(stream):
+            r = d_results.view(n, 2)
+            ok = r[:, 0] <= K_ERR
+            rec = torch.stack([torch.nonzero(ok).squeeze(1).to(torch.int32), r[ok, 0]], dim=1)
+            cnt = torch.tensor([rec.shape[0]], device=device, dtype=torch.int64)
+            counts = [torch.zeros_like(cnt) for _ in range(world)]
+            dist.all_gather(counts, cnt)
+            mx = int(max(int(c) for c in counts))
+            pad = torch.zeros((mx, 2), dtype=torch.int32, device=device)
+            pad[: rec.shape[0]] = rec
+            out = [torch.zeros_like(pad) for _ in range(world)] if rank == 0 else None
+            dist.gather(pad, out, dst=0)
+        return sum(int(c) for c in counts)
+
+    def step():
+        verify()
+        if world > 1:
+            gather_records()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+           for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record(stream)
+        verify()
+        b.record(stream)
+        if world > 1:
+            gather_records()
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    flags = ctx.take_flags()
+    if flags:
+        raise SystemExit("device error flags 0x%x" % flags)
+
+    res = d_results.view(n, 2).cpu().numpy()
+    accepted = int((res[:, 0] <= K_ERR).sum())
+
+    if rank == 0:
+        value = n * world * args.steps / dt
+        out = {
+            "metric": "verified candidates/sec",
+            "value": value,
+            "unit": "candidates/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64",
+            "data": "synthetic",
+            "config": {
+                "workload": "S1: LevMyers256 distance verification, 150 bp reads, k = 12, W = 174 "
+                            "(sensitive stages of BASELINE configs[1]); %d candidates per GPU per step, "
+                            "%d-symbol random genome with N runs, 50%% true candidates with 0..15 edits, "
+                            "50%% reverse strand" % (n, args.genome_symbols),
+                "candidates_per_gpu": n,
+                "accepted_fraction": accepted / n,
+                "parallelism": "bins sharded over %d GPU(s), no data-path collective; "
+                               "accepted records gathered to rank 0 over RCCL" % world,
+            },
+            "gcups": value * M * N_COLS / 1e9,
+        }
+        a_ops = n * LANE_OPS_PER_TASK / (kernel_ms * 1e-3)
+        out["roofline"] = {
+            "bound": "valu",
+            "kernel": "myers_distance_kernel<3,256>",
+            "achieved": a_ops / 1e12,
+            "peak": PEAK_VALU_LANEOPS / 1e12,
+            "unit": "T lane-op/s (32-bit integer VALU)",
+            "frac": a_ops / PEAK_VALU_LANEOPS,
+            "kernel_ms": kernel_ms,
+            "traffic": None,
+            "hbm": {"achieved": n * BYTES_PER_TASK / (kernel_ms * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9,
+                    "unit": "GB/s", "frac": n * BYTES_PER_TASK / (kernel_ms * 1e-3) / PEAK_HBM},
+        }
+        tj = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tj):
+            try:
+                t = json.load(open(tj))
+                out["roofline"]["traffic"] = t["hbm_bytes_per_task"] * n
+            except Exception:
+                pass
+        if not args.no_cpu_baseline:
+            threads = max(1, min(16, os.cpu_count() or 1))
+            base, cpu_res = cpu_baseline(packed.cpu().numpy(), ref_size, blob, off, lens, tasks,
+                                         min(args.cpu_sample, n), threads)
+            # the checker also checks: the GPU results of the sample equal the CPU's
+            k = len(cpu_res)
+            same = bool((cpu_res["edit_distance"] == res[:k, 0].astype(np.uint32)).all() and
+                        (cpu_res["pos"] == res[:k, 1].astype(np.uint32)).all())
+            base["gpu_matches_cpu_on_sample"] = same
+            out["cpu_baseline"] = base
+            if not same:
+                out["parity_error"] = "GPU and CPU results differ on the baseline sample"
+        print(json.dumps(out))
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    reads.free()
+    ctx.destroy()
+
+
+if __name__ == "__main__":
+    main()

@@ -105,7 +105,9 @@ typedef struct wamd_dist_result {
 
 /* One CEditDist::LevDiag call (mapper/edit_dist.h:50-51, edit_dist.cpp:106-344):
  * LevDiag(pattern, pattern_len, position_in_text, fixed_left, fixed_right,
- *         max_mismatches, dir_gen_flag) -> errors, or max_mismatches + 1. */
+ *         max_mismatches, dir_gen_flag) -> errors, or max_mismatches + 1.
+ * The reference only calls it below lev_alg_thr (common/defs.h:108,
+ * mapping_core_sa.cpp:236-239): max_mismatches <= 6 here, reads nibble-packed. */
 typedef struct wamd_levdiag_task {
     uint32_t read_idx;
     uint32_t position_in_text;
@@ -155,8 +157,19 @@ WAMD_API int wamd_ctx_set_scoring(wamd_ctx* ctx, const wamd_scoring* scoring);
  * max_distance_in_ref above it fail with WAMD_ERR_TEXT_LEN.  Default 16384
  * (mapper/sam.cpp:190). */
 WAMD_API int wamd_ctx_set_max_text_len(wamd_ctx* ctx, uint32_t max_text_len);
+/* What SetReference's ref_size / cur_offset arguments change between stages
+ * (every CMappingCore is built with its stage's anchor offset, mapping_core.cpp:156);
+ * the genome itself stays where it is. */
+WAMD_API int wamd_ctx_set_reference_params(wamd_ctx* ctx, uint32_t ref_size, uint32_t cur_offset);
 WAMD_API void* wamd_ctx_stream(wamd_ctx* ctx);   /* the context's own hipStream_t */
 WAMD_API int wamd_ctx_synchronize(wamd_ctx* ctx);
+/* "*_dev" calls cannot return per-task errors: kernels OR them into a device word
+ * (bit 0 text length, 1 window out of the genome, 2 read index, 3 orientation not
+ * uploaded, 4 variant/length, 5 malformed task, 6 cigar_stride too small) and mark
+ * the task's result with edit_distance = 0xffffffff.  This call waits for `stream`
+ * (NULL = the context's), returns the word in *flags and clears it.  The
+ * host-pointer entry points do this themselves and turn it into a status. */
+WAMD_API int wamd_ctx_take_flags(wamd_ctx* ctx, void* stream, uint32_t* flags);
 
 /* ---- reads: replaces preprocess()/preprocessRawSeq() ------------------- *
  * Uploads n reads and builds, per read and orientation, the pattern-match
@@ -194,7 +207,10 @@ WAMD_API int wamd_levdiag_dev(wamd_ctx* ctx, const wamd_reads* reads,
  * dynamicProgramming + getExtCigar (+ refine_ext_cigar when refine != 0) as in
  * fill_cigar_with_lev (sam_matching.cpp:689-752) and find_pairs<LevMyers>
  * (sam_matching.cpp:401-426).  ext-CIGARs are written NUL-terminated at
- * cigars + i * cigar_stride; cigar_stride >= 2 * max read length + 2. */
+ * cigars + i * cigar_stride; cigar_stride is a multiple of 4 and at least
+ * 2 * (read length + max_ed) + 4 (the reference's pool slots are 5 * max_read_len,
+ * mapper.cpp:697).  Only reads uploaded as WAMD_READS_ASCII take the reference's
+ * copy_direct/convert_to_rev_comp symbol mapping (sam.cpp:2296-2347). */
 WAMD_API int wamd_align(wamd_ctx* ctx, const wamd_reads* reads, const wamd_dist_task* tasks,
                         uint32_t n, int last_symbol, int refine,
                         wamd_align_result* results, uint8_t* cigars, uint32_t cigar_stride);

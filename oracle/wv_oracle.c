@@ -646,7 +646,14 @@ int wo_align_batch(const uint8_t* genome, const uint8_t* reads, const uint64_t* 
                 read_codes[1 + q] = (uint8_t)(rev ? rc_code(nib(s, m - 1 - q)) : nib(s, q));
         }
         read_codes[0] = 0;
-        wo_ref_codes(ref_codes, genome, t->ref_pos, W);
+        /* The reference unpacks W symbols (ref_copy_direct, sam_matching.cpp:712).  The
+         * skewed variants can end in column W + 1 when the read fits one word
+         * (word_num = 0), and getExtCigar then reads tmp_ref_sequence[W]: a stale byte
+         * of an earlier call.  That value is not a function of the inputs, so it
+         * cannot be reproduced; oracle and HIP path use the genome symbol the DP
+         * itself compared against in that column.  Reads above 64 symbols never get
+         * there (end column <= W + 1 - word_num). */
+        wo_ref_codes(ref_codes, genome, t->ref_pos, W + 1);
         uint32_t events = 0, edist = r->edit_distance;
         double score = 0;
         r->begin_pos = wo_ext_cigar(matrix, words, ec, ref_codes, read_codes, r->end_pos,

@@ -1,0 +1,112 @@
+"""Generates tests/golden/*.npz: inputs and the outputs of the REFERENCE's own verifier
+objects (oracle/_ref/libwhisper_ref.so, built by oracle/Makefile from /root/reference/src)
+on small seeded workloads.  Only data is stored - no reference source or binary.
+
+    python tests/golden/make_golden.py        (needs /root/reference; run in the build container)
+
+The fixtures pin oracle/wv_oracle.c (tests/test_oracle_golden.py) and the HIP path
+(tests/test_gpu_golden.py) on machines that never see the reference.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import common  # noqa: E402
+from oracle import bindings  # noqa: E402
+from whisper_amd import synth  # noqa: E402
+
+GENOME_SYMBOLS = 1 << 16
+GENOME_SEED = 20211219
+
+# name, m, k, W, variant, encoding, last_symbol, n
+DISTANCE = [
+    ("dist_m150_k12_nibble", 150, 12, None, 0, 0, -1, 1500),
+    ("dist_m150_k12_ascii_last0", 150, 12, None, 0, 1, 0, 1500),
+    ("dist_m150_k12_ascii_last3", 150, 12, None, 0, 1, 3, 1000),
+    ("dist_m250_k17", 250, 17, None, 0, 0, -1, 1000),
+    ("dist_m100_k10", 100, 10, None, 0, 0, -1, 1000),
+    ("dist_m300_k20", 300, 20, None, 0, 0, -1, 600),
+    ("dist_m150_k26_w660", 150, 26, 660, 0, 1, 0, 600),
+    ("dist_m64_k6", 64, 6, None, 0, 0, -1, 600),
+    ("dist_m128_k8", 128, 8, None, 0, 0, -1, 600),
+    ("dist_m256_k10", 256, 10, None, 0, 0, -1, 600),
+    ("dist_m150_k12_m64forced", 150, 12, None, 1, 0, -1, 600),
+]
+# name, m, k, segment index, n
+LEVDIAG = [("lev_m150_k%d_seg%d" % (k, j), 150, k, j, 600)
+           for k in (1, 2, 5, 6) for j in range(k + 1)]
+# name, m, k, W, last_symbol, refine, n
+ALIGN = [
+    ("align_m150_k12", 150, 12, None, 0, 1, 1500),
+    ("align_m150_k12_norefine", 150, 12, None, 0, 0, 600),
+    ("align_m150_k13_w177", 150, 13, 177, 0, 1, 1000),
+    ("align_m150_k26_w660", 150, 26, 660, 0, 1, 600),
+    ("align_m250_k17", 250, 17, None, 0, 1, 600),
+    ("align_m250_k44_w700", 250, 44, 700, 0, 1, 400),
+    ("align_m100_k10", 100, 10, None, 0, 1, 600),
+    ("align_m300_k20", 300, 20, None, 0, 1, 400),
+]
+
+
+def main():
+    ref = bindings.Reference()
+    codes = synth.make_genome(GENOME_SYMBOLS, seed=GENOME_SEED)
+    packed = synth.pack_nibbles(codes).numpy()
+    ref_size = codes.numel()
+    np.savez_compressed(os.path.join(HERE, "genome.npz"), packed=packed,
+                        ref_size=np.uint32(ref_size), reference_version=ref.version())
+    seed = 1000
+    for name, m, k, W, variant, enc, last, n in DISTANCE:
+        seed += 1
+        rd = synth.make_reads(codes, n, m, k, seed)
+        blob, off, lens = common.host_reads(rd, enc)
+        tasks = synth.distance_tasks(rd, m, k, W, variant)
+        rc, res = ref.distance(packed, ref_size, blob, off, lens, enc, tasks, last)
+        assert rc == 0
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), kind="distance", blob=blob, off=off,
+                            lens=lens, encoding=enc, last_symbol=last, tasks=tasks, results=res)
+        print(name, "accepted", int((res["edit_distance"] <= k).sum()), "of", n)
+    for name, m, k, j, n in LEVDIAG:
+        seed += 1
+        fl, fr = common.stage_segments(m, k)[j]
+        rd = synth.make_reads(codes, n, m, k, seed, rc_frac=0.0, protect=(fl, fr))
+        blob, off, lens = common.host_reads(rd, 0)
+        tasks = synth.levdiag_tasks(rd, k, fl, fr, 0)
+        rc, res = ref.levdiag(packed, ref_size, 0, blob, off, lens, tasks)
+        assert rc == 0
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), kind="levdiag", blob=blob, off=off,
+                            lens=lens, tasks=tasks, results=res, cur_offset=0)
+        print(name, "accepted", int((res <= k).sum()), "of", n)
+    for name, m, k, W, last, refine, n in ALIGN:
+        seed += 1
+        rd = synth.make_reads(codes, n, m, k, seed)
+        blob, off, lens = common.host_reads(rd, 1)
+        tasks = synth.distance_tasks(rd, m, k, W, 0)
+        stride = 4 * ((2 * (m + k) + 8 + 3) // 4)
+        rc, res, cig = ref.align(packed, ref_size, blob, off, lens, 1, tasks, last, refine,
+                                 cigar_stride=stride)
+        assert rc == 0
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), kind="align", blob=blob, off=off,
+                            lens=lens, encoding=1, last_symbol=last, refine=refine, tasks=tasks,
+                            results=res, cigars=cig, cigar_stride=stride)
+        print(name, "ok", int(res["ok"].sum()), "refined", int(res["refined"].sum()), "of", n)
+    for name, m, k, n in [("align_refine_planted_m150", 150, 12, 400), ("align_refine_planted_m100", 100, 8, 200)]:
+        seed += 1
+        _, _, (blob, off, lens), tasks = common.planted_refine_workload(n, m, k, seed, gen=(codes, packed))
+        stride = 4 * ((2 * (m + k) + 8 + 3) // 4)
+        rc, res, cig = ref.align(packed, ref_size, blob, off, lens, 1, tasks, 0, 1, cigar_stride=stride)
+        assert rc == 0
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), kind="align", blob=blob, off=off,
+                            lens=lens, encoding=1, last_symbol=0, refine=1, tasks=tasks,
+                            results=res, cigars=cig, cigar_stride=stride)
+        print(name, "ok", int(res["ok"].sum()), "refined", int(res["refined"].sum()), "of", n)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,175 @@
+"""HIP path (through the C-ABI) vs the oracle on seeded tasks.  Bit-exact bar for edit
+distances, positions, CIGARs, events; affine scores are sums of the same doubles in the
+same order, so they are compared for equality as well (north_star allows 1e-5)."""
+import numpy as np
+import pytest
+
+import common
+from whisper_amd import api
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    codes, packed = common.genome()
+    c = api.Context(packed, ref_size=codes.numel(), cur_offset=0)
+    yield c
+    c.destroy()
+
+
+DIST_CASES = [
+    # m, k, W, variant, encoding, last_symbol
+    (150, 12, None, 0, 0, -1),      # S1: mapping stage, M256, 3 words
+    (150, 12, None, 0, 1, 0),       # post-processing flavour: ASCII, stale last_symbol 0
+    (150, 12, None, 0, 1, 3),
+    (250, 17, None, 0, 0, -1),      # S5: 4 words
+    (250, 7, None, 0, 0, -1),
+    (100, 10, None, 0, 0, -1),      # S7: M128
+    (64, 6, None, 0, 0, -1),
+    (65, 6, None, 0, 0, -1),
+    (128, 8, None, 0, 0, -1),
+    (192, 8, None, 0, 0, -1),
+    (193, 8, None, 0, 0, -1),
+    (255, 10, None, 0, 0, -1),
+    (256, 10, None, 0, 0, -1),      # first M64 length
+    (300, 20, None, 0, 0, -1),      # S7: M64, 5 words
+    (600, 30, None, 0, 0, -1),      # 10 words
+    (150, 12, None, 1, 0, -1),      # M64 forced on a short read
+    (150, 26, 660, 0, 1, 0),        # S3: mate rescue window
+    (30, 3, None, 0, 0, -1),
+]
+
+
+@pytest.mark.parametrize("m,k,W,variant,enc,last", DIST_CASES)
+def test_distance(ctx, oracle, m, k, W, variant, enc, last):
+    codes, packed, (blob, off, lens), tasks = common.distance_workload(m, k, 6000, seed=100 + m + k,
+                                                                      encoding=enc, W=W, variant=variant)
+    rc, want = oracle.distance(packed, blob, off, lens, enc, tasks, last)
+    assert rc == 0
+    reads = ctx.upload_reads(blob, off, lens, enc)
+    got = ctx.dynamic_programming(reads, tasks, last)
+    reads.free()
+    assert (want["edit_distance"] <= k).sum() > 1000      # the workload has accepted candidates
+    np.testing.assert_array_equal(got["edit_distance"], want["edit_distance"])
+    np.testing.assert_array_equal(got["pos"], want["pos"])
+
+
+def test_distance_mixed_lengths_and_empty(ctx, oracle):
+    import torch
+    codes, packed = common.genome()
+    g = torch.Generator().manual_seed(7)
+    lens_ = [1, 2, 63, 64, 65, 127, 128, 129, 150, 151, 191, 192, 193, 255]
+    reads_codes, tasks = [], []
+    for i, m in enumerate(lens_ * 20):
+        p = int(torch.randint(20000, 900000, (1,), generator=g))
+        r = codes[p:p + m].clone()
+        if m > 4:
+            r[int(torch.randint(0, m, (1,), generator=g))] = int(torch.randint(0, 4, (1,), generator=g))
+        r[r > 3] = 4
+        reads_codes.append(r)
+        k = min(5, m)
+        tasks.append((i, p - k, m + 2 * k, k, 0, 0))
+    blob, off, lens = common.mixed_reads(reads_codes, 0)
+    tasks = np.array(tasks, api.DIST_TASK)
+    rc, want = oracle.distance(packed, blob, off, lens, 0, tasks, -1)
+    reads = ctx.upload_reads(blob, off, lens, 0)
+    got = ctx.dynamic_programming(reads, tasks, -1)
+    np.testing.assert_array_equal(got, want)
+    # empty batch is a no-op
+    assert len(ctx.dynamic_programming(reads, tasks[:0], -1)) == 0
+    reads.free()
+
+
+def test_distance_errors(ctx):
+    codes, packed, (blob, off, lens), tasks = common.distance_workload(150, 12, 300, seed=3)
+    reads = ctx.upload_reads(blob, off, lens, 0)
+    bad = tasks.copy()
+    bad["max_distance_in_ref"][5] = 0                  # the reference throws runtime_error
+    with pytest.raises(api.WamdError) as e:
+        ctx.dynamic_programming(reads, bad)
+    assert e.value.status == 5
+    bad = tasks.copy()
+    bad["max_distance_in_ref"][7] = 20000              # above max_text_len (16384)
+    with pytest.raises(api.WamdError) as e:
+        ctx.dynamic_programming(reads, bad)
+    assert e.value.status == 5
+    bad = tasks.copy()
+    bad["ref_pos"][9] = codes.numel() - 10             # window leaves the genome
+    with pytest.raises(api.WamdError) as e:
+        ctx.dynamic_programming(reads, bad)
+    assert e.value.status == 6
+    # the context stays usable
+    got = ctx.dynamic_programming(reads, tasks)
+    assert (got["edit_distance"] != 0xFFFFFFFF).all()
+    reads.free()
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 5, 6])
+def test_levdiag_stage_segments(ctx, oracle, k):
+    for j, (fl, fr) in enumerate(common.stage_segments(150, k)):
+        codes, packed, (blob, off, lens), tasks = common.levdiag_workload(150, k, fl, fr, 3000,
+                                                                         seed=200 + 10 * k + j)
+        rc, want = oracle.levdiag(packed, codes.numel(), 0, blob, off, lens, tasks)
+        reads = ctx.upload_reads(blob, off, lens, 0, orientations=1)
+        got = ctx.lev_diag(reads, tasks)
+        reads.free()
+        assert (want <= k).sum() > 300
+        np.testing.assert_array_equal(got, want)
+
+
+def test_levdiag_rc_and_offset(ctx, oracle):
+    """dir_gen_flag = 0 window arithmetic (edit_dist.cpp:114-115) and a non-zero cur_offset."""
+    codes, packed, (blob, off, lens), tasks = common.levdiag_workload(100, 4, 40, 60, 3000, seed=77,
+                                                                     cur_offset=40)
+    ref_size = codes.numel()
+    t2 = tasks.copy()
+    half = len(t2) // 2
+    # rc flavour: g0 = ref_size - position - m + cur_offset - k  ==  p - k
+    p = tasks["position_in_text"][:half].astype(np.int64) - 40
+    t2["position_in_text"][:half] = (ref_size - p - 100 + 40).astype(np.uint32)
+    t2["dir_gen_flag"][:half] = 0
+    ctx.set_reference_params(ref_size, 40)
+    try:
+        rc, want = oracle.levdiag(packed, ref_size, 40, blob, off, lens, t2)
+        reads = ctx.upload_reads(blob, off, lens, 0, orientations=1)
+        got = ctx.lev_diag(reads, t2)
+        reads.free()
+    finally:
+        ctx.set_reference_params(ref_size, 0)
+    assert (want <= 4).sum() > 500
+    np.testing.assert_array_equal(got, want)
+
+
+ALIGN_CASES = [
+    # m, k, W, last_symbol, refine, variant
+    (150, 12, None, 0, 1, 0),
+    (150, 12, None, 0, 0, 0),
+    (150, 13, 177, 0, 1, 0),        # S4: fill_cigar_with_lev
+    (150, 26, 660, 0, 1, 0),        # S3: mate rescue
+    (250, 17, None, 0, 1, 0),
+    (250, 44, 700, 0, 1, 0),        # S6: ed above 30 -> 128-row band
+    (100, 10, None, 0, 1, 0),
+    (300, 20, None, 0, 1, 0),
+    (150, 12, None, 3, 1, 0),
+    (150, 12, None, 0, 1, 1),       # M64 on a short read
+    (60, 40, None, 0, 1, 0),        # ed > 30 with a single word: whole columns kept
+]
+
+
+@pytest.mark.parametrize("m,k,W,last,refine,variant", ALIGN_CASES)
+def test_align(ctx, oracle, m, k, W, last, refine, variant):
+    codes, packed, (blob, off, lens), tasks = common.distance_workload(m, k, 4000, seed=300 + m + k,
+                                                                      encoding=1, W=W, variant=variant)
+    stride = 4 * ((2 * (m + k) + 8 + 3) // 4)
+    rc, want, wcig = oracle.align(packed, blob, off, lens, 1, tasks, last, refine, cigar_stride=stride)
+    assert rc == 0
+    reads = ctx.upload_reads(blob, off, lens, 1)
+    got, gcig = ctx.align(reads, tasks, last, refine, cigar_stride=stride)
+    reads.free()
+    assert want["ok"].sum() > 500
+    for f in want.dtype.names:
+        np.testing.assert_array_equal(got[f], want[f], err_msg=f)
+    for i in np.nonzero(want["ok"])[0]:
+        n = want["cigar_len"][i]
+        assert bytes(gcig[i, :n + 1]) == bytes(wcig[i, :n + 1]), i

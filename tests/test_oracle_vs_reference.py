@@ -1,0 +1,64 @@
+"""The CPU restatement against the reference's own objects on fresh seeded tasks.
+Runs only where oracle/_ref/libwhisper_ref.so exists (built from /root/reference)."""
+import numpy as np
+import pytest
+
+import common
+
+SHAPES = [(150, 12, None, 0, 0, -1), (150, 12, None, 0, 1, 0), (150, 12, None, 0, 1, 2),
+          (250, 17, None, 0, 0, -1), (100, 10, None, 0, 0, -1), (300, 20, None, 0, 0, -1),
+          (64, 6, None, 0, 0, -1), (65, 6, None, 0, 0, -1), (127, 8, None, 0, 0, -1),
+          (128, 8, None, 0, 0, -1), (255, 10, None, 0, 0, -1), (256, 10, None, 0, 0, -1),
+          (150, 12, None, 1, 0, -1), (150, 26, 660, 0, 1, 0), (250, 44, 700, 0, 1, 0)]
+
+
+@pytest.mark.parametrize("m,k,W,variant,enc,last", SHAPES)
+def test_distance(oracle, reference, m, k, W, variant, enc, last):
+    codes, packed, (blob, off, lens), tasks = common.distance_workload(m, k, 8000, seed=11 * m + k,
+                                                                      encoding=enc, W=W, variant=variant)
+    rc1, a = oracle.distance(packed, blob, off, lens, enc, tasks, last)
+    rc2, b = reference.distance(packed, codes.numel(), blob, off, lens, enc, tasks, last)
+    assert rc1 == 0 and rc2 == 0
+    np.testing.assert_array_equal(a, b)
+
+
+def test_distance_text_len_error(oracle, reference):
+    codes, packed, (blob, off, lens), tasks = common.distance_workload(150, 12, 10, seed=5)
+    tasks["max_distance_in_ref"][3] = 0
+    rc1, _ = oracle.distance(packed, blob, off, lens, 0, tasks, -1)
+    rc2, _ = reference.distance(packed, codes.numel(), blob, off, lens, 0, tasks, -1)
+    assert rc1 == 5 and rc2 == 5      # WAMD_ERR_TEXT_LEN: the reference threw runtime_error
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 6])
+def test_levdiag(oracle, reference, k):
+    for j, (fl, fr) in enumerate(common.stage_segments(150, k)):
+        codes, packed, (blob, off, lens), tasks = common.levdiag_workload(150, k, fl, fr, 4000,
+                                                                         seed=500 + 10 * k + j)
+        _, a = oracle.levdiag(packed, codes.numel(), 0, blob, off, lens, tasks)
+        _, b = reference.levdiag(packed, codes.numel(), 0, blob, off, lens, tasks)
+        np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("m,k,W,last,refine", [(150, 12, None, 0, 1), (150, 13, 177, 0, 1),
+                                               (150, 26, 660, 0, 1), (250, 17, None, 0, 1),
+                                               (100, 10, None, 0, 0), (300, 20, None, 0, 1),
+                                               (150, 12, None, 3, 1)])
+def test_align(oracle, reference, m, k, W, last, refine):
+    codes, packed, (blob, off, lens), tasks = common.distance_workload(m, k, 4000, seed=7 * m + k,
+                                                                      encoding=1, W=W)
+    _, a, ca = oracle.align(packed, blob, off, lens, 1, tasks, last, refine)
+    _, b, cb = reference.align(packed, codes.numel(), blob, off, lens, 1, tasks, last, refine)
+    for f in a.dtype.names:
+        np.testing.assert_array_equal(a[f], b[f], err_msg=f)
+    assert (ca == cb).all()
+
+
+def test_align_planted_refinement(oracle, reference):
+    codes, packed, (blob, off, lens), tasks = common.planted_refine_workload(600, 150, 12, seed=99)
+    _, a, ca = oracle.align(packed, blob, off, lens, 1, tasks, 0, 1)
+    _, b, cb = reference.align(packed, codes.numel(), blob, off, lens, 1, tasks, 0, 1)
+    assert b["refined"].sum() > 100
+    for f in a.dtype.names:
+        np.testing.assert_array_equal(a[f], b[f], err_msg=f)
+    assert (ca == cb).all()

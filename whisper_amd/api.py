@@ -1,0 +1,223 @@
+"""Python binding of the C-ABI (include/whisper_amd.h) - the host-side mirror used by
+the parity tests and bench.py.  It loads whisper_amd/libwhisper_amd.so and nothing
+else: there is no CPU fallback, a missing library or GPU raises.
+
+Class names follow the reference objects whose calls are batched:
+  Context   <- setReference() of every verifier (LevMyers64.cpp:83-89, edit_dist.cpp:98-103)
+  Reads     <- preprocess() / preprocessRawSeq() (LevMyers64.cpp:167-220)
+  Context.dynamic_programming <- LevMyers::dynamicProgramming (LevMyers.h:51)
+  Context.lev_diag            <- CEditDist::LevDiag (edit_dist.h:50-51)
+  Context.align               <- dynamicProgramming + getExtCigar + refine_ext_cigar
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwhisper_amd.so")
+
+VARIANT_AUTO, VARIANT_M64, VARIANT_M128, VARIANT_M256 = 0, 1, 2, 3
+READS_NIBBLE, READS_ASCII = 0, 1
+FLAG_REV_COMP = 1
+LAST_SYMBOL_FROM_READ = -1
+
+DIST_TASK = np.dtype([("read_idx", "<u4"), ("ref_pos", "<u4"), ("max_distance_in_ref", "<u4"),
+                      ("max_ed", "<u2"), ("variant", "u1"), ("flags", "u1")])
+DIST_RESULT = np.dtype([("edit_distance", "<u4"), ("pos", "<u4")])
+LEVDIAG_TASK = np.dtype([("read_idx", "<u4"), ("position_in_text", "<u4"), ("fixed_left", "<u2"),
+                         ("fixed_right", "<u2"), ("max_mismatches", "<u2"),
+                         ("dir_gen_flag", "<u2")])
+ALIGN_RESULT = np.dtype([("affine_score", "<f8"), ("ok", "<u4"), ("edit_distance", "<u4"),
+                         ("end_pos", "<u4"), ("begin_pos", "<u4"), ("num_events", "<u4"),
+                         ("cigar_len", "<u4"), ("refined", "<u4"), ("reserved", "<u4")])
+
+STATUS = {0: "WAMD_OK", 1: "WAMD_ERR_INVALID_ARG", 2: "WAMD_ERR_HIP", 3: "WAMD_ERR_NO_DEVICE",
+          4: "WAMD_ERR_TOO_LONG", 5: "WAMD_ERR_TEXT_LEN", 6: "WAMD_ERR_RANGE",
+          7: "WAMD_ERR_NO_MEMORY", 8: "WAMD_ERR_CAPACITY"}
+
+EXPORTS = [
+    "wamd_version", "wamd_last_error", "wamd_device_count", "wamd_ctx_create",
+    "wamd_ctx_create_dev", "wamd_ctx_destroy", "wamd_ctx_set_scoring",
+    "wamd_ctx_set_max_text_len", "wamd_ctx_set_reference_params", "wamd_ctx_stream",
+    "wamd_ctx_synchronize", "wamd_ctx_take_flags", "wamd_reads_upload", "wamd_reads_free",
+    "wamd_reads_count", "wamd_verify_distance", "wamd_verify_distance_dev", "wamd_levdiag",
+    "wamd_levdiag_dev", "wamd_align", "wamd_align_dev", "wamd_align_workspace_bytes",
+]
+
+
+class Scoring(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("match", "mismatch", "gap_ins_open", "gap_ins_extend",
+                                           "gap_del_open", "gap_del_extend", "clipping")]
+
+
+class WamdError(RuntimeError):
+    def __init__(self, status, text):
+        super().__init__("%s: %s" % (STATUS.get(status, status), text))
+        self.status = status
+
+
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(
+                LIB_PATH + " is missing: build it with `make -C whisper_amd/csrc` "
+                "(or __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.wamd_version.restype = C.c_char_p
+        L.wamd_last_error.restype = C.c_char_p
+        L.wamd_ctx_stream.restype = C.c_void_p
+        L.wamd_align_workspace_bytes.restype = C.c_uint64
+        L.wamd_reads_count.restype = C.c_uint32
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise WamdError(rc, lib().wamd_last_error().decode())
+
+
+def _ptr(a):
+    """void* of a numpy array (host) or of a torch tensor (host or device)."""
+    if a is None:
+        return C.c_void_p(0)
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    return C.c_void_p(a.data_ptr())
+
+
+class Reads:
+    def __init__(self, ctx, data, offsets, lens, encoding, orientations=3):
+        self.ctx = ctx
+        data = np.ascontiguousarray(data, np.uint8)
+        offsets = np.ascontiguousarray(offsets, np.uint64)
+        lens = np.ascontiguousarray(lens, np.uint32)
+        self.n = len(lens)
+        self.encoding = encoding
+        self.max_len = int(lens.max()) if self.n else 0
+        self.h = C.c_void_p()
+        _check(lib().wamd_reads_upload(ctx.h, _ptr(data), _ptr(offsets), _ptr(lens),
+                                       C.c_uint32(self.n), C.c_int(encoding),
+                                       C.c_int(orientations), C.byref(self.h)))
+
+    def free(self):
+        if self.h:
+            lib().wamd_reads_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    def __init__(self, genome, ref_size=None, cur_offset=0, device=0):
+        """genome: packed reference bytes (numpy uint8 on the host, or a torch uint8 tensor
+        already on the device, which is then borrowed, not copied)."""
+        self.h = C.c_void_p()
+        self._keep = genome
+        if isinstance(genome, np.ndarray):
+            genome = np.ascontiguousarray(genome, np.uint8)
+            nbytes = genome.size
+            fn = lib().wamd_ctx_create
+        else:
+            nbytes = genome.numel()
+            fn = lib().wamd_ctx_create_dev
+        if ref_size is None:
+            ref_size = 2 * nbytes
+        _check(fn(C.c_int(device), _ptr(genome), C.c_uint64(nbytes), C.c_uint32(ref_size),
+                  C.c_uint32(cur_offset), C.byref(self.h)))
+
+    def destroy(self):
+        if self.h:
+            lib().wamd_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    def set_scoring(self, sc):
+        _check(lib().wamd_ctx_set_scoring(self.h, C.byref(sc)))
+
+    def set_max_text_len(self, v):
+        _check(lib().wamd_ctx_set_max_text_len(self.h, C.c_uint32(v)))
+
+    def set_reference_params(self, ref_size, cur_offset):
+        _check(lib().wamd_ctx_set_reference_params(self.h, C.c_uint32(ref_size),
+                                                   C.c_uint32(cur_offset)))
+
+    def stream(self):
+        return lib().wamd_ctx_stream(self.h)
+
+    def synchronize(self):
+        _check(lib().wamd_ctx_synchronize(self.h))
+
+    def take_flags(self, stream=None):
+        f = C.c_uint32(0)
+        _check(lib().wamd_ctx_take_flags(self.h, C.c_void_p(stream or 0), C.byref(f)))
+        return f.value
+
+    def upload_reads(self, data, offsets, lens, encoding, orientations=3):
+        return Reads(self, data, offsets, lens, encoding, orientations)
+
+    # ---- host-pointer entry points ------------------------------------------------------
+    def dynamic_programming(self, reads, tasks, last_symbol=LAST_SYMBOL_FROM_READ):
+        tasks = np.ascontiguousarray(tasks, DIST_TASK)
+        res = np.zeros(len(tasks), DIST_RESULT)
+        _check(lib().wamd_verify_distance(self.h, reads.h, _ptr(tasks), C.c_uint32(len(tasks)),
+                                          C.c_int(last_symbol), _ptr(res)))
+        return res
+
+    def lev_diag(self, reads, tasks):
+        tasks = np.ascontiguousarray(tasks, LEVDIAG_TASK)
+        res = np.zeros(len(tasks), np.uint32)
+        _check(lib().wamd_levdiag(self.h, reads.h, _ptr(tasks), C.c_uint32(len(tasks)), _ptr(res)))
+        return res
+
+    def align(self, reads, tasks, last_symbol=0, refine=1, cigar_stride=1024):
+        tasks = np.ascontiguousarray(tasks, DIST_TASK)
+        res = np.zeros(len(tasks), ALIGN_RESULT)
+        cig = np.zeros((len(tasks), cigar_stride), np.uint8)
+        _check(lib().wamd_align(self.h, reads.h, _ptr(tasks), C.c_uint32(len(tasks)),
+                                C.c_int(last_symbol), C.c_int(refine), _ptr(res), _ptr(cig),
+                                C.c_uint32(cigar_stride)))
+        return res, cig
+
+    # ---- device-pointer entry points (torch tensors on this device) ----------------------
+    def dynamic_programming_dev(self, reads, d_tasks, n, d_results, last_symbol=-1, stream=None):
+        _check(lib().wamd_verify_distance_dev(self.h, reads.h, _ptr(d_tasks), C.c_uint32(n),
+                                              C.c_int(last_symbol), _ptr(d_results),
+                                              C.c_void_p(stream or 0)))
+
+    def lev_diag_dev(self, reads, d_tasks, n, d_results, stream=None):
+        _check(lib().wamd_levdiag_dev(self.h, reads.h, _ptr(d_tasks), C.c_uint32(n),
+                                      _ptr(d_results), C.c_void_p(stream or 0)))
+
+    def align_workspace_bytes(self, reads, n):
+        return int(lib().wamd_align_workspace_bytes(reads.h, C.c_uint32(n)))
+
+    def align_dev(self, reads, d_tasks, n, d_results, d_cigars, cigar_stride, d_ws, ws_bytes,
+                  last_symbol=0, refine=1, stream=None):
+        _check(lib().wamd_align_dev(self.h, reads.h, _ptr(d_tasks), C.c_uint32(n),
+                                    C.c_int(last_symbol), C.c_int(refine), _ptr(d_results),
+                                    _ptr(d_cigars), C.c_uint32(cigar_stride), _ptr(d_ws),
+                                    C.c_uint64(ws_bytes), C.c_void_p(stream or 0)))
+
+
+def device_count():
+    return int(lib().wamd_device_count())
+
+
+def version():
+    return lib().wamd_version().decode()

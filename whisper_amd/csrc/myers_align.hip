@@ -1,0 +1,654 @@
+// myers_align.hip - verification WITH alignment (post-processing half of the path).
+//
+// Replaces dynamicProgramming + getExtCigar (+ refine_ext_cigar) as called from
+// fill_cigar_with_lev and find_pairs<LevMyers> (mapper/sam_matching.cpp:689-752,
+// 401-426): end position with the variant's tie-break, begin position, ext-CIGAR,
+// affine score, number of gap opens, optional short-indel refinement.
+//
+// The reference keeps the whole bit-vector matrix of the forward pass (5 vectors x
+// words x columns: 28 KB for 150 bp x 175 columns, over 100 KB for a mate-rescue
+// window) and walks back through it.  Spilling that per lane would make the kernel
+// HBM-bound, so the work is split:
+//
+//   pass 1  the distance kernel (myers_distance.hip): edit distance and end column,
+//           nothing stored.  Most post-processing calls stop here (not ok).
+//   pass 2  accepted tasks only, compacted into lists by how wide a band the
+//           traceback can touch.  The forward recurrence is re-run over just the
+//           last m + ed columns before the end column - cells on an optimal path
+//           to (m, pos), and their neighbours whenever those can be predecessors,
+//           have optimal paths that start inside that window, so their values are
+//           the true ones - and per column only a window of 2ed+3 rows around the
+//           end diagonal is kept, of VP, VN and D0 (24 B per column instead of
+//           40 B x words).  HP/HN at a cell follow from VP/VN of the column to the
+//           left.  The traceback records 2 bits per step; a forward replay writes
+//           the ext-CIGAR in its final order and spots the refinement pattern on
+//           the fly.  The affine score is summed during the backward walk in the
+//           reference's order (double adds only), so it is bit-identical.
+#include "wamd_internal.h"
+
+namespace wamd {
+
+enum { OP_NONE = 0, OP_M = 1, OP_X = 2, OP_D = 3, OP_I = 4 };
+enum { DIR_D = 0, DIR_H = 1, DIR_V = 2 };
+
+// buffered reader of 4-bit symbols from packed memory, either direction
+struct NibStream {
+    const uint32_t* base;
+    int64_t idx;
+    uint32_t last_dword;
+    uint32_t cur;
+    int64_t cur_dw;
+    __device__ __forceinline__ void load()
+    {
+        int64_t d = idx >> 3;
+        d = d < 0 ? 0 : (d > (int64_t)last_dword ? (int64_t)last_dword : d);
+        cur_dw = idx >> 3;
+        cur = nibble_swap(base[d]);
+    }
+    __device__ __forceinline__ void init(const void* b, int64_t start, uint32_t last)
+    {
+        base = (const uint32_t*)b;
+        idx = start;
+        last_dword = last;
+        load();
+    }
+    __device__ __forceinline__ uint32_t get(int step)
+    {
+        if ((idx >> 3) != cur_dw)
+            load();
+        const uint32_t s = (cur >> (4 * (uint32_t)(idx & 7))) & 15u;
+        idx += step;
+        return s;
+    }
+};
+
+// ---- pass 2a: sort accepted tasks into classes by band width ------------------------
+// class 0: 2ed+3 <= 64 rows, class 1: <= 128 rows, class 2: whole columns
+__global__ __launch_bounds__(256) void align_classify_kernel(
+    ReadsView rv, const wamd_dist_task* __restrict__ tasks, const wamd_dist_result* __restrict__ dist,
+    uint32_t n, wamd_align_result* __restrict__ results, uint8_t* __restrict__ cigars,
+    uint32_t cigar_stride, uint32_t* __restrict__ lists, uint32_t* __restrict__ counters)
+{
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n)
+        return;
+    const wamd_dist_result d = dist[gid];
+    wamd_align_result r;
+    r.affine_score = 0;
+    r.ok = 0;
+    r.edit_distance = d.edit_distance;
+    r.end_pos = d.pos;
+    r.begin_pos = 0;
+    r.num_events = 0;
+    r.cigar_len = 0;
+    r.refined = 0;
+    r.reserved = 0;
+    cigars[(uint64_t)gid * cigar_stride] = 0;
+    const bool error = d.edit_distance == RESULT_ERROR;
+    const bool ok = !error && d.edit_distance <= tasks[gid].max_ed;
+    if (!ok) {
+        if (error)
+            r.end_pos = 0;
+        results[gid] = r;
+        return;
+    }
+    const uint32_t rows = 2 * d.edit_distance + 3;
+    const uint32_t cls = rows <= 64 ? 0u : (rows <= 128 ? 1u : 2u);
+    const uint32_t slot = atomicAdd(counters + cls, 1u);
+    lists[(uint64_t)cls * n + slot] = gid;
+}
+
+template <int NW, int WW>
+__device__ __forceinline__ void extract_window(const uint64_t (&V)[NW], uint32_t off, uint64_t (&out)[WW])
+{
+    if constexpr (WW >= NW) {
+#pragma unroll
+        for (int w = 0; w < WW; ++w)
+            out[w] = w < NW ? V[w] : 0;
+    } else {
+        const uint32_t wq = off >> 6, sh = off & 63u;
+        uint64_t S[WW + 1];
+#pragma unroll
+        for (int t = 0; t <= WW; ++t) {
+            S[t] = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+                S[t] = (wq + t == (uint32_t)w) ? V[w] : S[t];
+        }
+#pragma unroll
+        for (int t = 0; t < WW; ++t)
+            out[t] = sh ? ((S[t] >> sh) | (S[t + 1] << (64u - sh))) : S[t];
+    }
+}
+
+struct AlignParams {
+    const wamd_dist_task* tasks;
+    const wamd_dist_result* dist;
+    const uint32_t* list;
+    const uint32_t* count;
+    wamd_align_result* results;
+    uint8_t* cigars;
+    uint64_t* slots;          // per block: [col][vec][ww][tid] then path dwords [q][tid]
+    uint64_t slot_words;      // 64-bit words per block
+    uint32_t* flags;
+    wamd_scoring sc;
+    uint32_t cigar_stride;
+    uint32_t max_cols;
+    uint32_t path_dwords;
+    int refine;
+    int ascii;
+};
+
+// ---- pass 2b: windowed recompute + traceback + forward emission --------------------
+template <int NW, int WW, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void align_traceback_kernel(GenomeView g, ReadsView rv, AlignParams ap)
+{
+    __shared__ uint64_t pm_lds[5 * NW * BLOCK];
+    constexpr int WWE = WW >= NW ? NW : WW;   // words actually kept per vector and column
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t count = *ap.count;
+    uint64_t* mat = ap.slots + (uint64_t)blockIdx.x * ap.slot_words;
+    uint32_t* path = reinterpret_cast<uint32_t*>(mat + (uint64_t)ap.max_cols * 3 * WWE * BLOCK);
+    uint64_t* my_pm = pm_lds + tid;
+    // decode = "ACGTNNXX" (LevMyers64.cpp:398), one byte per code
+    auto decode = [](uint32_t c) -> uint32_t { return (uint32_t)(0x58584e4e54474341ull >> (8 * (c & 7u))) & 0xffu; };
+
+    for (uint32_t base = blockIdx.x * BLOCK; base < count; base += gridDim.x * BLOCK) {
+        const uint32_t li = base + tid;
+        bool valid = li < count;
+        const uint32_t gid = valid ? ap.list[li] : 0;
+
+        uint32_t m = 1, wn = 0, ed = 0, end_pos = 1, ref_pos = 0, read_idx = 0, presence = 0;
+        bool rev = false;
+        if (valid) {
+            const wamd_dist_task task = ap.tasks[gid];
+            const wamd_dist_result d = ap.dist[gid];
+            read_idx = task.read_idx;
+            m = rv.lens[read_idx];
+            wn = (m - 1) / 64;
+            ed = d.edit_distance;
+            end_pos = d.pos;
+            ref_pos = task.ref_pos;
+            rev = task.flags & WAMD_TASK_FLAG_REV_COMP;
+        }
+        // first recomputed column (1-based) and number of columns
+        const uint32_t span = m + ed;
+        const uint32_t s_col = end_pos > span ? end_pos - span : 1u;
+        uint32_t n_cols = valid ? end_pos - s_col + 1 : 0;
+        if (valid && (n_cols > ap.max_cols || end_pos == 0)) {
+            // cannot happen for ed <= m; keep the kernel safe anyway
+            raise_flag(ap.flags, FLAG_ARG);
+            valid = false;
+            n_cols = 0;
+        }
+
+        // ---- pattern-match vectors -> LDS (as in the distance kernel) ---------------
+        {
+            const uint32_t slot = valid ? (uint32_t)(rev ? rv.slot_rc : rv.slot_direct) : 0;
+            const uint64_t* src = rv.pm + ((uint64_t)read_idx * rv.n_orient + slot) * 4 * rv.words;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int w = 0; w < NW; ++w)
+                    my_pm[(c * NW + w) * BLOCK] = (valid && (uint32_t)w <= wn) ? src[c * rv.words + w] : 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+                my_pm[(4 * NW + w) * BLOCK] = 0;
+            if (valid)
+                presence = rv.meta[(uint64_t)read_idx * rv.n_orient + slot] & 0xffffu;
+        }
+        const uint8_t* my_codes = rv.codes + rv.code_off[read_idx];
+
+        // ---- forward recompute over columns s_col .. end_pos --------------------------
+        // window of column j starts at row bit off(j) = max(0, m - 2 - ed - (end_pos - j))
+        uint64_t VP[NW], VN[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            VP[w] = ~0ull;
+            VN[w] = 0;
+        }
+        {
+            const uint32_t first_sym = ref_pos + s_col - 1;
+            const uint32_t shift = (first_sym & 7u) * 4u;
+            uint32_t didx = first_sym >> 3;
+            uint32_t d_lo = load_genome_dword(g, didx);
+            uint32_t d_hi = load_genome_dword(g, didx + 1);
+            uint32_t d_nx = load_genome_dword(g, didx + 2);
+            didx += 3;
+            for (uint32_t cb = 0; __any(cb < n_cols); cb += 8) {
+                const uint32_t syms = __builtin_amdgcn_alignbit(d_hi, d_lo, shift);
+                d_lo = d_hi;
+                d_hi = d_nx;
+                d_nx = load_genome_dword(g, didx++);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t ci = cb + u;           // 0-based recomputed column
+                    const uint32_t c = (syms >> (4 * u)) & 15u;
+                    const uint32_t row = c < 4u ? c : 4u;
+                    const bool act = ci < n_cols;
+                    const bool exotic = act && c >= 4u && ((presence >> c) & 1u);
+                    if (exotic) {
+                        for (uint32_t w = 0; w <= wn; ++w) {
+                            uint64_t eq = 0;
+                            const uint32_t lo = w * 64, hi = min(m, lo + 64);
+                            for (uint32_t i = lo; i < hi; ++i) {
+                                const uint32_t rcode = rev ? rc_code(packed_symbol(my_codes, m - 1 - i))
+                                                           : packed_symbol(my_codes, i);
+                                eq |= (uint64_t)(rcode == c) << (i - lo);
+                            }
+                            my_pm[(4 * NW + w) * BLOCK] = eq;
+                        }
+                    }
+                    const uint64_t* eqrow = my_pm + row * (NW * BLOCK);
+                    uint64_t hn_in = 0, hp_in = 0;
+                    uint64_t D0v[NW];
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) {
+                        uint64_t X = eqrow[w * BLOCK] | hn_in;
+                        const uint64_t vp = VP[w], vn = VN[w];
+                        const uint64_t D0 = (((X & vp) + vp) ^ vp) | X | vn;
+                        const uint64_t HP = vn | ~(D0 | vp);
+                        const uint64_t HN = D0 & vp;
+                        X = (HP << 1) | hp_in;
+                        VP[w] = (HN << 1) | ~(D0 | X) | hn_in;
+                        VN[w] = D0 & X;
+                        hn_in = HN >> 63;
+                        hp_in = HP >> 63;
+                        D0v[w] = D0;
+                    }
+                    if (exotic) {
+                        for (uint32_t w = 0; w <= wn; ++w)
+                            my_pm[(4 * NW + w) * BLOCK] = 0;
+                    }
+                    if (act) {
+                        const uint32_t j = s_col + ci;
+                        const int32_t o = (int32_t)m - 2 - (int32_t)ed - (int32_t)(end_pos - j);
+                        const uint32_t off = o > 0 ? (uint32_t)o : 0u;
+                        uint64_t wv[WWE];
+                        uint64_t* dst = mat + ((uint64_t)ci * 3 * WWE) * BLOCK + tid;
+                        extract_window<NW, WWE>(VP, off, wv);
+#pragma unroll
+                        for (int t = 0; t < WWE; ++t)
+                            dst[(0 * WWE + t) * BLOCK] = wv[t];
+                        extract_window<NW, WWE>(VN, off, wv);
+#pragma unroll
+                        for (int t = 0; t < WWE; ++t)
+                            dst[(1 * WWE + t) * BLOCK] = wv[t];
+                        extract_window<NW, WWE>(D0v, off, wv);
+#pragma unroll
+                        for (int t = 0; t < WWE; ++t)
+                            dst[(2 * WWE + t) * BLOCK] = wv[t];
+                    }
+                }
+            }
+        }
+
+        // ---- backward walk (getExtCigar, LevMyers64.cpp:413-513) ----------------------
+        // bit of vector `vec` in the window of column j (1-based) at row bit beta
+        auto mat_bit = [&](uint32_t j, int vec, uint32_t beta) -> uint32_t {
+            if (j < s_col)   // the column before the window: VP all ones, VN zero
+                return vec == 0 ? 1u : 0u;
+            const uint32_t ci = j - s_col;
+            uint32_t b = beta;
+            if constexpr (WW < NW) {
+                const int32_t o = (int32_t)m - 2 - (int32_t)ed - (int32_t)(end_pos - j);
+                b = beta - (o > 0 ? (uint32_t)o : 0u);
+            }
+            const uint64_t word = mat[(((uint64_t)ci * 3 + vec) * WWE + (b >> 6)) * BLOCK + tid];
+            return (uint32_t)(word >> (b & 63u)) & 1u;
+        };
+
+        uint32_t read_pos = valid ? m : 0, pos = valid ? end_pos : 0;
+        uint32_t c_val = ed, events = 0, nsteps = 0, pacc = 0;
+        int prev_dir = DIR_D;
+        bool in_indel = false;
+        double score = 0;
+        NibStream rs, gs;
+        // oriented read symbol q (0-based) = code[q], or rc(code[m-1-q]) when reversed
+        rs.init(my_codes, rev ? 0 : (int64_t)m - 1, (uint32_t)((m + 7) / 8 - 1));
+        gs.init(g.dwords, (int64_t)ref_pos + (int64_t)end_pos - 1, g.last_dword);
+        uint32_t rsym = 0, gsym = 0;       // symbols at read_pos and pos - 1
+        bool rsym_ok = false, gsym_ok = false;
+
+        auto read_code = [&](uint32_t raw) -> uint32_t {
+            uint32_t c = rev ? rc_code(raw) : raw;
+            // copy_direct / convert_to_rev_comp: anything but ACGT is N_read (sam.cpp:2296-2347)
+            return (ap.ascii && c > 3u) ? 4u : c;
+        };
+        auto push_step = [&](int dir) {
+            pacc |= (uint32_t)dir << (2 * (nsteps & 15u));
+            ++nsteps;
+            if ((nsteps & 15u) == 0) {
+                path[(uint64_t)(nsteps / 16 - 1) * BLOCK + tid] = pacc;
+                pacc = 0;
+            }
+        };
+
+        while (__any(read_pos && pos)) {
+            if (read_pos && pos) {
+                if (!rsym_ok) {
+                    rsym = read_code(rs.get(rev ? 1 : -1));
+                    rsym_ok = true;
+                }
+                if (!gsym_ok) {
+                    const uint32_t x = gs.get(-1);
+                    gsym = x > 5u ? 5u : x;   // ref_copy_direct, sam.cpp:2372-2374
+                    gsym_ok = true;
+                }
+                const uint32_t beta = read_pos - 1;
+                const uint32_t vp = mat_bit(pos, 0, beta), vn = mat_bit(pos, 1, beta);
+                const uint32_t d0 = mat_bit(pos, 2, beta);
+                const uint32_t vp_l = mat_bit(pos - 1, 0, beta), vn_l = mat_bit(pos - 1, 1, beta);
+                const uint32_t d_val = c_val - (d0 ? 0u : 1u);
+                const uint32_t v_val = c_val - vp + vn;
+                const uint32_t h_val = d_val + vp_l - vn_l;   // C(i, j-1) = C(i-1, j-1) + V(i, j-1)
+                const uint32_t mism = rsym != gsym;
+                const bool from_h = h_val + 1 == c_val;
+                const bool from_v = v_val + 1 == c_val;
+                const bool from_d = d_val + mism == c_val;
+                int dir;
+                if (from_d && (prev_dir == DIR_D || (prev_dir == DIR_H && !from_h) ||
+                               (prev_dir == DIR_V && !from_v)))
+                    dir = DIR_D;
+                else if (from_h && (prev_dir == DIR_H || (prev_dir == DIR_D && !from_d) ||
+                                    (prev_dir == DIR_V && !from_v)))
+                    dir = DIR_H;
+                else
+                    dir = DIR_V;
+                if (dir == DIR_D) {
+                    score += mism ? ap.sc.mismatch : ap.sc.match;
+                    in_indel = false;
+                    --read_pos;
+                    --pos;
+                    rsym_ok = gsym_ok = false;
+                    c_val = d_val;
+                } else if (dir == DIR_H) {
+                    if (in_indel) {
+                        score += ap.sc.gap_del_extend;
+                    } else {
+                        score += ap.sc.gap_del_open;
+                        ++events;
+                        in_indel = true;
+                    }
+                    --pos;
+                    gsym_ok = false;
+                    c_val = h_val;
+                } else {
+                    if (in_indel) {
+                        score += ap.sc.gap_ins_extend;
+                    } else {
+                        score += ap.sc.gap_ins_open;
+                        ++events;
+                        in_indel = true;
+                    }
+                    --read_pos;
+                    rsym_ok = false;
+                    c_val = v_val;
+                }
+                prev_dir = dir;
+                push_step(dir);
+            }
+        }
+        while (__any(read_pos)) {   // LevMyers64.cpp:498-513
+            if (read_pos) {
+                if (in_indel) {
+                    score += ap.sc.gap_ins_extend;
+                } else {
+                    score += ap.sc.gap_ins_open;
+                    ++events;
+                    in_indel = true;
+                }
+                --read_pos;
+                push_step(DIR_V);
+            }
+        }
+        if (nsteps & 15u)
+            path[(uint64_t)(nsteps / 16) * BLOCK + tid] = pacc;
+        const uint32_t begin_pos = pos;
+
+        // ---- forward replay: ext-CIGAR in final order + refinement -----------------------
+        uint32_t cur = 0, acc = 0, refined = 0;
+        uint8_t* slot = ap.cigars + (uint64_t)gid * ap.cigar_stride;
+        if (valid && (2 * nsteps + 4 > ap.cigar_stride)) {
+            raise_flag(ap.flags, FLAG_CIGAR);
+            valid = false;
+        }
+        auto emit = [&](uint32_t byte) {
+            acc |= byte << (8 * (cur & 3u));
+            ++cur;
+            if ((cur & 3u) == 0) {
+                *reinterpret_cast<uint32_t*>(slot + cur - 4) = acc;
+                acc = 0;
+            }
+        };
+        NibStream rf, gf;
+        rf.init(my_codes, rev ? (int64_t)m - 1 : 0, (uint32_t)((m + 7) / 8 - 1));
+        gf.init(g.dwords, (int64_t)ref_pos + begin_pos, g.last_dword);
+        uint32_t hist = 0, ref_hist = 0;
+        uint32_t pw = 0;
+        const uint32_t total = valid ? nsteps : 0;
+        for (uint32_t k = 0; __any(k < total); ++k) {
+            if (k < total) {
+                const uint32_t st = total - 1 - k;   // steps were recorded end to start
+                if (k == 0 || (st & 15u) == 15u)
+                    pw = path[(uint64_t)(st / 16) * BLOCK + tid];
+                const uint32_t dir = (pw >> (2 * (st & 15u))) & 3u;
+                uint32_t op, b0, b1 = 0;
+                if (dir == DIR_D) {
+                    const uint32_t r = read_code(rf.get(rev ? -1 : 1));
+                    const uint32_t x = gf.get(1);
+                    const uint32_t gsy = x > 5u ? 5u : x;
+                    ref_hist = (ref_hist << 4) | gsy;
+                    op = r == gsy ? OP_M : OP_X;
+                    b0 = r == gsy ? (uint32_t)'.' : decode(gsy);
+                } else if (dir == DIR_H) {
+                    const uint32_t x = gf.get(1);
+                    const uint32_t gsy = x > 5u ? 5u : x;
+                    ref_hist = (ref_hist << 4) | gsy;
+                    op = OP_D;
+                    b0 = '^';
+                    b1 = decode(gsy);
+                } else {
+                    const uint32_t r = read_code(rf.get(rev ? -1 : 1));
+                    op = OP_I;
+                    b0 = '#';
+                    b1 = decode(r);
+                }
+                // refine_ext_cigar (sam_matching.cpp:858-924): first ". ^x . . #y ." or
+                // ". #y . . ^x ." becomes three mismatches.  hist = the five previous ops.
+                if (ap.refine && !refined && op == OP_M) {
+                    const uint32_t pat_a = (OP_M << 12) | (OP_D << 9) | (OP_M << 6) | (OP_M << 3) | OP_I;
+                    const uint32_t pat_b = (OP_M << 12) | (OP_I << 9) | (OP_M << 6) | (OP_M << 3) | OP_D;
+                    // the current match has just pushed its own reference symbol
+                    if (hist == pat_a || hist == pat_b) {
+                        refined = 1;
+                        // make memory hold every byte emitted so far
+                        for (uint32_t q = cur & ~3u; q < cur; ++q)
+                            slot[q] = (uint8_t)(acc >> (8 * (q & 3u)));
+                        const uint32_t q0 = cur - 6;   // "^x..#y" / "#y..^x"
+                        slot[q0 + 0] = (uint8_t)decode((ref_hist >> 12) & 15u);
+                        slot[q0 + 1] = (uint8_t)decode((ref_hist >> 8) & 15u);
+                        slot[q0 + 2] = (uint8_t)decode((ref_hist >> 4) & 15u);
+                        cur = q0 + 3;
+                        acc = 0;
+                        for (uint32_t q = cur & ~3u; q < cur; ++q)
+                            acc |= (uint32_t)slot[q] << (8 * (q & 3u));
+                        ++events;
+                        score += 3 * ap.sc.mismatch;
+                        score -= ap.sc.gap_ins_open + ap.sc.gap_del_open;
+                    }
+                }
+                hist = ((hist << 3) | op) & 0x7fffu;
+                emit(b0);
+                if (op == OP_D || op == OP_I)
+                    emit(b1);
+            }
+        }
+        if (valid) {
+            const uint32_t len = cur;
+            emit(0);
+            if (cur & 3u)
+                *reinterpret_cast<uint32_t*>(slot + (cur & ~3u)) = acc;
+            wamd_align_result r;
+            r.affine_score = score;
+            r.ok = 1;
+            r.edit_distance = ed;
+            r.end_pos = end_pos;
+            r.begin_pos = begin_pos;
+            r.num_events = events;
+            r.cigar_len = len;
+            r.refined = refined;
+            r.reserved = 0;
+            ap.results[gid] = r;
+        } else if (li < count) {
+            wamd_align_result r{};
+            r.edit_distance = RESULT_ERROR;
+            ap.results[gid] = r;
+        }
+    }
+}
+
+// ---- host side -----------------------------------------------------------------------
+
+static inline uint64_t up256(uint64_t x) { return (x + 255) / 256 * 256; }
+
+struct AlignLayout {
+    uint64_t dist_off, lists_off, counters_off, slots_off, total;
+    uint64_t slot_bytes_max;   // one block of the widest class
+    uint32_t blocks;           // blocks of class 0 the slot region is sized for
+    uint32_t block;            // threads per block
+    uint32_t cols[3], wwe[3], path_dwords;
+};
+
+static AlignLayout align_layout(const wamd_reads* r, uint32_t n)
+{
+    AlignLayout L{};
+    const uint32_t nw = r->words ? r->words : 1;
+    const uint32_t m = r->max_len ? r->max_len : 1;
+    L.block = nw <= 4 ? 256 : 64;
+    L.path_dwords = (2 * m + 15) / 16 + 1;
+    // class 0: ed <= 30, class 1: ed <= 62, class 2: ed <= m
+    L.cols[0] = m + 30 + 2;
+    L.cols[1] = m + 62 + 2;
+    L.cols[2] = 2 * m + 2;
+    L.wwe[0] = nw < 1 ? nw : 1;
+    L.wwe[1] = nw < 2 ? nw : 2;
+    L.wwe[2] = nw;
+    uint64_t per_block[3];
+    L.slot_bytes_max = 0;
+    for (int c = 0; c < 3; ++c) {
+        per_block[c] = ((uint64_t)L.cols[c] * 3 * L.wwe[c] * 8 + (uint64_t)L.path_dwords * 4) * L.block;
+        per_block[c] = up256(per_block[c]);
+        L.slot_bytes_max = per_block[c] > L.slot_bytes_max ? per_block[c] : L.slot_bytes_max;
+    }
+    const uint32_t need_blocks = (n + L.block - 1) / L.block;
+    const uint32_t cap_blocks = 256 * 2 * (256 / L.block);   // two 256-lane blocks per CU
+    L.blocks = need_blocks < cap_blocks ? need_blocks : cap_blocks;
+    if (L.blocks == 0)
+        L.blocks = 1;
+    uint64_t region = (uint64_t)L.blocks * per_block[0];
+    if (region < L.slot_bytes_max)
+        region = L.slot_bytes_max;
+    L.dist_off = 0;
+    L.lists_off = up256((uint64_t)n * sizeof(wamd_dist_result));
+    L.counters_off = L.lists_off + up256((uint64_t)3 * n * sizeof(uint32_t));
+    L.slots_off = L.counters_off + 256;
+    L.total = L.slots_off + region;
+    return L;
+}
+
+uint64_t align_workspace_bytes(const wamd_reads* r, uint32_t n) { return align_layout(r, n).total; }
+
+template <int NW, int WW, int BLOCK>
+static int launch_tb(const GenomeView& g, const ReadsView& rv, AlignParams ap, uint32_t blocks, hipStream_t s)
+{
+    hipLaunchKernelGGL((align_traceback_kernel<NW, WW, BLOCK>), dim3(blocks), dim3(BLOCK), 0, s, g, rv, ap);
+    WAMD_HIP(hipGetLastError());
+    return WAMD_OK;
+}
+
+template <int NW, int BLOCK>
+static int launch_tb_class(int cls, const GenomeView& g, const ReadsView& rv, const AlignParams& ap,
+                           uint32_t blocks, hipStream_t s)
+{
+    if (cls == 0)
+        return launch_tb<NW, 1, BLOCK>(g, rv, ap, blocks, s);
+    if (cls == 1)
+        return launch_tb<NW, 2, BLOCK>(g, rv, ap, blocks, s);
+    return launch_tb<NW, NW, BLOCK>(g, rv, ap, blocks, s);
+}
+
+int launch_align(wamd_ctx* ctx, const wamd_reads* r, const wamd_dist_task* d_tasks, uint32_t n,
+                 int last_symbol, int refine, wamd_align_result* d_results, uint8_t* d_cigars,
+                 uint32_t cigar_stride, void* d_ws, uint64_t ws_bytes, hipStream_t s)
+{
+    WAMD_HIP(hipSetDevice(ctx->device));
+    if ((cigar_stride & 3u) || ((uintptr_t)d_cigars & 3u) || ((uintptr_t)d_ws & 255u)) {
+        set_error("wamd_align: cigar_stride must be a multiple of 4, buffers aligned (cigars 4, workspace 256)");
+        return WAMD_ERR_INVALID_ARG;
+    }
+    const AlignLayout L = align_layout(r, n);
+    if (ws_bytes < L.total)
+        return WAMD_ERR_INVALID_ARG;
+    char* ws = (char*)d_ws;
+    auto* d_dist = (wamd_dist_result*)(ws + L.dist_off);
+    auto* d_lists = (uint32_t*)(ws + L.lists_off);
+    auto* d_counters = (uint32_t*)(ws + L.counters_off);
+    auto* d_slots = (uint64_t*)(ws + L.slots_off);
+    const uint64_t region = L.total - L.slots_off;
+
+    WAMD_HIP(hipMemsetAsync(d_counters, 0, 256, s));
+    int rc = launch_distance(ctx, r, d_tasks, n, last_symbol, d_dist, s);
+    if (rc)
+        return rc;
+    const ReadsView rv = r->view();
+    const GenomeView g = genome_view(ctx);
+    hipLaunchKernelGGL(align_classify_kernel, dim3((n + 255) / 256), dim3(256), 0, s, rv, d_tasks, d_dist,
+                       n, d_results, d_cigars, cigar_stride, d_lists, d_counters);
+    WAMD_HIP(hipGetLastError());
+
+    for (int cls = 0; cls < 3; ++cls) {
+        AlignParams ap;
+        ap.tasks = d_tasks;
+        ap.dist = d_dist;
+        ap.list = d_lists + (uint64_t)cls * n;
+        ap.count = d_counters + cls;
+        ap.results = d_results;
+        ap.cigars = d_cigars;
+        ap.slots = d_slots;
+        ap.flags = ctx->d_flags;
+        ap.sc = ctx->scoring;
+        ap.cigar_stride = cigar_stride;
+        ap.max_cols = L.cols[cls];
+        ap.path_dwords = L.path_dwords;
+        ap.refine = refine;
+        ap.ascii = r->encoding == WAMD_READS_ASCII;
+        const uint64_t per_block =
+            up256(((uint64_t)L.cols[cls] * 3 * L.wwe[cls] * 8 + (uint64_t)L.path_dwords * 4) * L.block);
+        ap.slot_words = per_block / 8;
+        uint64_t blocks64 = region / per_block;
+        const uint32_t need = (n + L.block - 1) / L.block;
+        uint32_t blocks = (uint32_t)(blocks64 < need ? blocks64 : need);
+        if (blocks == 0)
+            blocks = 1;
+        switch (rv.words) {
+        case 1: rc = launch_tb_class<1, 256>(cls, g, rv, ap, blocks, s); break;
+        case 2: rc = launch_tb_class<2, 256>(cls, g, rv, ap, blocks, s); break;
+        case 3: rc = launch_tb_class<3, 256>(cls, g, rv, ap, blocks, s); break;
+        case 4: rc = launch_tb_class<4, 256>(cls, g, rv, ap, blocks, s); break;
+        default:
+            if (rv.words <= 8)
+                rc = launch_tb_class<8, 64>(cls, g, rv, ap, blocks, s);
+            else if (rv.words <= 16)
+                rc = launch_tb_class<16, 64>(cls, g, rv, ap, blocks, s);
+            else
+                rc = WAMD_ERR_TOO_LONG;
+        }
+        if (rc)
+            return rc;
+    }
+    return WAMD_OK;
+}
+
+} // namespace wamd

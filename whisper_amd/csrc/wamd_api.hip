@@ -1,0 +1,535 @@
+// wamd_api.hip - host side of the C-ABI (include/whisper_amd.h): contexts, read
+// batches, staging for the host-pointer entry points.  No verification happens
+// here and there is no CPU fallback: every entry point ends in a kernel launch.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "wamd_internal.h"
+
+namespace wamd {
+
+static thread_local char g_error[512] = "";
+
+void set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char* what, const char* file, int line)
+{
+    set_error("%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+    return WAMD_ERR_HIP;
+}
+
+GenomeView genome_view(const wamd_ctx* ctx)
+{
+    GenomeView g;
+    g.dwords = reinterpret_cast<const uint32_t*>(ctx->d_genome);
+    g.n_symbols = 2 * ctx->genome_bytes;
+    // an owned copy is padded to a multiple of 4 bytes plus 64; a borrowed one may
+    // only be read up to its last whole dword
+    uint64_t dwords = ctx->owns_genome ? (ctx->genome_bytes + 3) / 4 + 8 : ctx->genome_bytes / 4;
+    g.last_dword = dwords ? (uint32_t)(dwords - 1) : 0;
+    return g;
+}
+
+int ensure_stage(wamd_ctx* ctx, uint64_t dev_bytes, uint64_t host_bytes)
+{
+    if (dev_bytes > ctx->d_stage_bytes) {
+        if (ctx->d_stage)
+            WAMD_HIP(hipFree(ctx->d_stage));
+        ctx->d_stage = nullptr;
+        ctx->d_stage_bytes = 0;
+        uint64_t want = dev_bytes + dev_bytes / 4 + 4096;
+        WAMD_HIP(hipMalloc(&ctx->d_stage, want));
+        ctx->d_stage_bytes = want;
+    }
+    if (host_bytes > ctx->h_stage_bytes) {
+        if (ctx->h_stage)
+            WAMD_HIP(hipHostFree(ctx->h_stage));
+        ctx->h_stage = nullptr;
+        ctx->h_stage_bytes = 0;
+        uint64_t want = host_bytes + host_bytes / 4 + 4096;
+        WAMD_HIP(hipHostMalloc(&ctx->h_stage, want, hipHostMallocDefault));
+        ctx->h_stage_bytes = want;
+    }
+    return WAMD_OK;
+}
+
+int flags_to_status(uint32_t f)
+{
+    if (!f)
+        return WAMD_OK;
+    if (f & FLAG_TEXT_LEN) {
+        set_error("max_distance_in_ref == 0 or above max_text_len (the reference throws here)");
+        return WAMD_ERR_TEXT_LEN;
+    }
+    if (f & FLAG_RANGE) {
+        set_error("a task's window leaves the packed genome");
+        return WAMD_ERR_RANGE;
+    }
+    if (f & FLAG_VARIANT) {
+        set_error("a task's variant cannot hold its read, or the read is too long");
+        return WAMD_ERR_TOO_LONG;
+    }
+    set_error("malformed task (device flags 0x%x)", f);
+    return WAMD_ERR_INVALID_ARG;
+}
+
+static int fetch_flags(wamd_ctx* ctx, hipStream_t s, uint32_t* out)
+{
+    WAMD_HIP(hipMemcpyAsync(ctx->h_flags, ctx->d_flags, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    WAMD_HIP(hipMemsetAsync(ctx->d_flags, 0, sizeof(uint32_t), s));
+    WAMD_HIP(hipStreamSynchronize(s));
+    *out = *ctx->h_flags;
+    return WAMD_OK;
+}
+
+} // namespace wamd
+
+using namespace wamd;
+
+wamd::ReadsView wamd_reads::view() const
+{
+    ReadsView v;
+    v.codes = d_codes;
+    v.code_off = d_code_off;
+    v.lens = d_lens;
+    v.pm = d_pm;
+    v.meta = d_meta;
+    v.n = n;
+    v.words = words;
+    v.n_orient = (orientations == 3) ? 2 : 1;
+    v.slot_direct = (orientations & 1) ? 0 : -1;
+    v.slot_rc = (orientations & 2) ? ((orientations & 1) ? 1 : 0) : -1;
+    return v;
+}
+
+extern "C" {
+
+const char* wamd_version(void) { return "whisper_amd 0.1 (gfx950; verification path of Whisper 2.0.2)"; }
+
+const char* wamd_last_error(void) { return g_error; }
+
+int wamd_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+static int ctx_create_common(int device, const uint8_t* genome, bool on_device, uint64_t genome_bytes,
+                             uint32_t ref_size, uint32_t cur_offset, wamd_ctx** out)
+{
+    if (!out || !genome || genome_bytes == 0) {
+        set_error("wamd_ctx_create: null or empty genome");
+        return WAMD_ERR_INVALID_ARG;
+    }
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
+        set_error("no HIP device available: this library has no CPU path");
+        return WAMD_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) {
+        set_error("device %d out of range (%d visible)", device, n);
+        return WAMD_ERR_INVALID_ARG;
+    }
+    WAMD_HIP(hipSetDevice(device));
+    wamd_ctx* c = new wamd_ctx();
+    memset(c, 0, sizeof(*c));
+    c->device = device;
+    c->genome_bytes = genome_bytes;
+    c->ref_size = ref_size;
+    c->cur_offset = cur_offset;
+    c->max_text_len = 16384;   // mapper/sam.cpp:190
+    c->scoring = wamd_scoring{1.0, -5.0, -5.0, -0.4, -5.0, -0.4, -6.0};   // mapper/params.h:145-154
+    int rc = WAMD_OK;
+    do {
+        hipError_t e;
+        if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+            rc = hip_fail(e, "hipStreamCreate", __FILE__, __LINE__);
+            break;
+        }
+        if (on_device) {
+            c->d_genome = const_cast<uint8_t*>(genome);
+            c->owns_genome = false;
+        } else {
+            uint64_t padded = (genome_bytes + 3) / 4 * 4 + 64;
+            if ((e = hipMalloc(&c->d_genome, padded)) != hipSuccess) {
+                rc = hip_fail(e, "hipMalloc(genome)", __FILE__, __LINE__);
+                break;
+            }
+            c->owns_genome = true;
+            // pad with 0xff: code 15 never matches anything (index/ref_seq.cpp:148-154)
+            if ((e = hipMemsetAsync(c->d_genome + genome_bytes / 4 * 4, 0xff,
+                                    padded - genome_bytes / 4 * 4, c->stream)) != hipSuccess ||
+                (e = hipMemcpyAsync(c->d_genome, genome, genome_bytes, hipMemcpyHostToDevice,
+                                    c->stream)) != hipSuccess) {
+                rc = hip_fail(e, "genome upload", __FILE__, __LINE__);
+                break;
+            }
+        }
+        if ((e = hipMalloc(&c->d_flags, sizeof(uint32_t))) != hipSuccess ||
+            (e = hipHostMalloc(&c->h_flags, sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess ||
+            (e = hipMemsetAsync(c->d_flags, 0, sizeof(uint32_t), c->stream)) != hipSuccess ||
+            (e = hipStreamSynchronize(c->stream)) != hipSuccess) {
+            rc = hip_fail(e, "context buffers", __FILE__, __LINE__);
+            break;
+        }
+    } while (0);
+    if (rc != WAMD_OK) {
+        wamd_ctx_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return WAMD_OK;
+}
+
+int wamd_ctx_create(int device, const uint8_t* genome, uint64_t genome_bytes, uint32_t ref_size,
+                    uint32_t cur_offset, wamd_ctx** out)
+{
+    return ctx_create_common(device, genome, false, genome_bytes, ref_size, cur_offset, out);
+}
+
+int wamd_ctx_create_dev(int device, const uint8_t* d_genome, uint64_t genome_bytes,
+                        uint32_t ref_size, uint32_t cur_offset, wamd_ctx** out)
+{
+    return ctx_create_common(device, d_genome, true, genome_bytes, ref_size, cur_offset, out);
+}
+
+int wamd_ctx_destroy(wamd_ctx* c)
+{
+    if (!c)
+        return WAMD_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream)
+        (void)hipStreamSynchronize(c->stream);
+    if (c->owns_genome && c->d_genome)
+        (void)hipFree(c->d_genome);
+    if (c->d_flags)
+        (void)hipFree(c->d_flags);
+    if (c->h_flags)
+        (void)hipHostFree(c->h_flags);
+    if (c->d_stage)
+        (void)hipFree(c->d_stage);
+    if (c->h_stage)
+        (void)hipHostFree(c->h_stage);
+    if (c->stream)
+        (void)hipStreamDestroy(c->stream);
+    delete c;
+    return WAMD_OK;
+}
+
+int wamd_ctx_set_scoring(wamd_ctx* ctx, const wamd_scoring* s)
+{
+    if (!ctx || !s)
+        return WAMD_ERR_INVALID_ARG;
+    ctx->scoring = *s;
+    return WAMD_OK;
+}
+
+int wamd_ctx_set_max_text_len(wamd_ctx* ctx, uint32_t max_text_len)
+{
+    if (!ctx || max_text_len < 10)   // LevMyers64.cpp:124-125 exits below 10
+        return WAMD_ERR_INVALID_ARG;
+    ctx->max_text_len = max_text_len;
+    return WAMD_OK;
+}
+
+int wamd_ctx_set_reference_params(wamd_ctx* ctx, uint32_t ref_size, uint32_t cur_offset)
+{
+    if (!ctx)
+        return WAMD_ERR_INVALID_ARG;
+    ctx->ref_size = ref_size;
+    ctx->cur_offset = cur_offset;
+    return WAMD_OK;
+}
+
+void* wamd_ctx_stream(wamd_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int wamd_ctx_synchronize(wamd_ctx* ctx)
+{
+    if (!ctx)
+        return WAMD_ERR_INVALID_ARG;
+    WAMD_HIP(hipSetDevice(ctx->device));
+    WAMD_HIP(hipStreamSynchronize(ctx->stream));
+    return WAMD_OK;
+}
+
+int wamd_ctx_take_flags(wamd_ctx* ctx, void* stream, uint32_t* flags)
+{
+    if (!ctx || !flags)
+        return WAMD_ERR_INVALID_ARG;
+    WAMD_HIP(hipSetDevice(ctx->device));
+    return fetch_flags(ctx, stream ? (hipStream_t)stream : ctx->stream, flags);
+}
+
+// ---- reads -----------------------------------------------------------------------
+
+int wamd_reads_upload(wamd_ctx* ctx, const uint8_t* data, const uint64_t* offsets,
+                      const uint32_t* lens, uint32_t n, int encoding, int orientations,
+                      wamd_reads** out)
+{
+    if (!ctx || !out || (n && (!data || !offsets || !lens)) ||
+        (encoding != WAMD_READS_NIBBLE && encoding != WAMD_READS_ASCII) || orientations < 1 ||
+        orientations > 3) {
+        set_error("wamd_reads_upload: bad argument");
+        return WAMD_ERR_INVALID_ARG;
+    }
+    *out = nullptr;
+    WAMD_HIP(hipSetDevice(ctx->device));
+
+    uint32_t max_len = 0;
+    uint64_t raw_end = 0;
+    std::vector<uint64_t> code_off((size_t)n + 1);
+    uint64_t acc = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (lens[i] == 0 || lens[i] > WAMD_MAX_READ_LEN) {
+            set_error("read %u has length %u (allowed 1..%u)", i, lens[i], WAMD_MAX_READ_LEN);
+            return WAMD_ERR_TOO_LONG;
+        }
+        max_len = lens[i] > max_len ? lens[i] : max_len;
+        uint64_t raw_bytes = encoding == WAMD_READS_NIBBLE ? (lens[i] + 1) / 2 : lens[i];
+        raw_end = offsets[i] + raw_bytes > raw_end ? offsets[i] + raw_bytes : raw_end;
+        code_off[i] = acc;
+        acc += ((uint64_t)(lens[i] + 1) / 2 + 3) / 4 * 4;
+    }
+    code_off[n] = acc;
+
+    wamd_reads* r = new wamd_reads();
+    memset(r, 0, sizeof(*r));
+    r->ctx = ctx;
+    r->n = n;
+    r->encoding = encoding;
+    r->orientations = orientations;
+    r->max_len = max_len;
+    r->words = max_len ? (max_len - 1) / 64 + 1 : 1;
+    r->codes_bytes = acc;
+    const uint32_t n_orient = orientations == 3 ? 2 : 1;
+    int rc = WAMD_OK;
+    uint8_t* d_raw = nullptr;
+    uint64_t* d_raw_off = nullptr;
+    do {
+        hipError_t e;
+        hipStream_t s = ctx->stream;
+        const uint64_t pm_bytes = (uint64_t)n * n_orient * 4 * r->words * sizeof(uint64_t);
+        if ((e = hipMalloc(&r->d_codes, acc + 64)) != hipSuccess ||
+            (e = hipMalloc(&r->d_code_off, ((size_t)n + 1) * sizeof(uint64_t))) != hipSuccess ||
+            (e = hipMalloc(&r->d_lens, ((size_t)n + 1) * sizeof(uint32_t))) != hipSuccess ||
+            (e = hipMalloc(&r->d_pm, pm_bytes + 64)) != hipSuccess ||
+            (e = hipMalloc(&r->d_meta, ((size_t)n * n_orient + 1) * sizeof(uint32_t))) != hipSuccess ||
+            (e = hipMalloc(&d_raw, raw_end + 64)) != hipSuccess ||
+            (e = hipMalloc(&d_raw_off, ((size_t)n + 1) * sizeof(uint64_t))) != hipSuccess) {
+            rc = hip_fail(e, "hipMalloc(reads)", __FILE__, __LINE__);
+            break;
+        }
+        if (n == 0)
+            break;
+        if ((e = hipMemcpyAsync(d_raw, data, raw_end, hipMemcpyHostToDevice, s)) != hipSuccess ||
+            (e = hipMemcpyAsync(d_raw_off, offsets, (size_t)n * sizeof(uint64_t),
+                                hipMemcpyHostToDevice, s)) != hipSuccess ||
+            (e = hipMemcpyAsync(r->d_code_off, code_off.data(), ((size_t)n + 1) * sizeof(uint64_t),
+                                hipMemcpyHostToDevice, s)) != hipSuccess ||
+            (e = hipMemcpyAsync(r->d_lens, lens, (size_t)n * sizeof(uint32_t),
+                                hipMemcpyHostToDevice, s)) != hipSuccess ||
+            (e = hipMemsetAsync(r->d_meta, 0, (size_t)n * n_orient * sizeof(uint32_t), s)) !=
+                hipSuccess) {
+            rc = hip_fail(e, "reads upload", __FILE__, __LINE__);
+            break;
+        }
+        rc = launch_reads_prepare(ctx, r, d_raw, d_raw_off, s);
+        if (rc != WAMD_OK)
+            break;
+        if ((e = hipStreamSynchronize(s)) != hipSuccess) {
+            rc = hip_fail(e, "reads prepare", __FILE__, __LINE__);
+            break;
+        }
+    } while (0);
+    if (d_raw)
+        (void)hipFree(d_raw);
+    if (d_raw_off)
+        (void)hipFree(d_raw_off);
+    if (rc != WAMD_OK) {
+        wamd_reads_free(r);
+        return rc;
+    }
+    *out = r;
+    return WAMD_OK;
+}
+
+int wamd_reads_free(wamd_reads* r)
+{
+    if (!r)
+        return WAMD_OK;
+    (void)hipSetDevice(r->ctx->device);
+    if (r->d_codes) (void)hipFree(r->d_codes);
+    if (r->d_code_off) (void)hipFree(r->d_code_off);
+    if (r->d_lens) (void)hipFree(r->d_lens);
+    if (r->d_pm) (void)hipFree(r->d_pm);
+    if (r->d_meta) (void)hipFree(r->d_meta);
+    delete r;
+    return WAMD_OK;
+}
+
+uint32_t wamd_reads_count(const wamd_reads* r) { return r ? r->n : 0; }
+
+// ---- host-pointer entry points: stage in, launch, stage out ----------------------
+
+static int check_batch(wamd_ctx* ctx, const wamd_reads* reads, const void* a, const void* b,
+                       const char* who)
+{
+    if (!ctx || !reads || reads->ctx != ctx || !a || !b) {
+        set_error("%s: null argument or reads of another context", who);
+        return WAMD_ERR_INVALID_ARG;
+    }
+    return WAMD_OK;
+}
+
+int wamd_verify_distance_dev(wamd_ctx* ctx, const wamd_reads* reads, const wamd_dist_task* d_tasks,
+                             uint32_t n, int last_symbol, wamd_dist_result* d_results, void* stream)
+{
+    if (n == 0)
+        return WAMD_OK;
+    int rc = check_batch(ctx, reads, d_tasks, d_results, "wamd_verify_distance_dev");
+    if (rc)
+        return rc;
+    if (last_symbol < -1 || last_symbol > 15)
+        return WAMD_ERR_INVALID_ARG;
+    return launch_distance(ctx, reads, d_tasks, n, last_symbol, d_results,
+                           stream ? (hipStream_t)stream : ctx->stream);
+}
+
+int wamd_verify_distance(wamd_ctx* ctx, const wamd_reads* reads, const wamd_dist_task* tasks,
+                         uint32_t n, int last_symbol, wamd_dist_result* results)
+{
+    if (n == 0)
+        return WAMD_OK;
+    int rc = check_batch(ctx, reads, tasks, results, "wamd_verify_distance");
+    if (rc)
+        return rc;
+    WAMD_HIP(hipSetDevice(ctx->device));
+    const uint64_t tb = (uint64_t)n * sizeof(wamd_dist_task), rb = (uint64_t)n * sizeof(wamd_dist_result);
+    rc = ensure_stage(ctx, tb + rb, 0);
+    if (rc)
+        return rc;
+    auto* d_tasks = (wamd_dist_task*)ctx->d_stage;
+    auto* d_res = (wamd_dist_result*)((char*)ctx->d_stage + tb);
+    hipStream_t s = ctx->stream;
+    WAMD_HIP(hipMemcpyAsync(d_tasks, tasks, tb, hipMemcpyHostToDevice, s));
+    rc = wamd_verify_distance_dev(ctx, reads, d_tasks, n, last_symbol, d_res, s);
+    if (rc)
+        return rc;
+    WAMD_HIP(hipMemcpyAsync(results, d_res, rb, hipMemcpyDeviceToHost, s));
+    uint32_t flags = 0;
+    rc = fetch_flags(ctx, s, &flags);
+    return rc ? rc : flags_to_status(flags);
+}
+
+int wamd_levdiag_dev(wamd_ctx* ctx, const wamd_reads* reads, const wamd_levdiag_task* d_tasks,
+                     uint32_t n, uint32_t* d_results, void* stream)
+{
+    if (n == 0)
+        return WAMD_OK;
+    int rc = check_batch(ctx, reads, d_tasks, d_results, "wamd_levdiag_dev");
+    if (rc)
+        return rc;
+    return launch_levdiag(ctx, reads, d_tasks, n, d_results, stream ? (hipStream_t)stream : ctx->stream);
+}
+
+int wamd_levdiag(wamd_ctx* ctx, const wamd_reads* reads, const wamd_levdiag_task* tasks, uint32_t n,
+                 uint32_t* results)
+{
+    if (n == 0)
+        return WAMD_OK;
+    int rc = check_batch(ctx, reads, tasks, results, "wamd_levdiag");
+    if (rc)
+        return rc;
+    WAMD_HIP(hipSetDevice(ctx->device));
+    const uint64_t tb = (uint64_t)n * sizeof(wamd_levdiag_task), rb = (uint64_t)n * sizeof(uint32_t);
+    rc = ensure_stage(ctx, tb + rb, 0);
+    if (rc)
+        return rc;
+    auto* d_tasks = (wamd_levdiag_task*)ctx->d_stage;
+    auto* d_res = (uint32_t*)((char*)ctx->d_stage + tb);
+    hipStream_t s = ctx->stream;
+    WAMD_HIP(hipMemcpyAsync(d_tasks, tasks, tb, hipMemcpyHostToDevice, s));
+    rc = wamd_levdiag_dev(ctx, reads, d_tasks, n, d_res, s);
+    if (rc)
+        return rc;
+    WAMD_HIP(hipMemcpyAsync(results, d_res, rb, hipMemcpyDeviceToHost, s));
+    uint32_t flags = 0;
+    rc = fetch_flags(ctx, s, &flags);
+    return rc ? rc : flags_to_status(flags);
+}
+
+uint64_t wamd_align_workspace_bytes(const wamd_reads* reads, uint32_t n)
+{
+    return reads ? align_workspace_bytes(reads, n) : 0;
+}
+
+int wamd_align_dev(wamd_ctx* ctx, const wamd_reads* reads, const wamd_dist_task* d_tasks, uint32_t n,
+                   int last_symbol, int refine, wamd_align_result* d_results, uint8_t* d_cigars,
+                   uint32_t cigar_stride, void* d_workspace, uint64_t workspace_bytes, void* stream)
+{
+    if (n == 0)
+        return WAMD_OK;
+    int rc = check_batch(ctx, reads, d_tasks, d_results, "wamd_align_dev");
+    if (rc)
+        return rc;
+    if (!d_cigars || !d_workspace || workspace_bytes < align_workspace_bytes(reads, n) ||
+        cigar_stride < 16 || last_symbol < -1 || last_symbol > 15) {
+        set_error("wamd_align_dev: missing buffer, workspace too small or bad argument");
+        return WAMD_ERR_INVALID_ARG;
+    }
+    return launch_align(ctx, reads, d_tasks, n, last_symbol, refine, d_results, d_cigars,
+                        cigar_stride, d_workspace, workspace_bytes,
+                        stream ? (hipStream_t)stream : ctx->stream);
+}
+
+int wamd_align(wamd_ctx* ctx, const wamd_reads* reads, const wamd_dist_task* tasks, uint32_t n,
+               int last_symbol, int refine, wamd_align_result* results, uint8_t* cigars,
+               uint32_t cigar_stride)
+{
+    if (n == 0)
+        return WAMD_OK;
+    int rc = check_batch(ctx, reads, tasks, results, "wamd_align");
+    if (rc)
+        return rc;
+    if (!cigars)
+        return WAMD_ERR_INVALID_ARG;
+    WAMD_HIP(hipSetDevice(ctx->device));
+    const uint64_t tb = (uint64_t)n * sizeof(wamd_dist_task);
+    const uint64_t rb = (uint64_t)n * sizeof(wamd_align_result);
+    const uint64_t cb = (uint64_t)n * cigar_stride;
+    const uint64_t wb = align_workspace_bytes(reads, n);
+    auto up = [](uint64_t x) { return (x + 255) / 256 * 256; };
+    rc = ensure_stage(ctx, up(tb) + up(rb) + up(cb) + up(wb), 0);
+    if (rc)
+        return rc;
+    char* base = (char*)ctx->d_stage;
+    auto* d_tasks = (wamd_dist_task*)base;
+    auto* d_res = (wamd_align_result*)(base + up(tb));
+    auto* d_cig = (uint8_t*)(base + up(tb) + up(rb));
+    void* d_ws = base + up(tb) + up(rb) + up(cb);
+    hipStream_t s = ctx->stream;
+    WAMD_HIP(hipMemcpyAsync(d_tasks, tasks, tb, hipMemcpyHostToDevice, s));
+    rc = wamd_align_dev(ctx, reads, d_tasks, n, last_symbol, refine, d_res, d_cig, cigar_stride,
+                        d_ws, wb, s);
+    if (rc)
+        return rc;
+    WAMD_HIP(hipMemcpyAsync(results, d_res, rb, hipMemcpyDeviceToHost, s));
+    WAMD_HIP(hipMemcpyAsync(cigars, d_cig, cb, hipMemcpyDeviceToHost, s));
+    uint32_t flags = 0;
+    rc = fetch_flags(ctx, s, &flags);
+    return rc ? rc : flags_to_status(flags);
+}
+
+} // extern "C"

@@ -1,0 +1,153 @@
+// wamd_internal.h - shared definitions of the MI355X read-verification library.
+// Host objects behind the opaque C-ABI handles, device-side views and the small
+// device helpers every kernel uses.  gfx950 only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/whisper_amd.h"
+
+namespace wamd {
+
+// ---- device error flags (OR-ed by kernels into ctx->d_flags) ---------------------
+enum : uint32_t {
+    FLAG_TEXT_LEN = 1u << 0,   // W == 0 or W > max_text_len (reference throws)
+    FLAG_RANGE = 1u << 1,      // window leaves the genome
+    FLAG_READ_IDX = 1u << 2,   // read_idx >= reads in batch
+    FLAG_ORIENT = 1u << 3,     // orientation not prepared by wamd_reads_upload
+    FLAG_VARIANT = 1u << 4,    // variant cannot hold the read (M128 needs len <= 128 ...)
+    FLAG_ARG = 1u << 5,        // malformed task (anchor outside read, k too large ...)
+    FLAG_CIGAR = 1u << 6,      // cigar_stride too small for a task
+};
+constexpr uint32_t RESULT_ERROR = 0xFFFFFFFFu;
+
+// ---- device view of a reads batch ------------------------------------------------
+// codes : canonical 4-bit codes of every read in DIRECT orientation, two per byte,
+//         even position in the high nibble (the reference's own packing), read i at
+//         byte code_off[i] (4-byte aligned).  ASCII input is converted with raw_code
+//         (LevMyers64.cpp:50-60): ACGT 0..3, N 4, anything else 6.
+// pm    : pattern-match bit-vectors, rows for text symbols 0..3 only (a text symbol
+//         >= 4 can only match a read holding that same code, which `presence` tells):
+//         pm[((read * n_orient + slot) * 4 + c) * words + w]
+// meta  : per (read, slot): bits 0..15 presence of each code in the read,
+//         bits 16..19 last symbol in that orientation (LevMyers64.cpp:182/192)
+struct ReadsView {
+    const uint8_t* codes;
+    const uint64_t* code_off;
+    const uint32_t* lens;
+    const uint64_t* pm;
+    const uint32_t* meta;
+    uint32_t n;
+    uint32_t words;        // 64-bit words per bit-vector in this batch (max over reads)
+    uint32_t n_orient;     // 1 or 2 slots per read
+    int32_t slot_direct;   // slot index of the direct orientation, -1 if absent
+    int32_t slot_rc;
+};
+
+struct GenomeView {
+    const uint32_t* dwords;   // packed genome viewed as little-endian dwords
+    uint64_t n_symbols;       // 2 * genome_bytes
+    uint32_t last_dword;      // index of the last dword that may be loaded
+};
+
+} // namespace wamd
+
+struct wamd_ctx {
+    int device;
+    hipStream_t stream;
+    uint8_t* d_genome;          // padded copy (owned) or caller's pointer
+    bool owns_genome;
+    uint64_t genome_bytes;
+    uint32_t ref_size;
+    uint32_t cur_offset;
+    uint32_t max_text_len;
+    wamd_scoring scoring;
+    uint32_t* d_flags;          // device error flags
+    uint32_t* h_flags;          // pinned mirror
+    // staging for the host-pointer entry points (grown on demand)
+    void* d_stage;
+    uint64_t d_stage_bytes;
+    void* h_stage;
+    uint64_t h_stage_bytes;
+};
+
+struct wamd_reads {
+    wamd_ctx* ctx;
+    uint32_t n;
+    int encoding;
+    int orientations;
+    uint32_t max_len;
+    uint32_t words;
+    uint8_t* d_codes;
+    uint64_t* d_code_off;
+    uint32_t* d_lens;
+    uint64_t* d_pm;
+    uint32_t* d_meta;
+    uint64_t codes_bytes;
+    wamd::ReadsView view() const;
+};
+
+namespace wamd {
+
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+GenomeView genome_view(const wamd_ctx* ctx);
+int ensure_stage(wamd_ctx* ctx, uint64_t dev_bytes, uint64_t host_bytes);
+int flags_to_status(uint32_t flags);
+
+#define WAMD_HIP(call)                                                           \
+    do {                                                                         \
+        hipError_t e_ = (call);                                                  \
+        if (e_ != hipSuccess)                                                    \
+            return ::wamd::hip_fail(e_, #call, __FILE__, __LINE__);              \
+    } while (0)
+
+// kernel launchers (each defined next to its kernel)
+int launch_reads_prepare(wamd_ctx* ctx, wamd_reads* r, const uint8_t* d_raw,
+                         const uint64_t* d_raw_off, hipStream_t s);
+int launch_distance(wamd_ctx* ctx, const wamd_reads* r, const wamd_dist_task* d_tasks, uint32_t n,
+                    int last_symbol, wamd_dist_result* d_results, hipStream_t s);
+int launch_levdiag(wamd_ctx* ctx, const wamd_reads* r, const wamd_levdiag_task* d_tasks,
+                   uint32_t n, uint32_t* d_results, hipStream_t s);
+int launch_align(wamd_ctx* ctx, const wamd_reads* r, const wamd_dist_task* d_tasks, uint32_t n,
+                 int last_symbol, int refine, wamd_align_result* d_results, uint8_t* d_cigars,
+                 uint32_t cigar_stride, void* d_ws, uint64_t ws_bytes, hipStream_t s);
+uint64_t align_workspace_bytes(const wamd_reads* r, uint32_t n);
+
+#ifdef __HIPCC__
+// ---- device helpers -------------------------------------------------------------
+
+// swap the two nibbles of every byte: afterwards symbol s of the dword (s = 0..7 in
+// genome order) sits at bits [4s+3 : 4s].
+__device__ __forceinline__ uint32_t nibble_swap(uint32_t d)
+{
+    return ((d & 0x0f0f0f0fu) << 4) | ((d >> 4) & 0x0f0f0f0fu);
+}
+
+__device__ __forceinline__ uint32_t load_genome_dword(const GenomeView& g, uint32_t idx)
+{
+    idx = idx < g.last_dword ? idx : g.last_dword;
+    return nibble_swap(__builtin_nontemporal_load(g.dwords + idx));
+}
+
+// one symbol of a packed sequence (GET_CHAR_FROM_GENOME / _PATTERN, LevMyers64.cpp:22-26)
+__device__ __forceinline__ uint32_t packed_symbol(const uint8_t* p, uint64_t i)
+{
+    uint32_t b = p[i >> 1];
+    return (i & 1) ? (b & 15u) : (b >> 4);
+}
+
+// rev_comp_code, LevMyers64.cpp:40-48
+__device__ __forceinline__ uint32_t rc_code(uint32_t c)
+{
+    return c < 4 ? 3 - c : (c < 8 ? c : 7);
+}
+
+__device__ __forceinline__ void raise_flag(uint32_t* flags, uint32_t f)
+{
+    atomicOr(flags, f);
+}
+#endif
+
+} // namespace wamd
