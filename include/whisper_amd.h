@@ -132,6 +132,94 @@ typedef struct wamd_align_result {
     uint32_t reserved;
 } wamd_align_result;
 
+/* mapping_type_t (common/defs.h:83-84). */
+enum {
+    WAMD_MAP_LEV = 0, WAMD_MAP_INDEL1 = 1, WAMD_MAP_INDEL2 = 2, WAMD_MAP_INDEL_CLIPPING = 3,
+    WAMD_MAP_CLIPPING_INDEL = 4, WAMD_MAP_MISMATCHES_CLIPPING = 5, WAMD_MAP_CLIPPING_MISMATCHES = 6,
+    WAMD_MAP_CLIPPING_CLIPPING = 7, WAMD_MAP_NONE = 8
+};
+
+/* One CIndelMatching::Match call (mapper/indels.h:283-284, indels.cpp:125-461):
+ * Match(ref_pos, max_indel_size, fixed_segment_pos, fixed_segment_size,
+ *       max_no_mismatches, candidate_mapping) on a read preprocessed with
+ * Preprocess / PreprocessRawSeq in the orientation given by flags. */
+typedef struct wamd_indel_task {
+    uint32_t read_idx;
+    uint32_t ref_pos;
+    uint16_t max_indel_size;
+    uint16_t fixed_segment_pos;
+    uint16_t fixed_segment_size;
+    uint8_t max_no_mismatches;
+    uint8_t flags;                 /* WAMD_TASK_FLAG_*                                  */
+} wamd_indel_task;
+
+/* candidate_mapping_t (common/types.h:224-318) as plain data.  `found` is Match's
+ * bool; the other fields hold whatever Match left in a default-constructed
+ * candidate_mapping_t, direction excluded (the caller sets it,
+ * mapping_core_sa.cpp:266, 319-320). */
+typedef struct wamd_mapping {
+    uint32_t found;
+    uint32_t type;                 /* WAMD_MAP_*                                        */
+    uint32_t pos;
+    uint32_t no_mismatches;
+    uint32_t matching_len1;
+    uint32_t matching_len2;
+    int32_t indel_len1;
+    int32_t indel_len2;
+    uint32_t clipping_len;
+    uint32_t penalty;              /* calc_penalty(), results.cpp:327-343               */
+} wamd_mapping;
+
+/* Parameters CIndelMatching takes from CParams (indels.cpp:21-32). */
+typedef struct wamd_indel_params {
+    wamd_scoring scoring;
+    double min_clipped_factor;     /* mapper/params.h:158: 1.0                          */
+} wamd_indel_params;
+
+/* Input of CIndelMatching::GetExtCigarNew (indels.cpp:938-957) as called from
+ * fill_cigar_with_indel_matching (sam_matching.cpp:824-852): the record of one
+ * mapping, the read and the window start (examined_start_pos). */
+typedef struct wamd_indel_cigar_task {
+    uint32_t read_idx;
+    uint32_t examined_start_pos;
+    uint32_t type;                 /* WAMD_MAP_*, not LEV                               */
+    uint32_t matching_len1;
+    uint32_t matching_len2;
+    int32_t indel_len1;
+    int32_t indel_len2;
+    uint32_t clipping_len;
+    uint32_t flags;                /* WAMD_TASK_FLAG_*                                  */
+    uint32_t reserved;
+} wamd_indel_cigar_task;
+
+/* What GetExtCigarNew leaves in mapping_desc_t. */
+typedef struct wamd_indel_cigar_result {
+    double score;
+    uint32_t ok;
+    uint32_t cigar_len;
+    uint16_t err_edit_distance;
+    uint16_t num_events;
+    uint16_t ref_length;
+    uint16_t left_clipping;
+    uint16_t right_clipping;
+    uint16_t method;               /* MatchingMethod::Enumeration (common/types.h)      */
+    uint32_t reserved;
+} wamd_indel_cigar_result;
+
+/* The fields of mapping_desc_t that CSoftClipping::clipBoundaryPositions
+ * (soft_clipping.cpp:827-994) reads and rewrites, next to the ext-CIGAR itself. */
+typedef struct wamd_clip_record {
+    double score;
+    int32_t ref_seq_pos;
+    uint16_t ref_length;
+    uint16_t err_edit_distance;
+    uint16_t left_clipping;
+    uint16_t right_clipping;
+    uint32_t cigar_len;            /* out: length after clipping                        */
+    uint32_t no_clippings;         /* out: sides clipped by this call (0..2)            */
+    uint32_t reserved;
+} wamd_clip_record;
+
 typedef struct wamd_ctx wamd_ctx;       /* one per (process, device)                  */
 typedef struct wamd_reads wamd_reads;   /* a device-resident batch of reads           */
 
@@ -221,6 +309,44 @@ WAMD_API int wamd_align_dev(wamd_ctx* ctx, const wamd_reads* reads,
                             uint32_t cigar_stride, void* d_workspace,
                             uint64_t workspace_bytes, void* stream);
 WAMD_API uint64_t wamd_align_workspace_bytes(const wamd_reads* reads, uint32_t n);
+
+/* ---- long-indel / clipping matcher (sensitive mapping stages) ----------- *
+ * Replaces indel_matching_{dir,rc}->Match(...) at mapping_core_sa.cpp:264/317 and
+ * mapping_core_dp.cpp.  Reads: nibble-packed (Preprocess) or ASCII (PreprocessRawSeq). */
+WAMD_API int wamd_indel_match(wamd_ctx* ctx, const wamd_reads* reads, const wamd_indel_task* tasks,
+                              uint32_t n, const wamd_indel_params* params, wamd_mapping* results);
+WAMD_API int wamd_indel_match_dev(wamd_ctx* ctx, const wamd_reads* reads,
+                                  const wamd_indel_task* d_tasks, uint32_t n,
+                                  const wamd_indel_params* params, wamd_mapping* d_results,
+                                  void* stream);
+
+/* Replaces indelMatching->{PreprocessRawSeq, prefetch_genome, GetExtCigarNew} in
+ * fill_cigar_with_indel_matching (sam_matching.cpp:824-852). */
+WAMD_API int wamd_indel_ext_cigar(wamd_ctx* ctx, const wamd_reads* reads,
+                                  const wamd_indel_cigar_task* tasks, uint32_t n,
+                                  wamd_indel_cigar_result* results, uint8_t* cigars,
+                                  uint32_t cigar_stride);
+WAMD_API int wamd_indel_ext_cigar_dev(wamd_ctx* ctx, const wamd_reads* reads,
+                                      const wamd_indel_cigar_task* d_tasks, uint32_t n,
+                                      wamd_indel_cigar_result* d_results, uint8_t* d_cigars,
+                                      uint32_t cigar_stride, void* stream);
+
+/* Replaces softClipping->clipBoundaryPositions(hit, scoring) (sam_matching.cpp:454-457,
+ * sam.cpp:1889-1900): ext-CIGARs at cigars + i * cigar_stride and records are
+ * rewritten in place. */
+WAMD_API int wamd_clip_boundary(wamd_ctx* ctx, uint32_t n, wamd_clip_record* records,
+                                uint8_t* cigars, uint32_t cigar_stride);
+WAMD_API int wamd_clip_boundary_dev(wamd_ctx* ctx, uint32_t n, wamd_clip_record* d_records,
+                                    uint8_t* d_cigars, uint32_t cigar_stride, void* stream);
+
+/* candidate_mapping_t::serialize (results.cpp:161-217): the 5..11-byte wire records
+ * that are gathered across GPUs.  sizes[i] bytes are written at out + i * 12;
+ * direction[i] != 0 means genome_t::direct. */
+WAMD_API int wamd_serialize_mappings(wamd_ctx* ctx, uint32_t n, const wamd_mapping* mappings,
+                                     const uint8_t* direction, uint8_t* out, uint8_t* sizes);
+WAMD_API int wamd_serialize_mappings_dev(wamd_ctx* ctx, uint32_t n, const wamd_mapping* d_mappings,
+                                         const uint8_t* d_direction, uint8_t* d_out,
+                                         uint8_t* d_sizes, void* stream);
 
 #ifdef __cplusplus
 }

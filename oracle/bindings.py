@@ -23,12 +23,41 @@ LEVDIAG_TASK = np.dtype([("read_idx", "<u4"), ("position_in_text", "<u4"), ("fix
 ALIGN_RESULT = np.dtype([("affine_score", "<f8"), ("ok", "<u4"), ("edit_distance", "<u4"),
                          ("end_pos", "<u4"), ("begin_pos", "<u4"), ("num_events", "<u4"),
                          ("cigar_len", "<u4"), ("refined", "<u4"), ("reserved", "<u4")])
+INDEL_TASK = np.dtype([("read_idx", "<u4"), ("ref_pos", "<u4"), ("max_indel_size", "<u2"),
+                       ("fixed_segment_pos", "<u2"), ("fixed_segment_size", "<u2"),
+                       ("max_no_mismatches", "u1"), ("flags", "u1")])
+MAPPING = np.dtype([("found", "<u4"), ("type", "<u4"), ("pos", "<u4"), ("no_mismatches", "<u4"),
+                    ("matching_len1", "<u4"), ("matching_len2", "<u4"), ("indel_len1", "<i4"),
+                    ("indel_len2", "<i4"), ("clipping_len", "<u4"), ("penalty", "<u4")])
+INDEL_CIGAR_TASK = np.dtype([("read_idx", "<u4"), ("examined_start_pos", "<u4"), ("type", "<u4"),
+                             ("matching_len1", "<u4"), ("matching_len2", "<u4"), ("indel_len1", "<i4"),
+                             ("indel_len2", "<i4"), ("clipping_len", "<u4"), ("flags", "<u4"),
+                             ("reserved", "<u4")])
+INDEL_CIGAR_RESULT = np.dtype([("score", "<f8"), ("ok", "<u4"), ("cigar_len", "<u4"),
+                               ("err_edit_distance", "<u2"), ("num_events", "<u2"),
+                               ("ref_length", "<u2"), ("left_clipping", "<u2"),
+                               ("right_clipping", "<u2"), ("method", "<u2"), ("reserved", "<u4")])
+CLIP_RECORD = np.dtype([("score", "<f8"), ("ref_seq_pos", "<i4"), ("ref_length", "<u2"),
+                        ("err_edit_distance", "<u2"), ("left_clipping", "<u2"),
+                        ("right_clipping", "<u2"), ("cigar_len", "<u4"), ("no_clippings", "<u4"),
+                        ("reserved", "<u4")])
 assert DIST_TASK.itemsize == 16 and LEVDIAG_TASK.itemsize == 16 and ALIGN_RESULT.itemsize == 40
+assert INDEL_TASK.itemsize == 16 and MAPPING.itemsize == 40 and INDEL_CIGAR_TASK.itemsize == 40
+assert INDEL_CIGAR_RESULT.itemsize == 32 and CLIP_RECORD.itemsize == 32
 
 
-class Scoring(C.Structure):
+
+class Scoring(C.Structure):  # noqa: E302
     _fields_ = [(n, C.c_double) for n in ("match", "mismatch", "gap_ins_open", "gap_ins_extend",
                                            "gap_del_open", "gap_del_extend", "clipping")]
+
+
+class IndelParams(C.Structure):
+    _fields_ = [("scoring", Scoring), ("min_clipped_factor", C.c_double)]
+
+
+def default_indel_params(min_clipped_factor=1.0):
+    return IndelParams(default_scoring(), min_clipped_factor)
 
 
 def default_scoring():
@@ -89,6 +118,43 @@ class Oracle(_Lib):
         return rc, res, cig
 
 
+    def indel_match(self, genome, reads, offsets, lens, encoding, tasks, params=None):
+        tasks = _c(tasks)
+        prm = params or default_indel_params()
+        res = np.zeros(len(tasks), MAPPING)
+        rc = self.lib.wo_indel_match_batch(_p(genome), _p(reads), _p(offsets), _p(lens),
+                                           C.c_int(encoding), _p(tasks), C.c_uint32(len(tasks)),
+                                           C.byref(prm), _p(res))
+        return rc, res
+
+    def indel_ext_cigar(self, genome, reads, offsets, lens, encoding, tasks, scoring=None,
+                        cigar_stride=1024):
+        tasks = _c(tasks)
+        sc = scoring or default_scoring()
+        res = np.zeros(len(tasks), INDEL_CIGAR_RESULT)
+        cig = np.zeros((len(tasks), cigar_stride), np.uint8)
+        rc = self.lib.wo_indel_ext_cigar_batch(_p(genome), _p(reads), _p(offsets), _p(lens),
+                                               C.c_int(encoding), _p(tasks), C.c_uint32(len(tasks)),
+                                               C.byref(sc), _p(res), _p(cig), C.c_uint32(cigar_stride))
+        return rc, res, cig
+
+    def clip_boundary(self, records, cigars, scoring=None):
+        sc = scoring or default_scoring()
+        rec = np.array(records, CLIP_RECORD, copy=True)
+        cig = np.array(cigars, np.uint8, copy=True)
+        rc = self.lib.wo_clip_boundary_batch(C.c_uint32(len(rec)), _p(rec), _p(cig),
+                                             C.c_uint32(cig.shape[1]), C.byref(sc))
+        return rc, rec, cig
+
+    def serialize(self, mappings, direction):
+        m = _c(mappings)
+        d = _c(direction, np.uint8)
+        out = np.zeros((len(m), 12), np.uint8)
+        sizes = np.zeros(len(m), np.uint8)
+        rc = self.lib.wo_serialize_batch(C.c_uint32(len(m)), _p(m), _p(d), _p(out), _p(sizes))
+        return rc, out, sizes
+
+
 class Reference(_Lib):
     """The reference's own objects (oracle/_ref/libwhisper_ref.so)."""
     path = REF_SO
@@ -139,3 +205,50 @@ class Reference(_Lib):
 
 def have_reference():
     return os.path.exists(REF_SO)
+
+
+def _ref_indel_match(self, genome, reads, offsets, lens, encoding, tasks, params=None, nthreads=1):
+    tasks = _c(tasks)
+    prm = params or default_indel_params()
+    res = np.zeros(len(tasks), MAPPING)
+    rc = self.lib.ref_indel_match_batch(_p(genome), _p(reads), _p(offsets), _p(lens), C.c_int(encoding),
+                                        _p(tasks), C.c_uint32(len(tasks)), C.byref(prm), _p(res),
+                                        C.c_int(nthreads))
+    return rc, res
+
+
+def _ref_indel_ext_cigar(self, genome, reads, offsets, lens, encoding, tasks, max_indel=50, scoring=None,
+                         cigar_stride=1024):
+    tasks = _c(tasks)
+    sc = scoring or default_scoring()
+    res = np.zeros(len(tasks), INDEL_CIGAR_RESULT)
+    cig = np.zeros((len(tasks), cigar_stride), np.uint8)
+    rc = self.lib.ref_indel_ext_cigar_batch(_p(genome), _p(reads), _p(offsets), _p(lens),
+                                            C.c_int(encoding), _p(tasks), C.c_uint32(len(tasks)),
+                                            C.c_uint32(max_indel), C.byref(sc), _p(res), _p(cig),
+                                            C.c_uint32(cigar_stride))
+    return rc, res, cig
+
+
+def _ref_clip_boundary(self, records, cigars, scoring=None):
+    sc = scoring or default_scoring()
+    rec = np.array(records, CLIP_RECORD, copy=True)
+    cig = np.array(cigars, np.uint8, copy=True)
+    rc = self.lib.ref_clip_boundary_batch(C.c_uint32(len(rec)), _p(rec), _p(cig),
+                                          C.c_uint32(cig.shape[1]), C.byref(sc))
+    return rc, rec, cig
+
+
+def _ref_serialize(self, mappings, direction):
+    m = _c(mappings)
+    d = _c(direction, np.uint8)
+    out = np.zeros((len(m), 12), np.uint8)
+    sizes = np.zeros(len(m), np.uint8)
+    rc = self.lib.ref_serialize_batch(C.c_uint32(len(m)), _p(m), _p(d), _p(out), _p(sizes))
+    return rc, out, sizes
+
+
+Reference.indel_match = _ref_indel_match
+Reference.indel_ext_cigar = _ref_indel_ext_cigar
+Reference.clip_boundary = _ref_clip_boundary
+Reference.serialize = _ref_serialize

@@ -297,3 +297,161 @@ REF_API int ref_align_batch(const uint8_t* genome, uint32_t ref_size, const uint
     });
     return rc;
 }
+
+// ---- CIndelMatching / CSoftClipping / candidate_mapping_t -----------------------------
+#include "mapper/indels.h"
+#include "mapper/soft_clipping.h"
+
+namespace {
+
+void fill_params(CParams& p, const wamd_scoring* sc, double min_clipped_factor)
+{
+    p.match_score = sc->match;
+    p.mismatch_score = sc->mismatch;
+    p.gap_ins_open = sc->gap_ins_open;
+    p.gap_ins_extend = sc->gap_ins_extend;
+    p.gap_del_open = sc->gap_del_open;
+    p.gap_del_extend = sc->gap_del_extend;
+    p.clipping_score = sc->clipping;
+    p.min_clipped_factor = min_clipped_factor;
+}
+
+void to_pod(const candidate_mapping_t& c, bool found, wamd_mapping& m)
+{
+    m.found = found;
+    m.type = (uint32_t)c.type;
+    m.pos = c.pos;
+    m.no_mismatches = c.no_mismatches;
+    m.matching_len1 = c.matching_len1;
+    m.matching_len2 = c.matching_len2;
+    m.indel_len1 = c.indel_len1;
+    m.indel_len2 = c.indel_len2;
+    m.clipping_len = c.clipping_len;
+    m.penalty = found ? (uint32_t)c.penalty : 0;
+}
+
+void from_pod(const wamd_mapping& m, candidate_mapping_t& c)
+{
+    c.type = (mapping_type_t)m.type;
+    c.pos = m.pos;
+    c.no_mismatches = m.no_mismatches;
+    c.matching_len1 = m.matching_len1;
+    c.matching_len2 = m.matching_len2;
+    c.indel_len1 = m.indel_len1;
+    c.indel_len2 = m.indel_len2;
+    c.clipping_len = m.clipping_len;
+}
+
+} // namespace
+
+REF_API int ref_indel_match_batch(const uint8_t* genome, const uint8_t* reads, const uint64_t* offsets,
+                                  const uint32_t* lens, int encoding, const wamd_indel_task* tasks,
+                                  uint32_t n, const wamd_indel_params* prm, wamd_mapping* results,
+                                  int nthreads)
+{
+    parallel_for(n, nthreads, [&](int, uint32_t b, uint32_t e) {
+        CParams params;
+        fill_params(params, &prm->scoring, prm->min_clipped_factor);
+        CIndelMatching im(&params);
+        im.SetReference(const_cast<uint8_t*>(genome), 0, 0);   // mapping_core.cpp:188-191
+        for (uint32_t i = b; i < e; ++i) {
+            const wamd_indel_task& t = tasks[i];
+            uint8_t* seq = const_cast<uint8_t*>(reads + offsets[t.read_idx]);
+            genome_t dir = (t.flags & WAMD_TASK_FLAG_REV_COMP) ? genome_t::rev_comp : genome_t::direct;
+            if (encoding == WAMD_READS_NIBBLE)
+                im.Preprocess(seq, lens[t.read_idx], dir);
+            else
+                im.PreprocessRawSeq(seq, lens[t.read_idx], dir);
+            candidate_mapping_t cm;
+            bool found = im.Match(t.ref_pos, t.max_indel_size, t.fixed_segment_pos, t.fixed_segment_size,
+                                  t.max_no_mismatches, cm);
+            to_pod(cm, found, results[i]);
+        }
+    });
+    return 0;
+}
+
+REF_API int ref_indel_ext_cigar_batch(const uint8_t* genome, const uint8_t* reads, const uint64_t* offsets,
+                                      const uint32_t* lens, int encoding,
+                                      const wamd_indel_cigar_task* tasks, uint32_t n, uint32_t max_indel,
+                                      const wamd_scoring* sc, wamd_indel_cigar_result* results,
+                                      uint8_t* cigars, uint32_t cigar_stride)
+{
+    CParams params;
+    fill_params(params, sc, 1.0);
+    CIndelMatching im(&params);
+    im.SetReference(const_cast<uint8_t*>(genome), 0, 0);
+    for (uint32_t i = 0; i < n; ++i) {
+        const wamd_indel_cigar_task& t = tasks[i];
+        const uint32_t m = lens[t.read_idx];
+        uint8_t* seq = const_cast<uint8_t*>(reads + offsets[t.read_idx]);
+        genome_t dir = (t.flags & WAMD_TASK_FLAG_REV_COMP) ? genome_t::rev_comp : genome_t::direct;
+        // fill_cigar_with_indel_matching, sam_matching.cpp:824-838
+        if (encoding == WAMD_READS_NIBBLE)
+            im.Preprocess(seq, m, dir);
+        else
+            im.PreprocessRawSeq(seq, m, dir);
+        im.prefetch_genome(t.examined_start_pos, m + 2 * max_indel + 1);
+        mapping_desc_t md;
+        md.read_length = (uint16_t)m;
+        md.ext_cigar = cigars + (size_t)i * cigar_stride;
+        md.mapping.type = (mapping_type_t)t.type;
+        md.mapping.matching_len1 = t.matching_len1;
+        md.mapping.matching_len2 = t.matching_len2;
+        md.mapping.indel_len1 = t.indel_len1;
+        md.mapping.indel_len2 = t.indel_len2;
+        md.mapping.clipping_len = t.clipping_len;
+        wamd_indel_cigar_result& r = results[i];
+        memset(&r, 0, sizeof(r));
+        md.ext_cigar[0] = 0;
+        r.ok = im.GetExtCigarNew(md, &params);
+        r.score = md.score;
+        r.err_edit_distance = md.err_edit_distance;
+        r.num_events = md.num_events;
+        r.ref_length = md.ref_length;
+        r.left_clipping = md.left_clipping;
+        r.right_clipping = md.right_clipping;
+        r.method = r.ok ? (uint16_t)md.method : 0;
+        r.cigar_len = (uint32_t)strlen((const char*)md.ext_cigar);
+    }
+    return 0;
+}
+
+REF_API int ref_clip_boundary_batch(uint32_t n, wamd_clip_record* records, uint8_t* cigars,
+                                    uint32_t cigar_stride, const wamd_scoring* sc)
+{
+    CSoftClipping clip(512, 16384, 3, 50, 0);
+    scoring_t scoring = make_scoring(sc);
+    for (uint32_t i = 0; i < n; ++i) {
+        wamd_clip_record& r = records[i];
+        mapping_desc_t md;
+        md.ext_cigar = cigars + (size_t)i * cigar_stride;
+        md.score = r.score;
+        md.ref_seq_pos = r.ref_seq_pos;
+        md.ref_length = r.ref_length;
+        md.err_edit_distance = r.err_edit_distance;
+        md.left_clipping = r.left_clipping;
+        md.right_clipping = r.right_clipping;
+        clip.clipBoundaryPositions(md, scoring);
+        r.score = md.score;
+        r.ref_seq_pos = md.ref_seq_pos;
+        r.ref_length = md.ref_length;
+        r.err_edit_distance = md.err_edit_distance;
+        r.left_clipping = md.left_clipping;
+        r.right_clipping = md.right_clipping;
+        r.cigar_len = (uint32_t)strlen((const char*)md.ext_cigar);
+    }
+    return 0;
+}
+
+REF_API int ref_serialize_batch(uint32_t n, const wamd_mapping* m, const uint8_t* direction, uint8_t* out,
+                                uint8_t* sizes)
+{
+    for (uint32_t i = 0; i < n; ++i) {
+        candidate_mapping_t c;
+        from_pod(m[i], c);
+        c.direction = direction[i] ? genome_t::direct : genome_t::rev_comp;
+        sizes[i] = (uint8_t)c.serialize(out + (size_t)i * 12);
+    }
+    return 0;
+}

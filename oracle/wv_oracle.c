@@ -673,3 +673,750 @@ int wo_align_batch(const uint8_t* genome, const uint8_t* reads, const uint64_t* 
     free(read_codes);
     return rc;
 }
+
+/* ======================================================================= */
+/* CIndelMatching (mapper/indels.cpp), CSoftClipping::clipBoundaryPositions */
+/* (mapper/soft_clipping.cpp), candidate_mapping_t::serialize (results.cpp)  */
+/* ======================================================================= */
+
+#include <ctype.h>
+#include <float.h>
+
+#define MIN_SIDE 7   /* min_side_size, indels.h:210 */
+#define MAX_SIDE_ERRORS 1
+
+/* rev_comp_code of CIndelMatching, indels.cpp:40-49: 8..15 -> 15 */
+static inline uint32_t rc_code_indel(uint32_t c)
+{
+    if (c < 4)
+        return 3 - c;
+    return c < 8 ? c : 15;
+}
+
+void wo_indel_query(uint8_t* query, const uint8_t* seq, uint32_t len, int encoding, int rev_comp)
+{
+    for (uint32_t i = 0; i < len; ++i) {
+        if (encoding == WAMD_READS_NIBBLE)
+            query[i] = (uint8_t)(rev_comp ? rc_code_indel(nib(seq, len - i - 1)) : nib(seq, i));
+        else
+            query[i] = (uint8_t)ascii_code((rev_comp ? seq[len - i - 1] : seq[i]) & 0x7f, rev_comp);
+    }
+}
+
+static inline uint32_t popcount64(uint64_t x) { return (uint32_t)__builtin_popcountll(x); }
+
+/* calc_penalty, results.cpp:327-343 with types.h:242-247 */
+static uint32_t mapping_penalty(uint32_t type, uint32_t no_mismatches)
+{
+    switch (type) {
+    case WAMD_MAP_LEV: return no_mismatches;
+    case WAMD_MAP_CLIPPING_INDEL:
+    case WAMD_MAP_INDEL_CLIPPING: return no_mismatches + 2;
+    case WAMD_MAP_CLIPPING_MISMATCHES:
+    case WAMD_MAP_MISMATCHES_CLIPPING: return no_mismatches + 1;
+    case WAMD_MAP_INDEL1: return no_mismatches + 1;
+    case WAMD_MAP_INDEL2: return no_mismatches + 2;
+    case WAMD_MAP_CLIPPING_CLIPPING: return no_mismatches + 2;
+    default: return 0;
+    }
+}
+
+/* CBitCharsSingleWord (indels.h:162-206): 4-bit one-hot cells, newest symbol in the
+ * lowest cell; a symbol >= 4 is NOT inserted at all, the window does not advance. */
+static uint64_t side_signature(const uint8_t* q)
+{
+    uint64_t d = 0;
+    for (int i = 0; i < MIN_SIDE; ++i)
+        if (q[i] < 4)
+            d += 1ull << (q[i] + 4 * (MIN_SIDE - i - 1));
+    return d;
+}
+
+/* find_candidates, indels.cpp:472-492.  cand must hold end - begin entries. */
+static uint32_t find_candidates(const uint8_t* g, uint64_t qsig, uint32_t begin, uint32_t end,
+                                uint32_t* cand)
+{
+    const uint64_t mask = ~0ull >> (4 * (16 - MIN_SIDE));
+    uint64_t d = 0;
+    uint32_t n = 0;
+    for (int i = 0; i < MIN_SIDE - 1; ++i)
+        if (g[begin + i] < 4)
+            d += 1ull << (g[begin + i] + 4 * (MIN_SIDE - i - 2));
+    for (int i = (int)begin + MIN_SIDE - 1; i < (int)end; ++i) {
+        if (g[i] < 4)
+            d = ((d << 4) + (1ull << g[i])) & mask;
+        if (popcount64(d & qsig) >= MIN_SIDE - MAX_SIDE_ERRORS)
+            cand[n++] = (uint32_t)(i - MIN_SIDE + 1);
+    }
+    return n;
+}
+
+/* calc_mismatches_with_indel, indels.cpp:495-563 */
+static void mismatches_with_indel(const uint8_t* g, const uint8_t* q, uint32_t query_len, uint32_t g_left,
+                                  uint32_t g_right, uint32_t q_left, uint32_t q_right, int left_margin,
+                                  uint32_t* left_mis, uint32_t* right_mis, uint32_t* no_mis,
+                                  uint32_t* indel_pos)
+{
+    const uint32_t text_size = g_right - g_left, query_size = q_right - q_left;
+    const uint32_t stats = text_size < query_size ? text_size : query_size;
+    if (stats <= MIN_SIDE) {
+        *no_mis = query_len + 1;
+        *indel_pos = 0;
+        return;
+    }
+    const int start = left_margin ? MIN_SIDE : 0;
+    const int end = (int)stats - (left_margin ? 0 : MIN_SIDE);
+    left_mis[0] = 0;
+    for (uint32_t i = 1; i <= stats; ++i)
+        left_mis[i] = left_mis[i - 1] + (g[g_left + i - 1] != q[q_left + i - 1]);
+    right_mis[stats] = 0;
+    for (uint32_t i = 1; i <= stats; ++i)
+        right_mis[stats - i] = right_mis[stats - i + 1] +
+                               (g[g_left + text_size - i] != q[q_left + query_size - i]);
+    int best = (int)query_len + 1, best_pos = 0;
+    for (int i = start; i < end; ++i) {
+        const int tot = (int)(left_mis[i] + right_mis[i]);
+        if (tot < best) {
+            best_pos = i;
+            best = tot;
+        }
+    }
+    *no_mis = (uint32_t)best;
+    *indel_pos = q_left + (uint32_t)best_pos;
+}
+
+int wo_indel_match(const uint8_t* genome_packed, const uint8_t* query, uint32_t query_len,
+                   uint32_t ref_pos, uint32_t max_indel, uint32_t fpos, uint32_t fsize,
+                   uint32_t max_mis, const wamd_indel_params* prm, wamd_mapping* cm)
+{
+    const double match_score = prm->scoring.match, mismatch_score = prm->scoring.mismatch;
+    const double gap_del_open = prm->scoring.gap_del_open, gap_del_extend = prm->scoring.gap_del_extend;
+    const double gap_ins_open = prm->scoring.gap_ins_open, gap_ins_extend = prm->scoring.gap_ins_extend;
+    const double clipping_score = prm->scoring.clipping;
+
+    /* a default-constructed candidate_mapping_t, types.h:250-261 */
+    memset(cm, 0, sizeof(*cm));
+    cm->type = WAMD_MAP_NONE;
+    cm->no_mismatches = max_mis + 1;
+
+    const uint32_t text_size = query_len + 2 * max_indel;
+    int rc = 0;
+    uint8_t* g = (uint8_t*)malloc((size_t)text_size + 8);
+    uint32_t* cand = (uint32_t*)malloc(((size_t)text_size + 8) * sizeof(uint32_t));
+    uint32_t* lm = (uint32_t*)malloc(((size_t)query_len + 8) * sizeof(uint32_t));
+    uint32_t* rm = (uint32_t*)malloc(((size_t)query_len + 8) * sizeof(uint32_t));
+    /* prefetch_genome(ref_pos - max_indel_size, text_size): raw 4-bit codes */
+    for (uint32_t i = 0; i < text_size + 2; ++i)
+        g[i] = (uint8_t)nib(genome_packed, (uint64_t)(ref_pos - max_indel) + i);
+
+    double total_cost = 0; /* min_acceptable_score */
+    const int min_size_after_clipping = (int)(query_len * prm->min_clipped_factor);
+
+    int left_indel_size = 0, right_indel_size = 0;
+    uint32_t no_left_mis_indel = query_len, no_right_mis_indel = query_len;
+    double best_left_cost = 0, best_right_cost = 0;
+    uint32_t best_left_indel_pos = 0, best_right_indel_pos = 0;
+    int left_indel_found = 0, right_indel_found = 0;
+    double best_left_clip_cost = 0, best_right_clip_cost = 0;
+    uint32_t best_no_left_clipped = 0, best_no_right_clipped = 0;
+    uint32_t no_left_mis_clipped = 0, no_right_mis_clipped = 0;
+    uint32_t best_no_left_mis_clipped = 0, best_no_right_mis_clipped = 0;
+
+    /* anchor, indels.cpp:167-169 */
+    for (uint32_t i = 0; i < fsize; ++i)
+        if (query[fpos + i] != g[max_indel + fpos + i])
+            goto done;
+
+    /* left part: raw mismatches and best clipping, 173-194 */
+    uint32_t no_left_mis_raw = 0;
+    double clipping_cost = clipping_score;
+    for (int i = (int)fpos - 1; i >= 0; --i) {
+        if (query[i] != g[max_indel + i]) {
+            ++no_left_mis_raw;
+            ++no_left_mis_clipped;
+            clipping_cost += mismatch_score;
+        } else {
+            clipping_cost += match_score;
+            if (clipping_cost > best_left_clip_cost) {
+                best_left_clip_cost = clipping_cost;
+                best_no_left_clipped = (uint32_t)i;
+                best_no_left_mis_clipped = no_left_mis_clipped;
+            }
+        }
+    }
+    if (fpos > (uint32_t)MIN_SIDE) { /* 198-231 */
+        const uint64_t qsig = side_signature(query);
+        const uint32_t nc = find_candidates(g, qsig, 0, max_indel + fpos, cand);
+        for (uint32_t c = 0; c < nc; ++c) {
+            uint32_t c_mis, indel_pos;
+            mismatches_with_indel(g, query, query_len, cand[c], max_indel + fpos + 1, 0, fpos + 1, 1, lm, rm,
+                                  &c_mis, &indel_pos);
+            if (c_mis > max_mis)
+                continue;
+            const int c_indel = (int)max_indel - (int)cand[c];
+            if (abs(c_indel) > (int)max_indel)
+                continue;
+            double cost = (fpos - c_mis) * match_score + c_mis * mismatch_score;
+            if (c_indel > 0)
+                cost += gap_del_open + (c_indel - 1) * gap_del_extend;
+            else if (c_indel < 0)
+                cost += gap_ins_open + (-c_indel - 1) * gap_ins_extend;
+            if (cost > best_left_cost) {
+                best_left_cost = cost;
+                no_left_mis_indel = c_mis;
+                best_left_indel_pos = indel_pos;
+                left_indel_size = c_indel;
+                left_indel_found = c_indel != 0;
+            }
+        }
+    }
+
+    /* right part, 235-293 */
+    uint32_t no_right_mis_raw = 0;
+    clipping_cost = clipping_score;
+    for (uint32_t i = fpos + fsize; i < query_len; ++i) {
+        if (query[i] != g[max_indel + i]) {
+            ++no_right_mis_raw;
+            ++no_right_mis_clipped;
+            clipping_cost += mismatch_score;
+        } else {
+            clipping_cost += match_score;
+            if (clipping_cost > best_right_clip_cost) {
+                best_right_clip_cost = clipping_cost;
+                best_no_right_mis_clipped = no_right_mis_clipped;
+                best_no_right_clipped = query_len - i - 1;
+            }
+        }
+    }
+    if (fpos + fsize + MIN_SIDE < query_len) {
+        const uint64_t qsig = side_signature(query + query_len - MIN_SIDE);
+        const uint32_t nc = find_candidates(g, qsig, max_indel + fpos + fsize, text_size, cand);
+        for (uint32_t c = 0; c < nc; ++c) {
+            uint32_t c_mis, indel_pos;
+            mismatches_with_indel(g, query, query_len, fpos + fsize - 1 + max_indel, cand[c] + MIN_SIDE,
+                                  fpos + fsize - 1, query_len, 0, lm, rm, &c_mis, &indel_pos);
+            if (c_mis > max_mis)
+                continue;
+            const int c_indel = ((int)cand[c] + MIN_SIDE) - ((int)text_size - (int)max_indel);
+            if (abs(c_indel) > (int)max_indel)
+                continue;
+            double cost = (query_len - fpos - fsize - c_mis) * match_score + c_mis * mismatch_score;
+            if (c_indel > 0)
+                cost += gap_del_open + (c_indel - 1) * gap_del_extend;
+            else if (c_indel < 0)
+                cost += gap_ins_open + (-c_indel - 1) * gap_ins_extend;
+            if (cost > best_right_cost) {
+                best_right_cost = cost;
+                no_right_mis_indel = c_mis;
+                best_right_indel_pos = indel_pos;
+                right_indel_size = c_indel;
+                right_indel_found = c_indel != 0;
+            }
+        }
+    }
+
+#define RESCALE(size) ((uint32_t)(size) * max_mis / query_len) /* indels.h:252-255 */
+#define LEFT_POS() (left_indel_size > 0 ? ref_pos - (uint32_t)left_indel_size : ref_pos + (uint32_t)(-left_indel_size))
+
+    /* the eight combined cases in the reference's order, 297-457 */
+    if (left_indel_found && no_left_mis_indel + no_right_mis_raw < max_mis) {
+        double c = best_left_cost + (query_len - fpos - no_right_mis_raw) * match_score +
+                   no_right_mis_raw * mismatch_score;
+        if (c > total_cost) {
+            total_cost = c;
+            cm->pos = LEFT_POS();
+            cm->type = WAMD_MAP_INDEL1;
+            cm->matching_len1 = best_left_indel_pos;
+            cm->indel_len1 = left_indel_size;
+            cm->no_mismatches = no_left_mis_indel + no_right_mis_raw;
+        }
+    }
+    if (right_indel_found && no_left_mis_raw + no_right_mis_indel < max_mis) {
+        double c = best_right_cost + (fpos + fsize - no_left_mis_raw) * match_score +
+                   no_left_mis_raw * mismatch_score;
+        if (c > total_cost) {
+            total_cost = c;
+            cm->pos = ref_pos;
+            cm->type = WAMD_MAP_INDEL1;
+            cm->matching_len1 = best_right_indel_pos;
+            cm->indel_len1 = right_indel_size;
+            cm->no_mismatches = no_left_mis_raw + no_right_mis_indel;
+        }
+    }
+    if (left_indel_found && right_indel_found && no_left_mis_indel + no_right_mis_indel < max_mis) {
+        double c = best_left_cost + best_right_cost + fsize * match_score;
+        if (c > total_cost) {
+            total_cost = c;
+            cm->type = WAMD_MAP_INDEL2;
+            cm->pos = LEFT_POS();
+            cm->matching_len1 = best_left_indel_pos;
+            cm->indel_len1 = left_indel_size;
+            if (left_indel_size > 0)
+                cm->matching_len2 = best_right_indel_pos - best_left_indel_pos;
+            else
+                cm->matching_len2 = best_right_indel_pos - (best_left_indel_pos + (uint32_t)(-left_indel_size));
+            cm->indel_len2 = right_indel_size;
+            cm->no_mismatches = no_left_mis_indel + no_right_mis_indel;
+        }
+    }
+    if (best_no_left_clipped > 0 &&
+        best_no_left_mis_clipped + no_right_mis_raw < RESCALE(query_len - best_no_left_clipped)) {
+        double c = best_left_clip_cost + (query_len - fpos - no_right_mis_raw) * match_score +
+                   no_right_mis_raw * mismatch_score;
+        if (c > total_cost && query_len - best_no_left_clipped >= (uint32_t)min_size_after_clipping) {
+            total_cost = c;
+            cm->pos = ref_pos + best_no_left_clipped;
+            cm->type = WAMD_MAP_CLIPPING_MISMATCHES;
+            cm->clipping_len = best_no_left_clipped;
+            cm->matching_len1 = query_len - best_no_left_clipped;
+            cm->no_mismatches = best_no_left_mis_clipped + no_right_mis_raw;
+        }
+    }
+    if (best_no_right_clipped > 0 &&
+        no_left_mis_raw + best_no_right_mis_clipped < RESCALE(query_len - best_no_right_clipped)) {
+        double c = best_right_clip_cost + (fpos + fsize - no_left_mis_raw) * match_score +
+                   no_left_mis_raw * mismatch_score;
+        if (c > total_cost && query_len - best_no_right_clipped >= (uint32_t)min_size_after_clipping) {
+            total_cost = c;
+            cm->pos = ref_pos;
+            cm->type = WAMD_MAP_MISMATCHES_CLIPPING;
+            cm->clipping_len = best_no_right_clipped;
+            cm->matching_len1 = query_len - best_no_right_clipped;
+            cm->no_mismatches = no_left_mis_raw + best_no_right_mis_clipped;
+        }
+    }
+    if (best_no_left_clipped > 0 && right_indel_found &&
+        best_no_left_mis_clipped + no_right_mis_indel < RESCALE(query_len - best_no_left_clipped)) {
+        double c = best_left_clip_cost + best_right_cost + fsize * match_score;
+        if (c > total_cost && query_len - best_no_left_clipped >= (uint32_t)min_size_after_clipping) {
+            total_cost = c;
+            cm->pos = ref_pos + best_no_left_clipped;
+            cm->type = WAMD_MAP_CLIPPING_INDEL;
+            cm->indel_len1 = right_indel_size;
+            cm->clipping_len = best_no_left_clipped;
+            cm->matching_len1 = best_right_indel_pos - best_no_left_clipped;
+            cm->no_mismatches = best_no_left_mis_clipped + no_right_mis_indel;
+        }
+    }
+    if (best_no_right_clipped > 0 && left_indel_found &&
+        best_no_right_mis_clipped + no_left_mis_indel < RESCALE(query_len - best_no_right_clipped)) {
+        double c = best_right_clip_cost + best_left_cost + fsize * match_score;
+        if (c > total_cost && query_len - best_no_right_clipped >= (uint32_t)min_size_after_clipping) {
+            total_cost = c;
+            cm->pos = LEFT_POS();
+            cm->type = WAMD_MAP_INDEL_CLIPPING;
+            cm->indel_len1 = left_indel_size;
+            cm->clipping_len = best_no_right_clipped;
+            cm->matching_len1 = best_left_indel_pos;
+            cm->no_mismatches = best_no_right_mis_clipped + no_left_mis_indel;
+        }
+    }
+    if (best_no_left_clipped > 0 && best_no_right_clipped > 0 &&
+        best_no_left_mis_clipped + best_no_right_mis_clipped <
+            RESCALE(query_len - best_no_left_clipped - best_no_right_clipped)) {
+        double c = best_left_clip_cost + best_right_clip_cost + fsize * match_score;
+        if (c > total_cost &&
+            query_len - best_no_left_clipped - best_no_right_clipped >= (uint32_t)min_size_after_clipping) {
+            total_cost = c;
+            cm->pos = ref_pos + best_no_left_clipped;
+            cm->type = WAMD_MAP_CLIPPING_CLIPPING;
+            cm->clipping_len = best_no_left_clipped;
+            cm->matching_len1 = query_len - best_no_left_clipped - best_no_right_clipped;
+            cm->no_mismatches = best_no_left_mis_clipped + best_no_right_mis_clipped;
+        }
+    }
+    rc = cm->type != WAMD_MAP_NONE;
+    if (rc)
+        cm->penalty = mapping_penalty(cm->type, cm->no_mismatches);
+done:
+    cm->found = (uint32_t)rc;
+    free(g);
+    free(cand);
+    free(lm);
+    free(rm);
+    return rc;
+}
+
+/* ---- GetExtCigarNew -------------------------------------------------------- */
+
+typedef struct ec_state {
+    const uint8_t* g;
+    const uint8_t* q;
+    uint8_t* ec;
+    uint32_t i_genome, i_query;
+    uint16_t edist, events;
+    double score;
+} ec_state;
+
+static const char code2symbol[17] = "ACGTNNNNNNNNNNNN"; /* indels.cpp:69-76 */
+
+static void ec_matching(ec_state* s, uint32_t len, const wamd_scoring* sc)
+{
+    int no_mis = 0; /* append_matching_part, indels.cpp:680-702 */
+    for (uint32_t i = 0; i < len; ++i) {
+        if (s->g[s->i_genome] == s->q[s->i_query]) {
+            *s->ec++ = '.';
+        } else {
+            *s->ec++ = (uint8_t)code2symbol[s->g[s->i_genome] & 15];
+            ++no_mis;
+        }
+        ++s->i_genome;
+        ++s->i_query;
+    }
+    s->score += (len - no_mis) * sc->match + no_mis * sc->mismatch;
+    s->events = (uint16_t)(s->events + no_mis);
+    s->edist = (uint16_t)(s->edist + no_mis);
+}
+
+static void ec_indel(ec_state* s, int len, const wamd_scoring* sc)
+{
+    if (len > 0) { /* append_indel, indels.cpp:705-732 */
+        for (uint32_t i = 0; i < (uint32_t)len; ++i) {
+            *s->ec++ = '^';
+            *s->ec++ = (uint8_t)code2symbol[s->g[s->i_genome++] & 15];
+        }
+        s->score += sc->gap_del_open + (len - 1) * sc->gap_del_extend;
+        s->events = (uint16_t)(s->events + 1);
+        s->edist = (uint16_t)(s->edist + len);
+    } else {
+        for (uint32_t i = 0; i < (uint32_t)-len; ++i) {
+            *s->ec++ = '#';
+            *s->ec++ = (uint8_t)code2symbol[s->q[s->i_query++] & 15];
+        }
+        /* the reference multiplies by (indel_len - 1) with indel_len NEGATIVE (728) */
+        s->score += sc->gap_ins_open + (len - 1) * sc->gap_ins_extend;
+        s->events = (uint16_t)(s->events + 1);
+        s->edist = (uint16_t)(s->edist + -len);
+    }
+}
+
+static void ec_clipping(ec_state* s, int len, const wamd_scoring* sc)
+{
+    for (uint32_t i = 0; i < (uint32_t)len; ++i) /* append_clipping, indels.cpp:735-745 */
+        *s->ec++ = '$';
+    s->score += sc->clipping;
+    s->events = (uint16_t)(s->events + 1);
+    s->i_query += (uint32_t)len;
+}
+
+int wo_indel_ext_cigar(const uint8_t* genome_packed, const uint8_t* query, uint32_t query_len,
+                       const wamd_indel_cigar_task* t, const wamd_scoring* sc,
+                       wamd_indel_cigar_result* r, uint8_t* ext_cigar)
+{
+    /* fill_cigar_with_indel_matching prefetches read_len + 2 * max_indel + 1 symbols from
+     * examined_start_pos; the walk below never needs more than read_len + |indels| */
+    const uint32_t span = query_len + (uint32_t)abs(t->indel_len1) + (uint32_t)abs(t->indel_len2) + 8;
+    uint8_t* g = (uint8_t*)malloc(span);
+    for (uint32_t i = 0; i < span; ++i)
+        g[i] = (uint8_t)nib(genome_packed, (uint64_t)t->examined_start_pos + i);
+    ec_state s = {g, query, ext_cigar, 0, 0, 0, 0, 0.0};
+    const uint32_t read_length = query_len;
+    memset(r, 0, sizeof(*r));
+    r->ok = 1;
+    switch (t->type) {
+    case WAMD_MAP_INDEL1: /* 748-773 */
+        ec_matching(&s, t->matching_len1, sc);
+        ec_indel(&s, t->indel_len1, sc);
+        ec_matching(&s, read_length - s.i_query, sc);
+        r->method = t->indel_len1 > 0 ? 14 : 13;
+        r->ref_length = (uint16_t)((int)read_length + t->indel_len1);
+        break;
+    case WAMD_MAP_INDEL2: /* 776-811 */
+        ec_matching(&s, t->matching_len1, sc);
+        ec_indel(&s, t->indel_len1, sc);
+        ec_matching(&s, t->matching_len2, sc);
+        ec_indel(&s, t->indel_len2, sc);
+        ec_matching(&s, read_length - s.i_query, sc);
+        if (t->indel_len1 > 0)
+            r->method = t->indel_len2 > 0 ? 18 : 17;
+        else
+            r->method = t->indel_len2 > 0 ? 15 : 16;
+        r->ref_length = (uint16_t)((int)read_length + t->indel_len1 + t->indel_len2);
+        break;
+    case WAMD_MAP_CLIPPING_MISMATCHES:
+    case WAMD_MAP_MISMATCHES_CLIPPING: /* 814-848 */
+        if (t->type == WAMD_MAP_CLIPPING_MISMATCHES) {
+            r->method = 19;
+            ec_clipping(&s, (int)(read_length - t->matching_len1), sc);
+            r->left_clipping = (uint16_t)(read_length - t->matching_len1);
+        }
+        ec_matching(&s, t->matching_len1, sc);
+        if (t->type == WAMD_MAP_MISMATCHES_CLIPPING) {
+            r->method = 20;
+            ec_clipping(&s, (int)(read_length - t->matching_len1), sc);
+            r->right_clipping = (uint16_t)(read_length - t->matching_len1);
+        }
+        r->ref_length = (uint16_t)t->matching_len1;
+        break;
+    case WAMD_MAP_CLIPPING_INDEL:
+    case WAMD_MAP_INDEL_CLIPPING: /* 851-906 */
+        if (t->type == WAMD_MAP_CLIPPING_INDEL) {
+            r->method = t->indel_len1 > 0 ? 23 : 21;
+            ec_clipping(&s, (int)t->clipping_len, sc);
+            ec_matching(&s, t->matching_len1, sc);
+            ec_indel(&s, t->indel_len1, sc);
+            ec_matching(&s, query_len - s.i_query, sc);
+            r->left_clipping = (uint16_t)t->clipping_len;
+        } else {
+            r->method = t->indel_len1 > 0 ? 24 : 22;
+            ec_matching(&s, t->matching_len1, sc);
+            ec_indel(&s, t->indel_len1, sc);
+            ec_matching(&s, query_len - s.i_query - t->clipping_len, sc);
+            ec_clipping(&s, (int)t->clipping_len, sc);
+            r->right_clipping = (uint16_t)t->clipping_len;
+        }
+        r->ref_length = (uint16_t)((int)read_length - (int)t->clipping_len + t->indel_len1);
+        break;
+    case WAMD_MAP_CLIPPING_CLIPPING: /* 909-935 */
+        r->method = 25;
+        r->left_clipping = (uint16_t)t->clipping_len;
+        ec_clipping(&s, r->left_clipping, sc);
+        ec_matching(&s, t->matching_len1, sc);
+        ec_clipping(&s, (int)(read_length - t->matching_len1 - r->left_clipping), sc);
+        r->right_clipping = (uint16_t)(read_length - t->matching_len1 - r->left_clipping);
+        r->ref_length = (uint16_t)t->matching_len1;
+        break;
+    default:
+        r->ok = 0;
+        break;
+    }
+    *s.ec = 0;
+    r->score = s.score;
+    r->err_edit_distance = s.edist;
+    r->num_events = s.events;
+    r->cigar_len = (uint32_t)(s.ec - ext_cigar);
+    free(g);
+    return (int)r->ok;
+}
+
+/* ---- clipBoundaryPositions -------------------------------------------------- */
+
+void wo_clip_boundary(wamd_clip_record* d, uint8_t* ext_cigar, const wamd_scoring* sc)
+{
+    d->cigar_len = (uint32_t)strlen((const char*)ext_cigar);
+    d->no_clippings = 0;
+    if (d->err_edit_distance == 0)
+        return;
+    int mini_pos = -1, maxi_pos = -1;
+    double mini = DBL_MAX, maxi = -DBL_MAX, cur = 0;
+    const double left_penalty = d->left_clipping > 0 ? 0 : sc->clipping;
+    const double right_penalty = d->right_clipping > 0 ? 0 : sc->clipping;
+    uint8_t* in = ext_cigar + d->left_clipping;
+    uint8_t* out;
+    int in_indel = 0, pos;
+
+    for (pos = 0; *in && *in != '$'; ++pos) { /* 849-890 */
+        if (*in == '.') {
+            cur += sc->match;
+            in_indel = 0;
+            ++in;
+        } else if (*in == '#') {
+            cur += in_indel ? sc->gap_ins_extend : sc->gap_ins_open;
+            in_indel = 1;
+            in += 2;
+            ++pos;
+        } else if (*in == '^') {
+            cur += in_indel ? sc->gap_del_extend : sc->gap_del_open;
+            in_indel = 1;
+            in += 2;
+            ++pos;
+        } else if (isalpha(*in)) {
+            cur += sc->mismatch;
+            in_indel = 0;
+            ++in;
+        } else {
+            ++in; /* the reference would spin here; no such byte occurs in an ext-CIGAR */
+        }
+        if (cur < mini) {
+            mini_pos = pos;
+            mini = cur;
+        }
+        if (cur > maxi) {
+            maxi_pos = pos;
+            maxi = cur;
+        }
+    }
+    if (mini_pos + 20 > maxi_pos)
+        return;
+
+    int no_clippings = 0;
+    if (maxi + right_penalty > cur) { /* right clipping, 898-941 */
+        ++no_clippings;
+        in = ext_cigar + d->left_clipping + maxi_pos + 1;
+        out = in;
+        while (*in && *in != '$') {
+            if (*in == '.') {
+                *out++ = '$';
+                ++in;
+                ++d->right_clipping;
+                --d->ref_length;
+            } else if (*in == '#') {
+                *out++ = '$';
+                in += 2;
+                ++d->right_clipping;
+                --d->err_edit_distance;
+            } else if (*in == '^') {
+                in += 2;
+                --d->ref_length;
+                --d->err_edit_distance;
+            } else if (isalpha(*in)) {
+                *out++ = '$';
+                ++in;
+                ++d->right_clipping;
+                --d->ref_length;
+                --d->err_edit_distance;
+            } else {
+                ++in;
+            }
+        }
+        while (*in)
+            *out++ = *in++;
+        *out = 0;
+    }
+    if (mini < left_penalty) { /* left clipping, 944-991 */
+        ++no_clippings;
+        in = ext_cigar + d->left_clipping;
+        out = in;
+        uint8_t* guard = in + mini_pos + 1;
+        while (in != guard) {
+            if (*in == '.') {
+                *out++ = '$';
+                ++in;
+                ++d->left_clipping;
+                ++d->ref_seq_pos;
+                --d->ref_length;
+            } else if (*in == '#') {
+                *out++ = '$';
+                in += 2;
+                ++d->left_clipping;
+                --d->err_edit_distance;
+            } else if (*in == '^') {
+                in += 2;
+                ++d->ref_seq_pos;
+                --d->ref_length;
+                --d->err_edit_distance;
+            } else if (isalpha(*in)) {
+                *out++ = '$';
+                ++in;
+                ++d->left_clipping;
+                ++d->ref_seq_pos;
+                --d->ref_length;
+                --d->err_edit_distance;
+            } else {
+                ++in;
+            }
+        }
+        while (*in)
+            *out++ = *in++;
+        *out = 0;
+    }
+    /* 993 */
+    d->score = (0.0 > maxi ? 0.0 : maxi) - (0.0 < mini ? 0.0 : mini) + no_clippings * sc->clipping;
+    d->no_clippings = (uint32_t)no_clippings;
+    d->cigar_len = (uint32_t)strlen((const char*)ext_cigar);
+}
+
+/* ---- wire records ------------------------------------------------------------- */
+
+static uint8_t indel_size_encode(int32_t x) /* types.h:296-302 */
+{
+    return x > 0 ? (uint8_t)x : (uint8_t)(-x + 128);
+}
+
+uint32_t wo_serialize_mapping(const wamd_mapping* m, int direct, uint8_t* p)
+{
+    uint8_t* p0 = p;
+    /* StoreUInt(ptr, pos, 4): big-endian, common/utils.cpp:431-445 */
+    *p++ = (uint8_t)(m->pos >> 24);
+    *p++ = (uint8_t)(m->pos >> 16);
+    *p++ = (uint8_t)(m->pos >> 8);
+    *p++ = (uint8_t)m->pos;
+    *p++ = (uint8_t)((direct ? 0x80u : 0) + (m->type == WAMD_MAP_LEV ? 0x40u : 0) + (m->no_mismatches & 0x3f));
+    if (m->type == WAMD_MAP_LEV)
+        return (uint32_t)(p - p0);
+    *p++ = (uint8_t)m->type;
+    switch (m->type) {
+    case WAMD_MAP_INDEL1:
+        *p++ = (uint8_t)((m->matching_len1 >> 8) & 0xf);
+        *p++ = (uint8_t)(m->matching_len1 & 0xff);
+        *p++ = indel_size_encode(m->indel_len1);
+        break;
+    case WAMD_MAP_INDEL2:
+        *p++ = (uint8_t)(((m->matching_len1 >> 8) & 0xf) + ((m->matching_len2 >> 4) & 0xf0u));
+        *p++ = (uint8_t)(m->matching_len1 & 0xffu);
+        *p++ = (uint8_t)(m->matching_len2 & 0xffu);
+        *p++ = indel_size_encode(m->indel_len1);
+        *p++ = indel_size_encode(m->indel_len2);
+        break;
+    case WAMD_MAP_INDEL_CLIPPING:
+    case WAMD_MAP_CLIPPING_INDEL:
+        *p++ = (uint8_t)(((m->matching_len1 >> 8) & 0xf) + ((m->clipping_len >> 4) & 0xf0u));
+        *p++ = (uint8_t)(m->matching_len1 & 0xffu);
+        *p++ = (uint8_t)(m->clipping_len & 0xffu);
+        *p++ = indel_size_encode(m->indel_len1);
+        break;
+    case WAMD_MAP_MISMATCHES_CLIPPING:
+    case WAMD_MAP_CLIPPING_MISMATCHES:
+        *p++ = (uint8_t)((m->matching_len1 >> 8) & 0xf);
+        *p++ = (uint8_t)(m->matching_len1 & 0xffu);
+        break;
+    case WAMD_MAP_CLIPPING_CLIPPING:
+        *p++ = (uint8_t)(((m->matching_len1 >> 8) & 0xf) + ((m->clipping_len >> 4) & 0xf0u));
+        *p++ = (uint8_t)(m->matching_len1 & 0xffu);
+        *p++ = (uint8_t)(m->clipping_len & 0xffu);
+        break;
+    default:
+        break;
+    }
+    return (uint32_t)(p - p0);
+}
+
+/* ---- batch drivers --------------------------------------------------------- */
+
+int wo_indel_match_batch(const uint8_t* genome, const uint8_t* reads, const uint64_t* offsets,
+                         const uint32_t* lens, int encoding, const wamd_indel_task* tasks, uint32_t n,
+                         const wamd_indel_params* prm, wamd_mapping* results)
+{
+    uint8_t* q = (uint8_t*)malloc(64 * WO_MAX_WORDS + 8);
+    for (uint32_t i = 0; i < n; ++i) {
+        const wamd_indel_task* t = &tasks[i];
+        const uint32_t m = lens[t->read_idx];
+        wo_indel_query(q, reads + offsets[t->read_idx], m, encoding, t->flags & WAMD_TASK_FLAG_REV_COMP);
+        wo_indel_match(genome, q, m, t->ref_pos, t->max_indel_size, t->fixed_segment_pos,
+                       t->fixed_segment_size, t->max_no_mismatches, prm, &results[i]);
+    }
+    free(q);
+    return 0;
+}
+
+int wo_indel_ext_cigar_batch(const uint8_t* genome, const uint8_t* reads, const uint64_t* offsets,
+                             const uint32_t* lens, int encoding, const wamd_indel_cigar_task* tasks,
+                             uint32_t n, const wamd_scoring* sc, wamd_indel_cigar_result* results,
+                             uint8_t* cigars, uint32_t cigar_stride)
+{
+    uint8_t* q = (uint8_t*)malloc(64 * WO_MAX_WORDS + 8);
+    for (uint32_t i = 0; i < n; ++i) {
+        const wamd_indel_cigar_task* t = &tasks[i];
+        const uint32_t m = lens[t->read_idx];
+        wo_indel_query(q, reads + offsets[t->read_idx], m, encoding, t->flags & WAMD_TASK_FLAG_REV_COMP);
+        wo_indel_ext_cigar(genome, q, m, t, sc, &results[i], cigars + (size_t)i * cigar_stride);
+    }
+    free(q);
+    return 0;
+}
+
+int wo_clip_boundary_batch(uint32_t n, wamd_clip_record* records, uint8_t* cigars,
+                           uint32_t cigar_stride, const wamd_scoring* sc)
+{
+    for (uint32_t i = 0; i < n; ++i)
+        wo_clip_boundary(&records[i], cigars + (size_t)i * cigar_stride, sc);
+    return 0;
+}
+
+int wo_serialize_batch(uint32_t n, const wamd_mapping* m, const uint8_t* direction, uint8_t* out,
+                       uint8_t* sizes)
+{
+    for (uint32_t i = 0; i < n; ++i)
+        sizes[i] = (uint8_t)wo_serialize_mapping(&m[i], direction[i], out + (size_t)i * 12);
+    return 0;
+}

@@ -89,6 +89,39 @@ int wo_align_batch(const uint8_t* genome, const uint8_t* reads, const uint64_t* 
                    int last_symbol, int refine, uint32_t max_text_len, const wamd_scoring* sc,
                    wamd_align_result* results, uint8_t* cigars, uint32_t cigar_stride);
 
+/* ---- long-indel / clipping matcher, its ext-CIGAR, boundary clipping, wire records ---- */
+
+/* CIndelMatching::Preprocess / PreprocessRawSeq (indels.cpp:960-991): one code per symbol. */
+void wo_indel_query(uint8_t* query, const uint8_t* seq, uint32_t len, int encoding, int rev_comp);
+
+/* CIndelMatching::Match, indels.cpp:125-461.  query: unpacked read codes. */
+int wo_indel_match(const uint8_t* genome, const uint8_t* query, uint32_t query_len, uint32_t ref_pos,
+                   uint32_t max_indel_size, uint32_t fixed_segment_pos, uint32_t fixed_segment_size,
+                   uint32_t max_no_mismatches, const wamd_indel_params* prm, wamd_mapping* out);
+
+/* CIndelMatching::GetExtCigarNew, indels.cpp:938-957 (+ 680-935). */
+int wo_indel_ext_cigar(const uint8_t* genome, const uint8_t* query, uint32_t query_len,
+                       const wamd_indel_cigar_task* t, const wamd_scoring* sc,
+                       wamd_indel_cigar_result* r, uint8_t* ext_cigar);
+
+/* CSoftClipping::clipBoundaryPositions, soft_clipping.cpp:827-994. */
+void wo_clip_boundary(wamd_clip_record* rec, uint8_t* ext_cigar, const wamd_scoring* sc);
+
+/* candidate_mapping_t::serialize, results.cpp:161-217; returns the record size. */
+uint32_t wo_serialize_mapping(const wamd_mapping* m, int direct, uint8_t* out);
+
+int wo_indel_match_batch(const uint8_t* genome, const uint8_t* reads, const uint64_t* offsets,
+                         const uint32_t* lens, int encoding, const wamd_indel_task* tasks, uint32_t n,
+                         const wamd_indel_params* prm, wamd_mapping* results);
+int wo_indel_ext_cigar_batch(const uint8_t* genome, const uint8_t* reads, const uint64_t* offsets,
+                             const uint32_t* lens, int encoding, const wamd_indel_cigar_task* tasks,
+                             uint32_t n, const wamd_scoring* sc, wamd_indel_cigar_result* results,
+                             uint8_t* cigars, uint32_t cigar_stride);
+int wo_clip_boundary_batch(uint32_t n, wamd_clip_record* records, uint8_t* cigars,
+                           uint32_t cigar_stride, const wamd_scoring* sc);
+int wo_serialize_batch(uint32_t n, const wamd_mapping* m, const uint8_t* direction, uint8_t* out,
+                       uint8_t* sizes);
+
 #ifdef __cplusplus
 }
 #endif

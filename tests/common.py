@@ -83,3 +83,124 @@ def planted_refine_workload(n, m, k, seed, gen=None):
     blob, off, lens = host_reads(rd, 1)
     tasks = synth.distance_tasks(rd, m, k, None, 0)
     return codes, packed, (blob, off, lens), tasks
+
+
+def indel_workload(n, m, seed, max_indel=50, max_mm=12, stage_major=5, encoding=0, gen=None):
+    """Candidates for CIndelMatching::Match: reads carrying one long indel (3..max_indel) on
+    either side of the anchor segment, reads with a junk end (clipping), plain reads with a
+    few substitutions, and reads where only the anchor matches."""
+    import torch
+    from oracle import bindings as ob
+    codes, packed = gen if gen is not None else genome()
+    g = torch.Generator().manual_seed(seed)
+    G = codes.numel()
+    segs = stage_segments(m, stage_major)
+    out = torch.zeros((n, m), dtype=torch.uint8)
+    tasks = np.zeros(n, ob.INDEL_TASK)
+
+    def rnd(lo, hi):
+        return int(torch.randint(lo, hi, (1,), generator=g))
+
+    clean = codes.clone()
+    for i in range(n):
+        fl, fr = segs[rnd(0, len(segs))]
+        p = rnd(synth.BOUNDARY_N_LEN + 200, G - synth.BOUNDARY_N_LEN - m - 200)
+        base = clean[p:p + m].clone()
+        kind = i % 8
+        L = rnd(3, max_indel + 1)
+        r = base.clone()
+        if kind in (0, 1) and fl > 12:          # indel left of the anchor
+            x = rnd(8, fl)                      # read[x:] stays aligned at p
+            if kind == 0:                       # deletion: the prefix comes from L earlier
+                r[:x] = clean[p - L:p - L + x]
+            else:                               # insertion of L (or fewer) random symbols
+                Li = min(L, x - 7) if x - 7 >= 3 else 0
+                if Li:
+                    r[:x - Li] = clean[p + Li:p + x]
+                    r[x - Li:x] = torch.randint(0, 4, (Li,), generator=g, dtype=torch.uint8)
+        elif kind in (2, 3) and m - fr > 12:    # indel right of the anchor
+            x = rnd(fr, m - 8)
+            if kind == 2:
+                r[x:] = clean[p + x + L:p + m + L]
+            else:
+                Li = min(L, m - x - 7) if m - x - 7 >= 3 else 0
+                if Li:
+                    r[x:x + Li] = torch.randint(0, 4, (Li,), generator=g, dtype=torch.uint8)
+                    r[x + Li:] = clean[p + x:p + m - Li]
+        elif kind == 4 and fl > 25:             # junk at the left end
+            c = rnd(10, fl - 5)
+            r[:c] = torch.randint(0, 4, (c,), generator=g, dtype=torch.uint8)
+        elif kind == 5 and m - fr > 25:         # junk at the right end
+            c = rnd(10, m - fr - 5)
+            r[m - c:] = torch.randint(0, 4, (c,), generator=g, dtype=torch.uint8)
+        elif kind == 6:                         # both: indel on the left, junk on the right
+            if fl > 12:
+                x = rnd(8, fl)
+                r[:x] = clean[p - L:p - L + x]
+            if m - fr > 25:
+                c = rnd(10, m - fr - 5)
+                r[m - c:] = torch.randint(0, 4, (c,), generator=g, dtype=torch.uint8)
+        else:                                   # only the anchor is shared
+            if i % 16 == 7:
+                r = torch.randint(0, 4, (m,), generator=g, dtype=torch.uint8)
+                r[fl:fr] = base[fl:fr]
+        for _ in range(rnd(0, 4)):              # a few substitutions outside the anchor
+            z = rnd(0, m)
+            if not (fl <= z < fr):
+                r[z] = (int(r[z]) + rnd(1, 4)) & 3
+        r[r > 3] = 4
+        if i % 31 == 0:
+            r[fl:fr] = base[fl:fr]
+            r[(fl + 3) % m if not (fl <= (fl + 3) % m < fr) else 0] = 4
+        out[i] = r
+        tasks[i] = (i, p, max_indel, fl, fr - fl, max_mm, 0)
+    rd = dict(codes=out)
+    blob, off, lens = host_reads(rd, encoding)
+    return codes, packed, (blob, off, lens), tasks
+
+
+def indel_cigar_tasks(match_tasks, mappings):
+    """fill_cigar_with_indel_matching inputs for the mappings Match found (direct strand:
+    examined_start_pos = mapping.pos, sam_matching.cpp:826-828)."""
+    from oracle import bindings as ob
+    idx = np.nonzero(mappings["found"])[0]
+    t = np.zeros(len(idx), ob.INDEL_CIGAR_TASK)
+    t["read_idx"] = match_tasks["read_idx"][idx]
+    t["examined_start_pos"] = mappings["pos"][idx]
+    for f in ("type", "matching_len1", "matching_len2", "indel_len1", "indel_len2", "clipping_len"):
+        t[f] = mappings[f][idx]
+    return t
+
+
+def clip_workload(n, m, seed, gen=None):
+    """ext-CIGARs with noisy ends (what clipBoundaryPositions clips) produced by aligning
+    reads whose first / last symbols are junk; returns (records, cigars) as the caller of
+    clipBoundaryPositions holds them after fill_cigar_with_lev."""
+    import torch
+    from oracle import bindings as ob
+    codes, packed = gen if gen is not None else genome()
+    g = torch.Generator().manual_seed(seed)
+    k = 40
+    rd = synth.make_reads(codes, n, m, 4, seed, true_frac=1.0, rc_frac=0.3)
+    r = rd["codes"]
+    for i in range(n):
+        side = i % 4
+        c = int(torch.randint(8, 30, (1,), generator=g))
+        junk = torch.randint(0, 4, (c,), generator=g, dtype=torch.uint8)
+        if side in (0, 2):
+            r[i, :c] = junk
+        if side in (1, 2):
+            c2 = int(torch.randint(8, 30, (1,), generator=g))
+            r[i, m - c2:] = torch.randint(0, 4, (c2,), generator=g, dtype=torch.uint8)
+    blob, off, lens = host_reads(rd, 1)
+    tasks = synth.distance_tasks(rd, m, k)
+    orc = ob.Oracle()
+    stride = 4 * ((2 * (m + k) + 8 + 3) // 4)
+    rc, res, cig = orc.align(packed, blob, off, lens, 1, tasks, 0, 1, cigar_stride=stride)
+    ok = np.nonzero(res["ok"])[0]
+    rec = np.zeros(len(ok), ob.CLIP_RECORD)
+    rec["score"] = res["affine_score"][ok]
+    rec["ref_seq_pos"] = 1000 + res["begin_pos"][ok]
+    rec["ref_length"] = (res["end_pos"][ok] - res["begin_pos"][ok]).astype(np.uint16)
+    rec["err_edit_distance"] = res["edit_distance"][ok]
+    return rec, np.ascontiguousarray(cig[ok])

@@ -106,6 +106,26 @@ def main():
                             lens=lens, encoding=1, last_symbol=0, refine=1, tasks=tasks,
                             results=res, cigars=cig, cigar_stride=stride)
         print(name, "ok", int(res["ok"].sum()), "refined", int(res["refined"].sum()), "of", n)
+    for name, enc, mcf, n in [("indel_m150_nibble", 0, 1.0, 800), ("indel_m150_ascii_clip06", 1, 0.6, 800)]:
+        seed += 1
+        _, _, (blob, off, lens), tasks = common.indel_workload(n, 150, seed, encoding=enc, gen=(codes, packed))
+        prm = bindings.default_indel_params(mcf)
+        rc, res = ref.indel_match(packed, blob, off, lens, enc, tasks, prm)
+        ct = common.indel_cigar_tasks(tasks, res)
+        rc, cres, ccig = ref.indel_ext_cigar(packed, blob, off, lens, enc, ct, cigar_stride=512)
+        direction = (np.arange(len(res)) % 3 != 0).astype(np.uint8)
+        rc, wire, sizes = ref.serialize(res, direction)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), kind="indel", blob=blob, off=off, lens=lens,
+                            encoding=enc, min_clipped_factor=mcf, tasks=tasks, results=res,
+                            cigar_tasks=ct, cigar_results=cres, cigars=ccig, cigar_stride=512,
+                            direction=direction, wire=wire, wire_sizes=sizes)
+        print(name, "found", int(res["found"].sum()), "types", np.bincount(res["type"][res["found"] == 1], minlength=9))
+    seed += 1
+    rec, cig = common.clip_workload(1200, 150, seed, gen=(codes, packed))
+    rc, rec2, cig2 = ref.clip_boundary(rec, cig)
+    np.savez_compressed(os.path.join(HERE, "clip_m150.npz"), kind="clip", records=rec, cigars=cig,
+                        out_records=rec2, out_cigars=cig2)
+    print("clip_m150 changed", int((cig2 != cig).any(axis=1).sum()), "of", len(rec))
 
 
 if __name__ == "__main__":

@@ -17,7 +17,8 @@ def cases(kind):
         name = os.path.basename(f)[:-4]
         if name == "genome":
             continue
-        prefix = {"distance": "dist_", "levdiag": "lev_", "align": "align_"}[kind]
+        prefix = {"distance": "dist_", "levdiag": "lev_", "align": "align_", "indel": "indel_",
+                  "clip": "clip_"}[kind]
         if name.startswith(prefix):
             out.append(name)
     return out

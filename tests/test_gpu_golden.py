@@ -49,3 +49,33 @@ def test_align(ctx, name):
         np.testing.assert_array_equal(got[f], want[f], err_msg=f)
     for i in np.nonzero(want["ok"])[0]:
         assert gu.cigar_bytes(cig, i) == gu.cigar_bytes(z["cigars"], i), i
+
+
+@pytest.mark.parametrize("name", gu.cases("indel"))
+def test_indel_match_cigar_and_records(ctx, name):
+    z = gu.load(name)
+    enc = int(z["encoding"])
+    reads = ctx.upload_reads(z["blob"], z["off"], z["lens"], enc, orientations=1)
+    got = ctx.indel_match(reads, z["tasks"], api.default_indel_params(float(z["min_clipped_factor"])))
+    np.testing.assert_array_equal(got, z["results"])
+    cres, ccig = ctx.indel_ext_cigar(reads, z["cigar_tasks"], cigar_stride=int(z["cigar_stride"]))
+    reads.free()
+    np.testing.assert_array_equal(cres, z["cigar_results"])
+    for i in range(len(cres)):
+        assert gu.cigar_bytes(ccig, i) == gu.cigar_bytes(z["cigars"], i), i
+    wire, sizes = ctx.serialize_mappings(z["results"], z["direction"])
+    np.testing.assert_array_equal(sizes, z["wire_sizes"])
+    for i in range(len(sizes)):
+        assert bytes(wire[i, :sizes[i]]) == bytes(z["wire"][i, :sizes[i]]), i
+
+
+@pytest.mark.parametrize("name", gu.cases("clip"))
+def test_clip_boundary(ctx, name):
+    z = gu.load(name)
+    rec, cig = ctx.clip_boundary(z["records"], z["cigars"])
+    want = z["out_records"]
+    for f in want.dtype.names:
+        if f not in ("no_clippings", "reserved"):
+            np.testing.assert_array_equal(rec[f], want[f], err_msg=f)
+    for i in range(len(rec)):
+        assert gu.cigar_bytes(cig, i) == gu.cigar_bytes(z["out_cigars"], i), i

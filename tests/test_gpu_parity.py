@@ -173,3 +173,66 @@ def test_align(ctx, oracle, m, k, W, last, refine, variant):
     for i in np.nonzero(want["ok"])[0]:
         n = want["cigar_len"][i]
         assert bytes(gcig[i, :n + 1]) == bytes(wcig[i, :n + 1]), i
+
+
+@pytest.mark.parametrize("m,enc,mcf,stage", [(150, 0, 1.0, 5), (150, 1, 0.6, 5), (100, 0, 0.5, 4), (250, 0, 1.0, 4)])
+def test_indel_match_chain(ctx, oracle, m, enc, mcf, stage):
+    """Match -> GetExtCigarNew -> serialize, each against the oracle."""
+    from oracle import bindings
+    codes, packed, (blob, off, lens), tasks = common.indel_workload(2000, m, seed=400 + m + enc, encoding=enc,
+                                                                   stage_major=stage)
+    _, want = oracle.indel_match(packed, blob, off, lens, enc, tasks, bindings.default_indel_params(mcf))
+    reads = ctx.upload_reads(blob, off, lens, enc, orientations=1)
+    got = ctx.indel_match(reads, tasks, api.default_indel_params(mcf))
+    assert want["found"].sum() > 500
+    np.testing.assert_array_equal(got, want)
+    ct = common.indel_cigar_tasks(tasks, want)
+    stride = 4 * ((2 * (m + 120) + 8 + 3) // 4)
+    _, wres, wcig = oracle.indel_ext_cigar(packed, blob, off, lens, enc, ct, cigar_stride=stride)
+    gres, gcig = ctx.indel_ext_cigar(reads, ct, cigar_stride=stride)
+    reads.free()
+    np.testing.assert_array_equal(gres, wres)
+    for i in range(len(wres)):
+        n = wres["cigar_len"][i] + 1
+        assert bytes(gcig[i, :n]) == bytes(wcig[i, :n]), i
+    d = (np.arange(len(want)) % 2).astype(np.uint8)
+    _, wwire, wsz = oracle.serialize(want, d)
+    gwire, gsz = ctx.serialize_mappings(want, d)
+    np.testing.assert_array_equal(gsz, wsz)
+    np.testing.assert_array_equal(gwire, wwire)
+
+
+def test_indel_match_rev_comp(ctx, oracle):
+    """rev_comp orientation of the read (Preprocess with genome_t::rev_comp, indels.cpp:969-971)."""
+    import torch
+    from whisper_amd import synth
+    codes, packed, (blob, off, lens), tasks = common.indel_workload(1500, 150, seed=8)
+    # store every read reverse-complemented and ask for the rev_comp orientation
+    n = len(tasks)
+    stride = blob.size // n
+    rd = torch.zeros((n, 150), dtype=torch.uint8)
+    b = torch.from_numpy(blob.reshape(n, stride))
+    rd[:, 0::2] = b >> 4
+    rd[:, 1::2] = b & 15
+    rc = synth.rev_comp(rd)
+    blob2, off2, lens2 = common.host_reads(dict(codes=rc), 0)
+    t2 = tasks.copy()
+    t2["flags"] = 1
+    _, want = oracle.indel_match(packed, blob2, off2, lens2, 0, t2)
+    _, direct = oracle.indel_match(packed, blob, off, lens, 0, tasks)
+    np.testing.assert_array_equal(want, direct)
+    reads = ctx.upload_reads(blob2, off2, lens2, 0, orientations=2)
+    got = ctx.indel_match(reads, t2)
+    reads.free()
+    np.testing.assert_array_equal(got, want)
+
+
+def test_clip_boundary(ctx, oracle):
+    rec, cig = common.clip_workload(3000, 150, seed=21)
+    _, wrec, wcig = oracle.clip_boundary(rec, cig)
+    grec, gcig = ctx.clip_boundary(rec, cig)
+    assert (wrec["no_clippings"] > 0).sum() > 1000
+    np.testing.assert_array_equal(grec, wrec)
+    for i in range(len(rec)):
+        n = wrec["cigar_len"][i] + 1
+        assert bytes(gcig[i, :n]) == bytes(wcig[i, :n]), i

@@ -39,3 +39,32 @@ def test_align(oracle, name):
         np.testing.assert_array_equal(res[f], want[f], err_msg=f)
     for i in np.nonzero(want["ok"])[0]:
         assert gu.cigar_bytes(cig, i) == gu.cigar_bytes(z["cigars"], i), i
+
+
+@pytest.mark.parametrize("name", gu.cases("indel"))
+def test_indel_match_cigar_and_records(oracle, name):
+    from oracle import bindings
+    packed, _ = gu.load_genome()
+    z = gu.load(name)
+    enc = int(z["encoding"])
+    prm = bindings.default_indel_params(float(z["min_clipped_factor"]))
+    rc, res = oracle.indel_match(packed, z["blob"], z["off"], z["lens"], enc, z["tasks"], prm)
+    np.testing.assert_array_equal(res, z["results"])
+    rc, cres, ccig = oracle.indel_ext_cigar(packed, z["blob"], z["off"], z["lens"], enc, z["cigar_tasks"],
+                                            cigar_stride=int(z["cigar_stride"]))
+    np.testing.assert_array_equal(cres, z["cigar_results"])
+    np.testing.assert_array_equal(ccig, z["cigars"])
+    rc, wire, sizes = oracle.serialize(z["results"], z["direction"])
+    np.testing.assert_array_equal(wire, z["wire"])
+    np.testing.assert_array_equal(sizes, z["wire_sizes"])
+
+
+@pytest.mark.parametrize("name", gu.cases("clip"))
+def test_clip_boundary(oracle, name):
+    z = gu.load(name)
+    rc, rec, cig = oracle.clip_boundary(z["records"], z["cigars"])
+    want = z["out_records"]
+    for f in want.dtype.names:
+        if f != "no_clippings":      # not a field of the reference's mapping_desc_t
+            np.testing.assert_array_equal(rec[f], want[f], err_msg=f)
+    np.testing.assert_array_equal(cig, z["out_cigars"])

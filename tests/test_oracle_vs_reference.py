@@ -62,3 +62,43 @@ def test_align_planted_refinement(oracle, reference):
     for f in a.dtype.names:
         np.testing.assert_array_equal(a[f], b[f], err_msg=f)
     assert (ca == cb).all()
+
+
+@pytest.mark.parametrize("enc,mcf", [(0, 1.0), (0, 0.6), (1, 1.0), (1, 0.5)])
+def test_indel_match_cigar_serialize(oracle, reference, enc, mcf):
+    from oracle import bindings
+    codes, packed, (blob, off, lens), tasks = common.indel_workload(2500, 150, seed=31 + enc, encoding=enc)
+    prm = bindings.default_indel_params(mcf)
+    _, a = oracle.indel_match(packed, blob, off, lens, enc, tasks, prm)
+    _, b = reference.indel_match(packed, blob, off, lens, enc, tasks, prm)
+    assert b["found"].sum() > 800
+    np.testing.assert_array_equal(a, b)
+    ct = common.indel_cigar_tasks(tasks, b)
+    _, ra, ca = oracle.indel_ext_cigar(packed, blob, off, lens, enc, ct)
+    _, rb, cb = reference.indel_ext_cigar(packed, blob, off, lens, enc, ct)
+    np.testing.assert_array_equal(ra, rb)
+    np.testing.assert_array_equal(ca, cb)
+    d = (np.arange(len(b)) % 2).astype(np.uint8)
+    _, wa, sa = oracle.serialize(b, d)
+    _, wb, sb = reference.serialize(b, d)
+    np.testing.assert_array_equal(wa, wb)
+    np.testing.assert_array_equal(sa, sb)
+
+
+def test_indel_match_m100_and_m250(oracle, reference):
+    for m in (100, 250):
+        codes, packed, (blob, off, lens), tasks = common.indel_workload(1200, m, seed=m, stage_major=4)
+        _, a = oracle.indel_match(packed, blob, off, lens, 0, tasks)
+        _, b = reference.indel_match(packed, blob, off, lens, 0, tasks)
+        np.testing.assert_array_equal(a, b)
+
+
+def test_clip_boundary(oracle, reference):
+    rec, cig = common.clip_workload(2500, 150, seed=17)
+    _, ra, ca = oracle.clip_boundary(rec, cig)
+    _, rb, cb = reference.clip_boundary(rec, cig)
+    assert (cb != cig).any(axis=1).sum() > 1000
+    for f in ra.dtype.names:
+        if f != "no_clippings":
+            np.testing.assert_array_equal(ra[f], rb[f], err_msg=f)
+    np.testing.assert_array_equal(ca, cb)

@@ -32,6 +32,25 @@ ALIGN_RESULT = np.dtype([("affine_score", "<f8"), ("ok", "<u4"), ("edit_distance
                          ("end_pos", "<u4"), ("begin_pos", "<u4"), ("num_events", "<u4"),
                          ("cigar_len", "<u4"), ("refined", "<u4"), ("reserved", "<u4")])
 
+INDEL_TASK = np.dtype([("read_idx", "<u4"), ("ref_pos", "<u4"), ("max_indel_size", "<u2"),
+                       ("fixed_segment_pos", "<u2"), ("fixed_segment_size", "<u2"),
+                       ("max_no_mismatches", "u1"), ("flags", "u1")])
+MAPPING = np.dtype([("found", "<u4"), ("type", "<u4"), ("pos", "<u4"), ("no_mismatches", "<u4"),
+                    ("matching_len1", "<u4"), ("matching_len2", "<u4"), ("indel_len1", "<i4"),
+                    ("indel_len2", "<i4"), ("clipping_len", "<u4"), ("penalty", "<u4")])
+INDEL_CIGAR_TASK = np.dtype([("read_idx", "<u4"), ("examined_start_pos", "<u4"), ("type", "<u4"),
+                             ("matching_len1", "<u4"), ("matching_len2", "<u4"), ("indel_len1", "<i4"),
+                             ("indel_len2", "<i4"), ("clipping_len", "<u4"), ("flags", "<u4"),
+                             ("reserved", "<u4")])
+INDEL_CIGAR_RESULT = np.dtype([("score", "<f8"), ("ok", "<u4"), ("cigar_len", "<u4"),
+                               ("err_edit_distance", "<u2"), ("num_events", "<u2"),
+                               ("ref_length", "<u2"), ("left_clipping", "<u2"),
+                               ("right_clipping", "<u2"), ("method", "<u2"), ("reserved", "<u4")])
+CLIP_RECORD = np.dtype([("score", "<f8"), ("ref_seq_pos", "<i4"), ("ref_length", "<u2"),
+                        ("err_edit_distance", "<u2"), ("left_clipping", "<u2"),
+                        ("right_clipping", "<u2"), ("cigar_len", "<u4"), ("no_clippings", "<u4"),
+                        ("reserved", "<u4")])
+
 STATUS = {0: "WAMD_OK", 1: "WAMD_ERR_INVALID_ARG", 2: "WAMD_ERR_HIP", 3: "WAMD_ERR_NO_DEVICE",
           4: "WAMD_ERR_TOO_LONG", 5: "WAMD_ERR_TEXT_LEN", 6: "WAMD_ERR_RANGE",
           7: "WAMD_ERR_NO_MEMORY", 8: "WAMD_ERR_CAPACITY"}
@@ -43,12 +62,24 @@ EXPORTS = [
     "wamd_ctx_synchronize", "wamd_ctx_take_flags", "wamd_reads_upload", "wamd_reads_free",
     "wamd_reads_count", "wamd_verify_distance", "wamd_verify_distance_dev", "wamd_levdiag",
     "wamd_levdiag_dev", "wamd_align", "wamd_align_dev", "wamd_align_workspace_bytes",
+    "wamd_indel_match", "wamd_indel_match_dev", "wamd_indel_ext_cigar", "wamd_indel_ext_cigar_dev",
+    "wamd_clip_boundary", "wamd_clip_boundary_dev", "wamd_serialize_mappings",
+    "wamd_serialize_mappings_dev",
 ]
 
 
 class Scoring(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("match", "mismatch", "gap_ins_open", "gap_ins_extend",
                                            "gap_del_open", "gap_del_extend", "clipping")]
+
+
+class IndelParams(C.Structure):
+    _fields_ = [("scoring", Scoring), ("min_clipped_factor", C.c_double)]
+
+
+def default_indel_params(min_clipped_factor=1.0):
+    # mapper/params.h:145-158
+    return IndelParams(Scoring(1.0, -5.0, -5.0, -0.4, -5.0, -0.4, -6.0), min_clipped_factor)
 
 
 class WamdError(RuntimeError):
@@ -193,6 +224,42 @@ class Context:
                                 C.c_int(last_symbol), C.c_int(refine), _ptr(res), _ptr(cig),
                                 C.c_uint32(cigar_stride)))
         return res, cig
+
+    def indel_match(self, reads, tasks, params=None):
+        """CIndelMatching::Match for a batch (indels.cpp:125-461)."""
+        tasks = np.ascontiguousarray(tasks, INDEL_TASK)
+        prm = params or default_indel_params()
+        res = np.zeros(len(tasks), MAPPING)
+        _check(lib().wamd_indel_match(self.h, reads.h, _ptr(tasks), C.c_uint32(len(tasks)),
+                                      C.byref(prm), _ptr(res)))
+        return res
+
+    def indel_ext_cigar(self, reads, tasks, cigar_stride=1024):
+        """CIndelMatching::GetExtCigarNew for a batch (indels.cpp:938-957)."""
+        tasks = np.ascontiguousarray(tasks, INDEL_CIGAR_TASK)
+        res = np.zeros(len(tasks), INDEL_CIGAR_RESULT)
+        cig = np.zeros((len(tasks), cigar_stride), np.uint8)
+        _check(lib().wamd_indel_ext_cigar(self.h, reads.h, _ptr(tasks), C.c_uint32(len(tasks)),
+                                          _ptr(res), _ptr(cig), C.c_uint32(cigar_stride)))
+        return res, cig
+
+    def clip_boundary(self, records, cigars):
+        """CSoftClipping::clipBoundaryPositions for a batch (soft_clipping.cpp:827-994)."""
+        rec = np.array(records, CLIP_RECORD, copy=True)
+        cig = np.array(cigars, np.uint8, copy=True)
+        _check(lib().wamd_clip_boundary(self.h, C.c_uint32(len(rec)), _ptr(rec), _ptr(cig),
+                                        C.c_uint32(cig.shape[1])))
+        return rec, cig
+
+    def serialize_mappings(self, mappings, direction):
+        """candidate_mapping_t::serialize for a batch (results.cpp:161-217)."""
+        m = np.ascontiguousarray(mappings, MAPPING)
+        d = np.ascontiguousarray(direction, np.uint8)
+        out = np.zeros((len(m), 12), np.uint8)
+        sizes = np.zeros(len(m), np.uint8)
+        _check(lib().wamd_serialize_mappings(self.h, C.c_uint32(len(m)), _ptr(m), _ptr(d), _ptr(out),
+                                             _ptr(sizes)))
+        return out, sizes
 
     # ---- device-pointer entry points (torch tensors on this device) ----------------------
     def dynamic_programming_dev(self, reads, d_tasks, n, d_results, last_symbol=-1, stream=None):

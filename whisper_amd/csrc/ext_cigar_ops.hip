@@ -1,0 +1,472 @@
+// ext_cigar_ops.hip - the linear passes of the post-processing half of the path:
+//   * CIndelMatching::GetExtCigarNew   (mapper/indels.cpp:938-957, 680-935)
+//   * CSoftClipping::clipBoundaryPositions (mapper/soft_clipping.cpp:827-994)
+//   * candidate_mapping_t::serialize   (mapper/results.cpp:161-217)
+// One record per lane.  All three are byte-stream scans with a handful of double adds
+// in a fixed order, so they are HBM/latency bound; they exist on the device so that
+// ext-CIGARs produced by the align kernels need not travel to the host and back.
+#include "wamd_internal.h"
+
+namespace wamd {
+
+// rev_comp_code of CIndelMatching (indels.cpp:40-49)
+__device__ __forceinline__ uint32_t rc_code_indel2(uint32_t c) { return c < 4 ? 3 - c : (c < 8 ? c : 15); }
+
+// code2symbol of CIndelMatching (indels.cpp:69-76): ACGT, everything else 'N'
+__device__ __forceinline__ uint32_t code2symbol(uint32_t c)
+{
+    return c < 4 ? ((0x54474341u >> (8 * c)) & 0xffu) : (uint32_t)'N';
+}
+
+struct CigarWriter {
+    uint8_t* slot;
+    uint32_t cur, acc;
+    __device__ __forceinline__ void put(uint32_t b)
+    {
+        acc |= b << (8 * (cur & 3u));
+        ++cur;
+        if ((cur & 3u) == 0) {
+            *reinterpret_cast<uint32_t*>(slot + cur - 4) = acc;
+            acc = 0;
+        }
+    }
+    __device__ __forceinline__ uint32_t finish()
+    {
+        const uint32_t len = cur;
+        put(0);
+        if (cur & 3u)
+            *reinterpret_cast<uint32_t*>(slot + (cur & ~3u)) = acc;
+        return len;
+    }
+};
+
+__global__ __launch_bounds__(256) void indel_ext_cigar_kernel(const uint8_t* __restrict__ genome,
+                                                              uint64_t genome_symbols, ReadsView rv,
+                                                              const wamd_indel_cigar_task* __restrict__ tasks,
+                                                              uint32_t n, wamd_scoring sc,
+                                                              wamd_indel_cigar_result* __restrict__ results,
+                                                              uint8_t* __restrict__ cigars, uint32_t cigar_stride,
+                                                              uint32_t* __restrict__ flags)
+{
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n)
+        return;
+    const wamd_indel_cigar_task t = tasks[gid];
+    wamd_indel_cigar_result r;
+    r.score = 0;
+    r.ok = 0;
+    r.cigar_len = 0;
+    r.err_edit_distance = r.num_events = r.ref_length = r.left_clipping = r.right_clipping = r.method = 0;
+    r.reserved = 0;
+    uint8_t* slot = cigars + (uint64_t)gid * cigar_stride;
+    slot[0] = 0;
+    uint32_t err = 0;
+    uint32_t m = 0;
+    if (t.read_idx >= rv.n)
+        err = FLAG_READ_IDX;
+    else
+        m = rv.lens[t.read_idx];
+    const uint32_t a1 = t.indel_len1 < 0 ? -t.indel_len1 : t.indel_len1;
+    const uint32_t a2 = t.indel_len2 < 0 ? -t.indel_len2 : t.indel_len2;
+    if (!err && (uint64_t)t.examined_start_pos + m + a1 + a2 + 1 > genome_symbols)
+        err = FLAG_RANGE;
+    if (!err && 2 * (m + a1 + a2) + 8 > cigar_stride)
+        err = FLAG_CIGAR;
+    if (!err && (t.matching_len1 > m || t.matching_len2 > m || t.clipping_len > m))
+        err = FLAG_ARG;
+    if (err) {
+        raise_flag(flags, err);
+        results[gid] = r;
+        return;
+    }
+    const uint8_t* codes = rv.codes + rv.code_off[t.read_idx];
+    const bool rev = t.flags & WAMD_TASK_FLAG_REV_COMP;
+    auto Q = [&](uint32_t i) -> uint32_t {
+        return rev ? rc_code_indel2(packed_symbol(codes, m - 1 - i)) : packed_symbol(codes, i);
+    };
+    auto G = [&](uint32_t i) -> uint32_t { return packed_symbol(genome, (uint64_t)t.examined_start_pos + i); };
+
+    CigarWriter w{slot, 0, 0};
+    uint32_t i_genome = 0, i_query = 0;
+    uint16_t edist = 0, events = 0;
+    double score = 0;
+    bool overflow = false;
+
+    auto matching = [&](uint32_t len) {   // append_matching_part, indels.cpp:680-702
+        if (i_query + len > m) {
+            overflow = true;
+            return;
+        }
+        int no_mis = 0;
+        for (uint32_t i = 0; i < len; ++i) {
+            const uint32_t g = G(i_genome), q = Q(i_query);
+            if (g == q) {
+                w.put('.');
+            } else {
+                w.put(code2symbol(g));
+                ++no_mis;
+            }
+            ++i_genome;
+            ++i_query;
+        }
+        score += (len - no_mis) * sc.match + no_mis * sc.mismatch;
+        events = (uint16_t)(events + no_mis);
+        edist = (uint16_t)(edist + no_mis);
+    };
+    auto indel = [&](int len) {   // append_indel, indels.cpp:705-732
+        if (len > 0) {
+            for (uint32_t i = 0; i < (uint32_t)len; ++i) {
+                w.put('^');
+                w.put(code2symbol(G(i_genome++)));
+            }
+            score += sc.gap_del_open + (len - 1) * sc.gap_del_extend;
+            events = (uint16_t)(events + 1);
+            edist = (uint16_t)(edist + len);
+        } else {
+            if (i_query + (uint32_t)-len > m) {
+                overflow = true;
+                return;
+            }
+            for (uint32_t i = 0; i < (uint32_t)-len; ++i) {
+                w.put('#');
+                w.put(code2symbol(Q(i_query++)));
+            }
+            // the reference multiplies by (indel_len - 1) with indel_len negative (728)
+            score += sc.gap_ins_open + (len - 1) * sc.gap_ins_extend;
+            events = (uint16_t)(events + 1);
+            edist = (uint16_t)(edist + -len);
+        }
+    };
+    auto clipping = [&](int len) {   // append_clipping, indels.cpp:735-745
+        if (len < 0 || i_query + (uint32_t)len > m) {
+            overflow = true;
+            return;
+        }
+        for (uint32_t i = 0; i < (uint32_t)len; ++i)
+            w.put('$');
+        score += sc.clipping;
+        events = (uint16_t)(events + 1);
+        i_query += (uint32_t)len;
+    };
+
+    r.ok = 1;
+    switch (t.type) {
+    case WAMD_MAP_INDEL1:   // indels.cpp:748-773
+        matching(t.matching_len1);
+        indel(t.indel_len1);
+        matching(m - i_query);
+        r.method = t.indel_len1 > 0 ? 14 : 13;
+        r.ref_length = (uint16_t)((int)m + t.indel_len1);
+        break;
+    case WAMD_MAP_INDEL2:   // 776-811
+        matching(t.matching_len1);
+        indel(t.indel_len1);
+        matching(t.matching_len2);
+        indel(t.indel_len2);
+        matching(m - i_query);
+        r.method = t.indel_len1 > 0 ? (t.indel_len2 > 0 ? 18 : 17) : (t.indel_len2 > 0 ? 15 : 16);
+        r.ref_length = (uint16_t)((int)m + t.indel_len1 + t.indel_len2);
+        break;
+    case WAMD_MAP_CLIPPING_MISMATCHES:
+    case WAMD_MAP_MISMATCHES_CLIPPING:   // 814-848
+        if (t.type == WAMD_MAP_CLIPPING_MISMATCHES) {
+            r.method = 19;
+            clipping((int)(m - t.matching_len1));
+            r.left_clipping = (uint16_t)(m - t.matching_len1);
+        }
+        matching(t.matching_len1);
+        if (t.type == WAMD_MAP_MISMATCHES_CLIPPING) {
+            r.method = 20;
+            clipping((int)(m - t.matching_len1));
+            r.right_clipping = (uint16_t)(m - t.matching_len1);
+        }
+        r.ref_length = (uint16_t)t.matching_len1;
+        break;
+    case WAMD_MAP_CLIPPING_INDEL:
+    case WAMD_MAP_INDEL_CLIPPING:   // 851-906
+        if (t.type == WAMD_MAP_CLIPPING_INDEL) {
+            r.method = t.indel_len1 > 0 ? 23 : 21;
+            clipping((int)t.clipping_len);
+            matching(t.matching_len1);
+            indel(t.indel_len1);
+            matching(m - i_query);
+            r.left_clipping = (uint16_t)t.clipping_len;
+        } else {
+            r.method = t.indel_len1 > 0 ? 24 : 22;
+            matching(t.matching_len1);
+            indel(t.indel_len1);
+            matching(m - i_query - t.clipping_len);
+            clipping((int)t.clipping_len);
+            r.right_clipping = (uint16_t)t.clipping_len;
+        }
+        r.ref_length = (uint16_t)((int)m - (int)t.clipping_len + t.indel_len1);
+        break;
+    case WAMD_MAP_CLIPPING_CLIPPING:   // 909-935
+        r.method = 25;
+        r.left_clipping = (uint16_t)t.clipping_len;
+        clipping((int)r.left_clipping);
+        matching(t.matching_len1);
+        clipping((int)(m - t.matching_len1 - r.left_clipping));
+        r.right_clipping = (uint16_t)(m - t.matching_len1 - r.left_clipping);
+        r.ref_length = (uint16_t)t.matching_len1;
+        break;
+    default:
+        r.ok = 0;
+        break;
+    }
+    if (overflow) {   // a record that does not describe this read
+        raise_flag(flags, FLAG_ARG);
+        r.ok = 0;
+    }
+    r.cigar_len = w.finish();
+    r.score = score;
+    r.err_edit_distance = edist;
+    r.num_events = events;
+    results[gid] = r;
+}
+
+__device__ __forceinline__ bool is_alpha(uint32_t c) { return ((c | 32u) - 'a') < 26u; }
+
+__global__ __launch_bounds__(256) void clip_boundary_kernel(uint32_t n, wamd_clip_record* __restrict__ records,
+                                                            uint8_t* __restrict__ cigars, uint32_t cigar_stride,
+                                                            wamd_scoring sc)
+{
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n)
+        return;
+    wamd_clip_record d = records[gid];
+    uint8_t* ec = cigars + (uint64_t)gid * cigar_stride;
+    d.no_clippings = 0;
+
+    auto length = [&]() {
+        uint32_t l = 0;
+        while (l < cigar_stride && ec[l])
+            ++l;
+        return l;
+    };
+    if (d.err_edit_distance == 0) {
+        d.cigar_len = length();
+        records[gid] = d;
+        return;
+    }
+    int mini_pos = -1, maxi_pos = -1;
+    double mini = 1.7976931348623157e308, maxi = -1.7976931348623157e308, cur = 0;
+    const double left_penalty = d.left_clipping > 0 ? 0 : sc.clipping;
+    const double right_penalty = d.right_clipping > 0 ? 0 : sc.clipping;
+    uint32_t in = d.left_clipping;
+    bool in_indel = false;
+    int pos;
+    for (pos = 0; in < cigar_stride && ec[in] && ec[in] != '$'; ++pos) {   // 849-890
+        const uint32_t c = ec[in];
+        if (c == '.') {
+            cur += sc.match;
+            in_indel = false;
+            ++in;
+        } else if (c == '#') {
+            cur += in_indel ? sc.gap_ins_extend : sc.gap_ins_open;
+            in_indel = true;
+            in += 2;
+            ++pos;
+        } else if (c == '^') {
+            cur += in_indel ? sc.gap_del_extend : sc.gap_del_open;
+            in_indel = true;
+            in += 2;
+            ++pos;
+        } else if (is_alpha(c)) {
+            cur += sc.mismatch;
+            in_indel = false;
+            ++in;
+        } else {
+            ++in;
+        }
+        if (cur < mini) {
+            mini_pos = pos;
+            mini = cur;
+        }
+        if (cur > maxi) {
+            maxi_pos = pos;
+            maxi = cur;
+        }
+    }
+    if (mini_pos + 20 > maxi_pos) {
+        d.cigar_len = length();
+        records[gid] = d;
+        return;
+    }
+    int no_clippings = 0;
+    if (maxi + right_penalty > cur) {   // right clipping, 898-941
+        ++no_clippings;
+        in = d.left_clipping + (uint32_t)maxi_pos + 1;
+        uint32_t out = in;
+        while (ec[in] && ec[in] != '$') {
+            const uint32_t c = ec[in];
+            if (c == '.') {
+                ec[out++] = '$';
+                ++in;
+                ++d.right_clipping;
+                --d.ref_length;
+            } else if (c == '#') {
+                ec[out++] = '$';
+                in += 2;
+                ++d.right_clipping;
+                --d.err_edit_distance;
+            } else if (c == '^') {
+                in += 2;
+                --d.ref_length;
+                --d.err_edit_distance;
+            } else if (is_alpha(c)) {
+                ec[out++] = '$';
+                ++in;
+                ++d.right_clipping;
+                --d.ref_length;
+                --d.err_edit_distance;
+            } else {
+                ++in;
+            }
+        }
+        while (ec[in])
+            ec[out++] = ec[in++];
+        ec[out] = 0;
+    }
+    if (mini < left_penalty) {   // left clipping, 944-991
+        ++no_clippings;
+        in = d.left_clipping;
+        uint32_t out = in;
+        const uint32_t guard = in + (uint32_t)mini_pos + 1;
+        while (in != guard) {
+            const uint32_t c = ec[in];
+            if (c == '.') {
+                ec[out++] = '$';
+                ++in;
+                ++d.left_clipping;
+                ++d.ref_seq_pos;
+                --d.ref_length;
+            } else if (c == '#') {
+                ec[out++] = '$';
+                in += 2;
+                ++d.left_clipping;
+                --d.err_edit_distance;
+            } else if (c == '^') {
+                in += 2;
+                ++d.ref_seq_pos;
+                --d.ref_length;
+                --d.err_edit_distance;
+            } else if (is_alpha(c)) {
+                ec[out++] = '$';
+                ++in;
+                ++d.left_clipping;
+                ++d.ref_seq_pos;
+                --d.ref_length;
+                --d.err_edit_distance;
+            } else {
+                ++in;
+            }
+        }
+        while (ec[in])
+            ec[out++] = ec[in++];
+        ec[out] = 0;
+    }
+    // 993
+    d.score = (0.0 > maxi ? 0.0 : maxi) - (0.0 < mini ? 0.0 : mini) + no_clippings * sc.clipping;
+    d.no_clippings = (uint32_t)no_clippings;
+    d.cigar_len = length();
+    records[gid] = d;
+}
+
+__device__ __forceinline__ uint8_t indel_size_encode(int32_t x)   // types.h:296-302
+{
+    return x > 0 ? (uint8_t)x : (uint8_t)(-x + 128);
+}
+
+__global__ __launch_bounds__(256) void serialize_kernel(uint32_t n, const wamd_mapping* __restrict__ mappings,
+                                                        const uint8_t* __restrict__ direction,
+                                                        uint8_t* __restrict__ out, uint8_t* __restrict__ sizes)
+{
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n)
+        return;
+    const wamd_mapping m = mappings[gid];
+    uint8_t b[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t k = 0;
+    b[k++] = (uint8_t)(m.pos >> 24);   // StoreUInt big-endian, common/utils.cpp:431-445
+    b[k++] = (uint8_t)(m.pos >> 16);
+    b[k++] = (uint8_t)(m.pos >> 8);
+    b[k++] = (uint8_t)m.pos;
+    b[k++] = (uint8_t)((direction[gid] ? 0x80u : 0) + (m.type == WAMD_MAP_LEV ? 0x40u : 0) + (m.no_mismatches & 0x3f));
+    if (m.type != WAMD_MAP_LEV) {
+        b[k++] = (uint8_t)m.type;
+        const uint8_t hi1 = (uint8_t)((m.matching_len1 >> 8) & 0xf);
+        switch (m.type) {
+        case WAMD_MAP_INDEL1:
+            b[k++] = hi1;
+            b[k++] = (uint8_t)(m.matching_len1 & 0xff);
+            b[k++] = indel_size_encode(m.indel_len1);
+            break;
+        case WAMD_MAP_INDEL2:
+            b[k++] = (uint8_t)(hi1 + ((m.matching_len2 >> 4) & 0xf0u));
+            b[k++] = (uint8_t)(m.matching_len1 & 0xffu);
+            b[k++] = (uint8_t)(m.matching_len2 & 0xffu);
+            b[k++] = indel_size_encode(m.indel_len1);
+            b[k++] = indel_size_encode(m.indel_len2);
+            break;
+        case WAMD_MAP_INDEL_CLIPPING:
+        case WAMD_MAP_CLIPPING_INDEL:
+            b[k++] = (uint8_t)(hi1 + ((m.clipping_len >> 4) & 0xf0u));
+            b[k++] = (uint8_t)(m.matching_len1 & 0xffu);
+            b[k++] = (uint8_t)(m.clipping_len & 0xffu);
+            b[k++] = indel_size_encode(m.indel_len1);
+            break;
+        case WAMD_MAP_MISMATCHES_CLIPPING:
+        case WAMD_MAP_CLIPPING_MISMATCHES:
+            b[k++] = hi1;
+            b[k++] = (uint8_t)(m.matching_len1 & 0xffu);
+            break;
+        case WAMD_MAP_CLIPPING_CLIPPING:
+            b[k++] = (uint8_t)(hi1 + ((m.clipping_len >> 4) & 0xf0u));
+            b[k++] = (uint8_t)(m.matching_len1 & 0xffu);
+            b[k++] = (uint8_t)(m.clipping_len & 0xffu);
+            break;
+        default:
+            break;
+        }
+    }
+    uint32_t* o = reinterpret_cast<uint32_t*>(out + (uint64_t)gid * 12);
+    o[0] = b[0] | (b[1] << 8) | (b[2] << 16) | ((uint32_t)b[3] << 24);
+    o[1] = b[4] | (b[5] << 8) | (b[6] << 16) | ((uint32_t)b[7] << 24);
+    o[2] = b[8] | (b[9] << 8) | (b[10] << 16) | ((uint32_t)b[11] << 24);
+    sizes[gid] = (uint8_t)k;
+}
+
+int launch_indel_ext_cigar(wamd_ctx* ctx, const wamd_reads* r, const wamd_indel_cigar_task* d_tasks,
+                           uint32_t n, wamd_indel_cigar_result* d_results, uint8_t* d_cigars,
+                           uint32_t cigar_stride, hipStream_t s)
+{
+    WAMD_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(indel_ext_cigar_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ctx->d_genome,
+                       2 * ctx->genome_bytes, r->view(), d_tasks, n, ctx->scoring, d_results, d_cigars,
+                       cigar_stride, ctx->d_flags);
+    WAMD_HIP(hipGetLastError());
+    return WAMD_OK;
+}
+
+int launch_clip_boundary(wamd_ctx* ctx, uint32_t n, wamd_clip_record* d_records, uint8_t* d_cigars,
+                         uint32_t cigar_stride, hipStream_t s)
+{
+    WAMD_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(clip_boundary_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_records, d_cigars,
+                       cigar_stride, ctx->scoring);
+    WAMD_HIP(hipGetLastError());
+    return WAMD_OK;
+}
+
+int launch_serialize(wamd_ctx* ctx, uint32_t n, const wamd_mapping* d_mappings, const uint8_t* d_direction,
+                     uint8_t* d_out, uint8_t* d_sizes, hipStream_t s)
+{
+    WAMD_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(serialize_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_mappings, d_direction,
+                       d_out, d_sizes);
+    WAMD_HIP(hipGetLastError());
+    return WAMD_OK;
+}
+
+} // namespace wamd

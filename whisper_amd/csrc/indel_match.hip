@@ -1,0 +1,460 @@
+// indel_match.hip - one long indel / clipping around an exact anchor, one candidate per lane.
+//
+// Replaces CIndelMatching::Match (mapper/indels.cpp:125-461), called for every SA
+// candidate of the sensitive stages (mapper/mapping_core_sa.cpp:264/317).  It is not a
+// DP: raw mismatch counts and the best clipping point on either side of the anchor, then
+// 7-mer seeded candidates for a single long indel per side (one-hot popcount signature,
+// at most one error), each scored by the best split of prefix / suffix mismatch counts,
+// and finally eight combinations tried in a fixed order with strict `>` on double costs.
+//
+// MI355X mapping: one wave per 64 candidates, both sequences of a lane unpacked once into
+// LDS, two symbols per byte ([byte][lane]: a wave reading the same index touches 16
+// dwords, no bank conflicts), everything else lane-private registers.  The split search
+// keeps running prefix / suffix counts instead of the reference's two arrays.  Costs are
+// evaluated with the reference's expressions in the reference's order (-ffp-contract=off),
+// so accepted mappings and their tie-breaks are identical.
+#include "wamd_internal.h"
+
+namespace wamd {
+
+constexpr int IM_SIDE = 7;          // min_side_size, indels.h:210
+constexpr int IM_SIDE_ERRORS = 1;   // max_no_side_errors
+constexpr uint32_t IM_MAX_READ = 256;   // longest read the LDS-staged variant takes
+constexpr uint32_t IM_MAX_INDEL = 80;   // largest max_indel_size it takes
+
+struct IndelKernelParams {
+    wamd_scoring sc;
+    double min_clipped_factor;
+};
+
+// rev_comp_code of CIndelMatching (indels.cpp:40-49): 8..15 -> 15
+__device__ __forceinline__ uint32_t rc_code_indel(uint32_t c) { return c < 4 ? 3 - c : (c < 8 ? c : 15); }
+
+template <bool STAGED>
+struct Seqs {
+    // STAGED: bytes in LDS; otherwise straight from packed global memory
+    const uint8_t* lds_g;
+    const uint8_t* lds_q;
+    const uint8_t* genome;
+    const uint8_t* codes;
+    uint64_t g0;
+    uint32_t m;
+    bool rev;
+    // LDS image: two symbols per byte, first in the high nibble, [byte][lane]
+    __device__ __forceinline__ uint32_t G(uint32_t i) const
+    {
+        if constexpr (STAGED)
+            return (lds_g[(i >> 1) * 64] >> ((i & 1u) ? 0 : 4)) & 15u;
+        else
+            return packed_symbol(genome, g0 + i);
+    }
+    __device__ __forceinline__ uint32_t Q(uint32_t i) const
+    {
+        if constexpr (STAGED)
+            return (lds_q[(i >> 1) * 64] >> ((i & 1u) ? 0 : 4)) & 15u;
+        else
+            return rev ? rc_code_indel(packed_symbol(codes, m - 1 - i)) : packed_symbol(codes, i);
+    }
+};
+
+// calc_mismatches_with_indel, indels.cpp:495-563, without the two arrays
+template <bool STAGED>
+__device__ void split_mismatches(const Seqs<STAGED>& s, uint32_t query_len, uint32_t g_left, uint32_t g_right,
+                                 uint32_t q_left, uint32_t q_right, bool left_margin, uint32_t& no_mis,
+                                 uint32_t& indel_pos)
+{
+    const uint32_t text_size = g_right - g_left, query_size = q_right - q_left;
+    const uint32_t stats = text_size < query_size ? text_size : query_size;
+    if (stats <= (uint32_t)IM_SIDE) {
+        no_mis = query_len + 1;
+        indel_pos = 0;
+        return;
+    }
+    const uint32_t start = left_margin ? IM_SIDE : 0;
+    const uint32_t end = stats - (left_margin ? 0 : IM_SIDE);
+    const uint32_t g_r = g_left + text_size - stats, q_r = q_left + query_size - stats;
+    uint32_t R = 0;
+    for (uint32_t t = 0; t < stats; ++t)
+        R += s.G(g_r + t) != s.Q(q_r + t);
+    uint32_t L = 0;
+    int best = (int)query_len + 1, best_pos = 0;
+    for (uint32_t i = 0; i < end; ++i) {
+        if (i >= start && (int)(L + R) < best) {
+            best = (int)(L + R);
+            best_pos = (int)i;
+        }
+        L += s.G(g_left + i) != s.Q(q_left + i);
+        R -= s.G(g_r + i) != s.Q(q_r + i);
+    }
+    no_mis = (uint32_t)best;
+    indel_pos = q_left + (uint32_t)best_pos;
+}
+
+template <bool STAGED>
+__global__ __launch_bounds__(64) void indel_match_kernel(const uint8_t* __restrict__ genome,
+                                                         uint64_t genome_symbols, ReadsView rv, int ascii,
+                                                         const wamd_indel_task* __restrict__ tasks, uint32_t n,
+                                                         IndelKernelParams prm, uint32_t text_bytes,
+                                                         wamd_mapping* __restrict__ results,
+                                                         uint32_t* __restrict__ flags)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // (text_bytes + read bytes) x 64
+    const uint32_t lane = threadIdx.x;
+    const uint32_t gid = blockIdx.x * 64 + lane;
+    if (gid >= n)
+        return;
+    const wamd_indel_task t = tasks[gid];
+
+    wamd_mapping cm;   // a default-constructed candidate_mapping_t, types.h:250-261
+    cm.found = 0;
+    cm.type = WAMD_MAP_NONE;
+    cm.pos = 0;
+    cm.no_mismatches = (uint32_t)t.max_no_mismatches + 1;
+    cm.matching_len1 = cm.matching_len2 = 0;
+    cm.indel_len1 = cm.indel_len2 = 0;
+    cm.clipping_len = 0;
+    cm.penalty = 0;
+
+    uint32_t err = 0;
+    uint32_t query_len = 0;
+    if (t.read_idx >= rv.n)
+        err = FLAG_READ_IDX;
+    else
+        query_len = rv.lens[t.read_idx];
+    const uint32_t max_indel = t.max_indel_size, fpos = t.fixed_segment_pos, fsize = t.fixed_segment_size;
+    const uint32_t max_mis = t.max_no_mismatches, ref_pos = t.ref_pos;
+    const uint32_t text_size = query_len + 2 * max_indel;
+    if (!err && (fpos + fsize > query_len ||
+                 (STAGED && (query_len > IM_MAX_READ || max_indel > IM_MAX_INDEL || (text_size + 3) / 2 > text_bytes))))
+        err = FLAG_ARG;
+    if (!err && (ref_pos < max_indel || (uint64_t)ref_pos - max_indel + text_size + 3 > genome_symbols))
+        err = FLAG_RANGE;
+    if (err) {
+        raise_flag(flags, err);
+        cm.type = RESULT_ERROR;
+        results[gid] = cm;
+        return;
+    }
+
+    Seqs<STAGED> s;
+    s.genome = genome;
+    s.codes = rv.codes + rv.code_off[t.read_idx];
+    s.g0 = (uint64_t)ref_pos - max_indel;   // prefetch_genome(ref_pos - max_indel_size, text_size)
+    s.m = query_len;
+    s.rev = t.flags & WAMD_TASK_FLAG_REV_COMP;
+    s.lds_g = lds + lane;
+    s.lds_q = lds + (STAGED ? text_bytes * 64 : 0) + lane;
+    if constexpr (STAGED) {
+        uint8_t* lg = lds + lane;
+        uint8_t* lq = lds + text_bytes * 64 + lane;
+        for (uint32_t i = 0; i < text_size + 2; i += 2)
+            lg[(i >> 1) * 64] = (uint8_t)((packed_symbol(genome, s.g0 + i) << 4) | packed_symbol(genome, s.g0 + i + 1));
+        for (uint32_t i = 0; i < query_len; i += 2) {
+            const uint32_t a = s.rev ? rc_code_indel(packed_symbol(s.codes, query_len - 1 - i)) : packed_symbol(s.codes, i);
+            const uint32_t b = i + 1 < query_len
+                                   ? (s.rev ? rc_code_indel(packed_symbol(s.codes, query_len - 2 - i)) : packed_symbol(s.codes, i + 1))
+                                   : 15u;
+            lq[(i >> 1) * 64] = (uint8_t)((a << 4) | b);
+        }
+    }
+    (void)ascii;   // ASCII reads were canonicalised with raw_code at upload (indels.cpp:977-991)
+
+    const double match_score = prm.sc.match, mismatch_score = prm.sc.mismatch;
+    const double gap_del_open = prm.sc.gap_del_open, gap_del_extend = prm.sc.gap_del_extend;
+    const double gap_ins_open = prm.sc.gap_ins_open, gap_ins_extend = prm.sc.gap_ins_extend;
+    const double clipping_score = prm.sc.clipping;
+
+    // anchor, indels.cpp:167-169
+    bool anchor_ok = true;
+    for (uint32_t i = 0; i < fsize; ++i)
+        if (s.Q(fpos + i) != s.G(max_indel + fpos + i)) {
+            anchor_ok = false;
+            break;
+        }
+    if (!anchor_ok) {
+        results[gid] = cm;
+        return;
+    }
+
+    double total_cost = 0;
+    const int min_size_after_clipping = (int)(query_len * prm.min_clipped_factor);
+    int left_indel_size = 0, right_indel_size = 0;
+    uint32_t no_left_mis_indel = query_len, no_right_mis_indel = query_len;
+    double best_left_cost = 0, best_right_cost = 0;
+    uint32_t best_left_indel_pos = 0, best_right_indel_pos = 0;
+    bool left_indel_found = false, right_indel_found = false;
+    double best_left_clip_cost = 0, best_right_clip_cost = 0;
+    uint32_t best_no_left_clipped = 0, best_no_right_clipped = 0;
+    uint32_t no_left_mis_clipped = 0, no_right_mis_clipped = 0;
+    uint32_t best_no_left_mis_clipped = 0, best_no_right_mis_clipped = 0;
+    const uint64_t sig_mask = ~0ull >> (4 * (16 - IM_SIDE));
+
+    // ---- left part: raw mismatches and best clipping point, 173-194
+    uint32_t no_left_mis_raw = 0;
+    double clipping_cost = clipping_score;
+    for (int i = (int)fpos - 1; i >= 0; --i) {
+        if (s.Q(i) != s.G(max_indel + i)) {
+            ++no_left_mis_raw;
+            ++no_left_mis_clipped;
+            clipping_cost += mismatch_score;
+        } else {
+            clipping_cost += match_score;
+            if (clipping_cost > best_left_clip_cost) {
+                best_left_clip_cost = clipping_cost;
+                best_no_left_clipped = (uint32_t)i;
+                best_no_left_mis_clipped = no_left_mis_clipped;
+            }
+        }
+    }
+    if (fpos > (uint32_t)IM_SIDE) {   // 198-231
+        // CBitCharsSingleWord (indels.h:162-206): newest symbol in the lowest 4-bit cell;
+        // a symbol >= 4 is not inserted at all (the window does not advance)
+        uint64_t qsig = 0;
+        for (int i = 0; i < IM_SIDE; ++i) {
+            const uint32_t c = s.Q(i);
+            if (c < 4)
+                qsig += 1ull << (c + 4 * (IM_SIDE - i - 1));
+        }
+        uint64_t d = 0;
+        for (int i = 0; i < IM_SIDE - 1; ++i) {
+            const uint32_t c = s.G(i);
+            if (c < 4)
+                d += 1ull << (c + 4 * (IM_SIDE - i - 2));
+        }
+        const uint32_t end = max_indel + fpos;
+        for (uint32_t i = IM_SIDE - 1; i < end; ++i) {
+            const uint32_t c = s.G(i);
+            if (c < 4)
+                d = ((d << 4) + (1ull << c)) & sig_mask;
+            if (__popcll(d & qsig) < IM_SIDE - IM_SIDE_ERRORS)
+                continue;
+            const uint32_t g_left = i - IM_SIDE + 1;
+            uint32_t c_mis, indel_pos;
+            split_mismatches(s, query_len, g_left, max_indel + fpos + 1, 0, fpos + 1, true, c_mis, indel_pos);
+            if (c_mis > max_mis)
+                continue;
+            const int c_indel = (int)max_indel - (int)g_left;
+            if ((c_indel < 0 ? -c_indel : c_indel) > (int)max_indel)
+                continue;
+            double cost = (fpos - c_mis) * match_score + c_mis * mismatch_score;
+            if (c_indel > 0)
+                cost += gap_del_open + (c_indel - 1) * gap_del_extend;
+            else if (c_indel < 0)
+                cost += gap_ins_open + (-c_indel - 1) * gap_ins_extend;
+            if (cost > best_left_cost) {
+                best_left_cost = cost;
+                no_left_mis_indel = c_mis;
+                best_left_indel_pos = indel_pos;
+                left_indel_size = c_indel;
+                left_indel_found = c_indel != 0;
+            }
+        }
+    }
+
+    // ---- right part, 235-293
+    uint32_t no_right_mis_raw = 0;
+    clipping_cost = clipping_score;
+    for (uint32_t i = fpos + fsize; i < query_len; ++i) {
+        if (s.Q(i) != s.G(max_indel + i)) {
+            ++no_right_mis_raw;
+            ++no_right_mis_clipped;
+            clipping_cost += mismatch_score;
+        } else {
+            clipping_cost += match_score;
+            if (clipping_cost > best_right_clip_cost) {
+                best_right_clip_cost = clipping_cost;
+                best_no_right_mis_clipped = no_right_mis_clipped;
+                best_no_right_clipped = query_len - i - 1;
+            }
+        }
+    }
+    if (fpos + fsize + IM_SIDE < query_len) {
+        uint64_t qsig = 0;
+        for (int i = 0; i < IM_SIDE; ++i) {
+            const uint32_t c = s.Q(query_len - IM_SIDE + i);
+            if (c < 4)
+                qsig += 1ull << (c + 4 * (IM_SIDE - i - 1));
+        }
+        const uint32_t begin = max_indel + fpos + fsize;
+        uint64_t d = 0;
+        for (int i = 0; i < IM_SIDE - 1; ++i) {
+            const uint32_t c = s.G(begin + i);
+            if (c < 4)
+                d += 1ull << (c + 4 * (IM_SIDE - i - 2));
+        }
+        for (uint32_t i = begin + IM_SIDE - 1; i < text_size; ++i) {
+            const uint32_t c = s.G(i);
+            if (c < 4)
+                d = ((d << 4) + (1ull << c)) & sig_mask;
+            if (__popcll(d & qsig) < IM_SIDE - IM_SIDE_ERRORS)
+                continue;
+            const uint32_t right_pos = i - IM_SIDE + 1;
+            uint32_t c_mis, indel_pos;
+            split_mismatches(s, query_len, fpos + fsize - 1 + max_indel, right_pos + IM_SIDE, fpos + fsize - 1,
+                             query_len, false, c_mis, indel_pos);
+            if (c_mis > max_mis)
+                continue;
+            const int c_indel = ((int)right_pos + IM_SIDE) - ((int)text_size - (int)max_indel);
+            if ((c_indel < 0 ? -c_indel : c_indel) > (int)max_indel)
+                continue;
+            double cost = (query_len - fpos - fsize - c_mis) * match_score + c_mis * mismatch_score;
+            if (c_indel > 0)
+                cost += gap_del_open + (c_indel - 1) * gap_del_extend;
+            else if (c_indel < 0)
+                cost += gap_ins_open + (-c_indel - 1) * gap_ins_extend;
+            if (cost > best_right_cost) {
+                best_right_cost = cost;
+                no_right_mis_indel = c_mis;
+                best_right_indel_pos = indel_pos;
+                right_indel_size = c_indel;
+                right_indel_found = c_indel != 0;
+            }
+        }
+    }
+
+    auto rescale = [&](uint32_t size) { return size * max_mis / query_len; };   // indels.h:252-255
+    const uint32_t left_pos =
+        left_indel_size > 0 ? ref_pos - (uint32_t)left_indel_size : ref_pos + (uint32_t)(-left_indel_size);
+
+    // ---- the eight combinations in the reference's order, 297-457
+    if (left_indel_found && no_left_mis_indel + no_right_mis_raw < max_mis) {
+        const double c = best_left_cost + (query_len - fpos - no_right_mis_raw) * match_score +
+                         no_right_mis_raw * mismatch_score;
+        if (c > total_cost) {
+            total_cost = c;
+            cm.pos = left_pos;
+            cm.type = WAMD_MAP_INDEL1;
+            cm.matching_len1 = best_left_indel_pos;
+            cm.indel_len1 = left_indel_size;
+            cm.no_mismatches = no_left_mis_indel + no_right_mis_raw;
+        }
+    }
+    if (right_indel_found && no_left_mis_raw + no_right_mis_indel < max_mis) {
+        const double c = best_right_cost + (fpos + fsize - no_left_mis_raw) * match_score +
+                         no_left_mis_raw * mismatch_score;
+        if (c > total_cost) {
+            total_cost = c;
+            cm.pos = ref_pos;
+            cm.type = WAMD_MAP_INDEL1;
+            cm.matching_len1 = best_right_indel_pos;
+            cm.indel_len1 = right_indel_size;
+            cm.no_mismatches = no_left_mis_raw + no_right_mis_indel;
+        }
+    }
+    if (left_indel_found && right_indel_found && no_left_mis_indel + no_right_mis_indel < max_mis) {
+        const double c = best_left_cost + best_right_cost + fsize * match_score;
+        if (c > total_cost) {
+            total_cost = c;
+            cm.type = WAMD_MAP_INDEL2;
+            cm.pos = left_pos;
+            cm.matching_len1 = best_left_indel_pos;
+            cm.indel_len1 = left_indel_size;
+            cm.matching_len2 = left_indel_size > 0
+                                   ? best_right_indel_pos - best_left_indel_pos
+                                   : best_right_indel_pos - (best_left_indel_pos + (uint32_t)(-left_indel_size));
+            cm.indel_len2 = right_indel_size;
+            cm.no_mismatches = no_left_mis_indel + no_right_mis_indel;
+        }
+    }
+    if (best_no_left_clipped > 0 &&
+        best_no_left_mis_clipped + no_right_mis_raw < rescale(query_len - best_no_left_clipped)) {
+        const double c = best_left_clip_cost + (query_len - fpos - no_right_mis_raw) * match_score +
+                         no_right_mis_raw * mismatch_score;
+        if (c > total_cost && query_len - best_no_left_clipped >= (uint32_t)min_size_after_clipping) {
+            total_cost = c;
+            cm.pos = ref_pos + best_no_left_clipped;
+            cm.type = WAMD_MAP_CLIPPING_MISMATCHES;
+            cm.clipping_len = best_no_left_clipped;
+            cm.matching_len1 = query_len - best_no_left_clipped;
+            cm.no_mismatches = best_no_left_mis_clipped + no_right_mis_raw;
+        }
+    }
+    if (best_no_right_clipped > 0 &&
+        no_left_mis_raw + best_no_right_mis_clipped < rescale(query_len - best_no_right_clipped)) {
+        const double c = best_right_clip_cost + (fpos + fsize - no_left_mis_raw) * match_score +
+                         no_left_mis_raw * mismatch_score;
+        if (c > total_cost && query_len - best_no_right_clipped >= (uint32_t)min_size_after_clipping) {
+            total_cost = c;
+            cm.pos = ref_pos;
+            cm.type = WAMD_MAP_MISMATCHES_CLIPPING;
+            cm.clipping_len = best_no_right_clipped;
+            cm.matching_len1 = query_len - best_no_right_clipped;
+            cm.no_mismatches = no_left_mis_raw + best_no_right_mis_clipped;
+        }
+    }
+    if (best_no_left_clipped > 0 && right_indel_found &&
+        best_no_left_mis_clipped + no_right_mis_indel < rescale(query_len - best_no_left_clipped)) {
+        const double c = best_left_clip_cost + best_right_cost + fsize * match_score;
+        if (c > total_cost && query_len - best_no_left_clipped >= (uint32_t)min_size_after_clipping) {
+            total_cost = c;
+            cm.pos = ref_pos + best_no_left_clipped;
+            cm.type = WAMD_MAP_CLIPPING_INDEL;
+            cm.indel_len1 = right_indel_size;
+            cm.clipping_len = best_no_left_clipped;
+            cm.matching_len1 = best_right_indel_pos - best_no_left_clipped;
+            cm.no_mismatches = best_no_left_mis_clipped + no_right_mis_indel;
+        }
+    }
+    if (best_no_right_clipped > 0 && left_indel_found &&
+        best_no_right_mis_clipped + no_left_mis_indel < rescale(query_len - best_no_right_clipped)) {
+        const double c = best_right_clip_cost + best_left_cost + fsize * match_score;
+        if (c > total_cost && query_len - best_no_right_clipped >= (uint32_t)min_size_after_clipping) {
+            total_cost = c;
+            cm.pos = left_pos;
+            cm.type = WAMD_MAP_INDEL_CLIPPING;
+            cm.indel_len1 = left_indel_size;
+            cm.clipping_len = best_no_right_clipped;
+            cm.matching_len1 = best_left_indel_pos;
+            cm.no_mismatches = best_no_right_mis_clipped + no_left_mis_indel;
+        }
+    }
+    if (best_no_left_clipped > 0 && best_no_right_clipped > 0 &&
+        best_no_left_mis_clipped + best_no_right_mis_clipped <
+            rescale(query_len - best_no_left_clipped - best_no_right_clipped)) {
+        const double c = best_left_clip_cost + best_right_clip_cost + fsize * match_score;
+        if (c > total_cost &&
+            query_len - best_no_left_clipped - best_no_right_clipped >= (uint32_t)min_size_after_clipping) {
+            total_cost = c;
+            cm.pos = ref_pos + best_no_left_clipped;
+            cm.type = WAMD_MAP_CLIPPING_CLIPPING;
+            cm.clipping_len = best_no_left_clipped;
+            cm.matching_len1 = query_len - best_no_left_clipped - best_no_right_clipped;
+            cm.no_mismatches = best_no_left_mis_clipped + best_no_right_mis_clipped;
+        }
+    }
+    if (cm.type != WAMD_MAP_NONE) {
+        cm.found = 1;
+        // calc_penalty, results.cpp:327-343 with types.h:242-247
+        const uint32_t add = (cm.type == WAMD_MAP_INDEL1 || cm.type == WAMD_MAP_CLIPPING_MISMATCHES ||
+                              cm.type == WAMD_MAP_MISMATCHES_CLIPPING) ? 1u : 2u;
+        cm.penalty = cm.no_mismatches + add;
+    }
+    results[gid] = cm;
+}
+
+int launch_indel_match(wamd_ctx* ctx, const wamd_reads* r, const wamd_indel_task* d_tasks, uint32_t n,
+                       const wamd_indel_params* prm, wamd_mapping* d_results, hipStream_t s)
+{
+    WAMD_HIP(hipSetDevice(ctx->device));
+    IndelKernelParams kp;
+    kp.sc = prm->scoring;
+    kp.min_clipped_factor = prm->min_clipped_factor;
+    const uint32_t blocks = (n + 63) / 64;
+    const ReadsView rv = r->view();
+    const int ascii = r->encoding == WAMD_READS_ASCII;
+    // staged variant: reads up to 256 symbols with max_indel up to 80; tasks beyond that are
+    // flagged by the kernel, so pick the unstaged one when the batch has longer reads
+    if (r->max_len <= IM_MAX_READ) {
+        const uint32_t text_bytes = (r->max_len + 2 * IM_MAX_INDEL + 3) / 2;
+        const uint32_t lds_bytes = (text_bytes + (r->max_len + 1) / 2) * 64;
+        hipLaunchKernelGGL(indel_match_kernel<true>, dim3(blocks), dim3(64), lds_bytes, s, ctx->d_genome,
+                           2 * ctx->genome_bytes, rv, ascii, d_tasks, n, kp, text_bytes, d_results, ctx->d_flags);
+    } else {
+        hipLaunchKernelGGL(indel_match_kernel<false>, dim3(blocks), dim3(64), 0, s, ctx->d_genome,
+                           2 * ctx->genome_bytes, rv, ascii, d_tasks, n, kp, 0u, d_results, ctx->d_flags);
+    }
+    WAMD_HIP(hipGetLastError());
+    return WAMD_OK;
+}
+
+} // namespace wamd

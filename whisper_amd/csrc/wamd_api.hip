@@ -532,4 +532,170 @@ int wamd_align(wamd_ctx* ctx, const wamd_reads* reads, const wamd_dist_task* tas
     return rc ? rc : flags_to_status(flags);
 }
 
+// ---- long-indel matcher, its ext-CIGAR, boundary clipping, wire records ---------------
+
+static hipStream_t pick(wamd_ctx* ctx, void* stream) { return stream ? (hipStream_t)stream : ctx->stream; }
+
+int wamd_indel_match_dev(wamd_ctx* ctx, const wamd_reads* reads, const wamd_indel_task* d_tasks, uint32_t n,
+                         const wamd_indel_params* params, wamd_mapping* d_results, void* stream)
+{
+    if (n == 0)
+        return WAMD_OK;
+    int rc = check_batch(ctx, reads, d_tasks, d_results, "wamd_indel_match_dev");
+    if (rc)
+        return rc;
+    if (!params)
+        return WAMD_ERR_INVALID_ARG;
+    return launch_indel_match(ctx, reads, d_tasks, n, params, d_results, pick(ctx, stream));
+}
+
+int wamd_indel_match(wamd_ctx* ctx, const wamd_reads* reads, const wamd_indel_task* tasks, uint32_t n,
+                     const wamd_indel_params* params, wamd_mapping* results)
+{
+    if (n == 0)
+        return WAMD_OK;
+    int rc = check_batch(ctx, reads, tasks, results, "wamd_indel_match");
+    if (rc)
+        return rc;
+    WAMD_HIP(hipSetDevice(ctx->device));
+    const uint64_t tb = (uint64_t)n * sizeof(wamd_indel_task), rb = (uint64_t)n * sizeof(wamd_mapping);
+    rc = ensure_stage(ctx, tb + rb + 256, 0);
+    if (rc)
+        return rc;
+    auto* d_tasks = (wamd_indel_task*)ctx->d_stage;
+    auto* d_res = (wamd_mapping*)((char*)ctx->d_stage + (tb + 255) / 256 * 256);
+    hipStream_t s = ctx->stream;
+    WAMD_HIP(hipMemcpyAsync(d_tasks, tasks, tb, hipMemcpyHostToDevice, s));
+    rc = wamd_indel_match_dev(ctx, reads, d_tasks, n, params, d_res, s);
+    if (rc)
+        return rc;
+    WAMD_HIP(hipMemcpyAsync(results, d_res, rb, hipMemcpyDeviceToHost, s));
+    uint32_t flags = 0;
+    rc = fetch_flags(ctx, s, &flags);
+    return rc ? rc : flags_to_status(flags);
+}
+
+int wamd_indel_ext_cigar_dev(wamd_ctx* ctx, const wamd_reads* reads, const wamd_indel_cigar_task* d_tasks,
+                             uint32_t n, wamd_indel_cigar_result* d_results, uint8_t* d_cigars,
+                             uint32_t cigar_stride, void* stream)
+{
+    if (n == 0)
+        return WAMD_OK;
+    int rc = check_batch(ctx, reads, d_tasks, d_results, "wamd_indel_ext_cigar_dev");
+    if (rc)
+        return rc;
+    if (!d_cigars || (cigar_stride & 3u) || ((uintptr_t)d_cigars & 3u) || cigar_stride < 16)
+        return WAMD_ERR_INVALID_ARG;
+    return launch_indel_ext_cigar(ctx, reads, d_tasks, n, d_results, d_cigars, cigar_stride, pick(ctx, stream));
+}
+
+int wamd_indel_ext_cigar(wamd_ctx* ctx, const wamd_reads* reads, const wamd_indel_cigar_task* tasks, uint32_t n,
+                         wamd_indel_cigar_result* results, uint8_t* cigars, uint32_t cigar_stride)
+{
+    if (n == 0)
+        return WAMD_OK;
+    int rc = check_batch(ctx, reads, tasks, results, "wamd_indel_ext_cigar");
+    if (rc)
+        return rc;
+    if (!cigars)
+        return WAMD_ERR_INVALID_ARG;
+    WAMD_HIP(hipSetDevice(ctx->device));
+    auto up = [](uint64_t x) { return (x + 255) / 256 * 256; };
+    const uint64_t tb = (uint64_t)n * sizeof(wamd_indel_cigar_task), rb = (uint64_t)n * sizeof(wamd_indel_cigar_result);
+    const uint64_t cb = (uint64_t)n * cigar_stride;
+    rc = ensure_stage(ctx, up(tb) + up(rb) + up(cb), 0);
+    if (rc)
+        return rc;
+    char* base = (char*)ctx->d_stage;
+    auto* d_tasks = (wamd_indel_cigar_task*)base;
+    auto* d_res = (wamd_indel_cigar_result*)(base + up(tb));
+    auto* d_cig = (uint8_t*)(base + up(tb) + up(rb));
+    hipStream_t s = ctx->stream;
+    WAMD_HIP(hipMemcpyAsync(d_tasks, tasks, tb, hipMemcpyHostToDevice, s));
+    rc = wamd_indel_ext_cigar_dev(ctx, reads, d_tasks, n, d_res, d_cig, cigar_stride, s);
+    if (rc)
+        return rc;
+    WAMD_HIP(hipMemcpyAsync(results, d_res, rb, hipMemcpyDeviceToHost, s));
+    WAMD_HIP(hipMemcpyAsync(cigars, d_cig, cb, hipMemcpyDeviceToHost, s));
+    uint32_t flags = 0;
+    rc = fetch_flags(ctx, s, &flags);
+    return rc ? rc : flags_to_status(flags);
+}
+
+int wamd_clip_boundary_dev(wamd_ctx* ctx, uint32_t n, wamd_clip_record* d_records, uint8_t* d_cigars,
+                           uint32_t cigar_stride, void* stream)
+{
+    if (n == 0)
+        return WAMD_OK;
+    if (!ctx || !d_records || !d_cigars || cigar_stride == 0)
+        return WAMD_ERR_INVALID_ARG;
+    return launch_clip_boundary(ctx, n, d_records, d_cigars, cigar_stride, pick(ctx, stream));
+}
+
+int wamd_clip_boundary(wamd_ctx* ctx, uint32_t n, wamd_clip_record* records, uint8_t* cigars, uint32_t cigar_stride)
+{
+    if (n == 0)
+        return WAMD_OK;
+    if (!ctx || !records || !cigars || cigar_stride == 0)
+        return WAMD_ERR_INVALID_ARG;
+    WAMD_HIP(hipSetDevice(ctx->device));
+    auto up = [](uint64_t x) { return (x + 255) / 256 * 256; };
+    const uint64_t rb = (uint64_t)n * sizeof(wamd_clip_record), cb = (uint64_t)n * cigar_stride;
+    int rc = ensure_stage(ctx, up(rb) + up(cb), 0);
+    if (rc)
+        return rc;
+    auto* d_rec = (wamd_clip_record*)ctx->d_stage;
+    auto* d_cig = (uint8_t*)ctx->d_stage + up(rb);
+    hipStream_t s = ctx->stream;
+    WAMD_HIP(hipMemcpyAsync(d_rec, records, rb, hipMemcpyHostToDevice, s));
+    WAMD_HIP(hipMemcpyAsync(d_cig, cigars, cb, hipMemcpyHostToDevice, s));
+    rc = wamd_clip_boundary_dev(ctx, n, d_rec, d_cig, cigar_stride, s);
+    if (rc)
+        return rc;
+    WAMD_HIP(hipMemcpyAsync(records, d_rec, rb, hipMemcpyDeviceToHost, s));
+    WAMD_HIP(hipMemcpyAsync(cigars, d_cig, cb, hipMemcpyDeviceToHost, s));
+    WAMD_HIP(hipStreamSynchronize(s));
+    return WAMD_OK;
+}
+
+int wamd_serialize_mappings_dev(wamd_ctx* ctx, uint32_t n, const wamd_mapping* d_mappings,
+                                const uint8_t* d_direction, uint8_t* d_out, uint8_t* d_sizes, void* stream)
+{
+    if (n == 0)
+        return WAMD_OK;
+    if (!ctx || !d_mappings || !d_direction || !d_out || !d_sizes || ((uintptr_t)d_out & 3u))
+        return WAMD_ERR_INVALID_ARG;
+    return launch_serialize(ctx, n, d_mappings, d_direction, d_out, d_sizes, pick(ctx, stream));
+}
+
+int wamd_serialize_mappings(wamd_ctx* ctx, uint32_t n, const wamd_mapping* mappings, const uint8_t* direction,
+                            uint8_t* out, uint8_t* sizes)
+{
+    if (n == 0)
+        return WAMD_OK;
+    if (!ctx || !mappings || !direction || !out || !sizes)
+        return WAMD_ERR_INVALID_ARG;
+    WAMD_HIP(hipSetDevice(ctx->device));
+    auto up = [](uint64_t x) { return (x + 255) / 256 * 256; };
+    const uint64_t mb = (uint64_t)n * sizeof(wamd_mapping), ob = (uint64_t)n * 12;
+    int rc = ensure_stage(ctx, up(mb) + up(n) + up(ob) + up(n), 0);
+    if (rc)
+        return rc;
+    char* base = (char*)ctx->d_stage;
+    auto* d_m = (wamd_mapping*)base;
+    auto* d_dir = (uint8_t*)(base + up(mb));
+    auto* d_out = (uint8_t*)(base + up(mb) + up(n));
+    auto* d_sz = (uint8_t*)(base + up(mb) + up(n) + up(ob));
+    hipStream_t s = ctx->stream;
+    WAMD_HIP(hipMemcpyAsync(d_m, mappings, mb, hipMemcpyHostToDevice, s));
+    WAMD_HIP(hipMemcpyAsync(d_dir, direction, n, hipMemcpyHostToDevice, s));
+    rc = wamd_serialize_mappings_dev(ctx, n, d_m, d_dir, d_out, d_sz, s);
+    if (rc)
+        return rc;
+    WAMD_HIP(hipMemcpyAsync(out, d_out, ob, hipMemcpyDeviceToHost, s));
+    WAMD_HIP(hipMemcpyAsync(sizes, d_sz, n, hipMemcpyDeviceToHost, s));
+    WAMD_HIP(hipStreamSynchronize(s));
+    return WAMD_OK;
+}
+
 } // extern "C"

@@ -114,6 +114,15 @@ int launch_align(wamd_ctx* ctx, const wamd_reads* r, const wamd_dist_task* d_tas
                  int last_symbol, int refine, wamd_align_result* d_results, uint8_t* d_cigars,
                  uint32_t cigar_stride, void* d_ws, uint64_t ws_bytes, hipStream_t s);
 uint64_t align_workspace_bytes(const wamd_reads* r, uint32_t n);
+int launch_indel_match(wamd_ctx* ctx, const wamd_reads* r, const wamd_indel_task* d_tasks, uint32_t n,
+                       const wamd_indel_params* prm, wamd_mapping* d_results, hipStream_t s);
+int launch_indel_ext_cigar(wamd_ctx* ctx, const wamd_reads* r, const wamd_indel_cigar_task* d_tasks,
+                           uint32_t n, wamd_indel_cigar_result* d_results, uint8_t* d_cigars,
+                           uint32_t cigar_stride, hipStream_t s);
+int launch_clip_boundary(wamd_ctx* ctx, uint32_t n, wamd_clip_record* d_records, uint8_t* d_cigars,
+                         uint32_t cigar_stride, hipStream_t s);
+int launch_serialize(wamd_ctx* ctx, uint32_t n, const wamd_mapping* d_mappings, const uint8_t* d_direction,
+                     uint8_t* d_out, uint8_t* d_sizes, hipStream_t s);
 
 #ifdef __HIPCC__
 // ---- device helpers -------------------------------------------------------------
