@@ -27,7 +27,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from whisper_amd import api, synth  # noqa: E402
+from whisper_amd import api, gather, synth  # noqa: E402
 
 M, K_ERR = 150, 12
 W = M + 2 * K_ERR
@@ -136,22 +136,21 @@ def main():
     def verify():
         ctx.dynamic_programming_dev(reads, d_tasks, n, d_results, last_symbol=-1)
 
+    # mapping records of the accepted candidates (results.cpp:161-217) -> rank 0: the path's
+    # only exchange step.  Positions / strands are what the host loop would record
+    # (mapping_core_sa.cpp:243, 298); here: the window start + k on the direct strand.
+    d_rec_pos = torch.from_numpy((tasks["ref_pos"] + K_ERR).astype(np.uint32).view(np.int32)).to(device)
+    d_dir = torch.ones(n, dtype=torch.uint8, device=device)
+    d_records = torch.zeros((n, gather.RECORD_BYTES), dtype=torch.uint8, device=device)
+    d_count = torch.zeros(1, dtype=torch.int32, device=device)
+    d_scratch = torch.zeros(ctx.records_scratch_bytes(n), dtype=torch.uint8, device=device)
+
     def gather_records():
-        """Mapping records of the accepted candidates -> rank 0 (results.cpp:161-217:
-        4 B position + 1 B direction/type/errors); the path's only exchange step."""
+        ctx.emit_lev_records_dev(n, d_tasks, d_results, d_rec_pos, d_dir, d_records, d_count, d_scratch)
         with torch.cuda.stream(stream):
-            r = d_results.view(n, 2)
-            ok = r[:, 0] <= K_ERR
-            rec = torch.stack([torch.nonzero(ok).squeeze(1).to(torch.int32), r[ok, 0]], dim=1)
-            cnt = torch.tensor([rec.shape[0]], device=device, dtype=torch.int64)
-            counts = [torch.zeros_like(cnt) for _ in range(world)]
-            dist.all_gather(counts, cnt)
-            mx = int(max(int(c) for c in counts))
-            pad = torch.zeros((mx, 2), dtype=torch.int32, device=device)
-            pad[: rec.shape[0]] = rec
-            out = [torch.zeros_like(pad) for _ in range(world)] if rank == 0 else None
-            dist.gather(pad, out, dst=0)
-        return sum(int(c) for c in counts)
+            cnt = int(d_count.item())
+            out = gather.gather_records(d_records, cnt, dst=0)
+        return out
 
     def step():
         verify()

@@ -348,6 +348,21 @@ WAMD_API int wamd_serialize_mappings_dev(wamd_ctx* ctx, uint32_t n, const wamd_m
                                          const uint8_t* d_direction, uint8_t* d_out,
                                          uint8_t* d_sizes, void* stream);
 
+/* Mapping records of the accepted candidates of a distance batch, in task order: what
+ * the mapping loop pushes to the results collector (mapping_core_sa.cpp:241-243, 293-298,
+ * mapping_core.cpp:980-997) and what is gathered across GPUs.  A candidate is accepted when
+ * edit_distance <= its task's max_ed.  Each record is 12 bytes:
+ *   [0..3] read_idx (little-endian)   [4..8] candidate_mapping_t::serialize of a lev mapping
+ *   (4 B big-endian position, then 0x80 if direct + 0x40 + errors & 0x3f)   [9..11] zero.
+ * record_pos[i] / direction[i]: the position and strand the host loop would record for
+ * task i.  *d_count receives the number of records; d_scratch needs
+ * wamd_records_scratch_bytes(n) bytes. */
+WAMD_API uint64_t wamd_records_scratch_bytes(uint32_t n);
+WAMD_API int wamd_emit_lev_records_dev(wamd_ctx* ctx, uint32_t n, const wamd_dist_task* d_tasks,
+                                       const wamd_dist_result* d_results, const uint32_t* d_record_pos,
+                                       const uint8_t* d_direction, uint8_t* d_records, uint32_t* d_count,
+                                       void* d_scratch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,64 @@
+"""The N > 1 path on CPU: two processes (gloo) shard bins and gather variable-length
+mapping-record blocks to rank 0, as bench.py does over RCCL."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from whisper_amd import gather
+
+
+def _records(rank, n):
+    g = np.random.default_rng(100 + rank)
+    r = np.zeros((n + 5, gather.RECORD_BYTES), np.uint8)
+    r[:n] = g.integers(0, 256, (n, gather.RECORD_BYTES), dtype=np.uint8)
+    return r
+
+
+def _worker(rank, world, port, counts, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rec = torch.from_numpy(_records(rank, counts[rank]))
+        out = gather.gather_records(rec, counts[rank], dst=0)
+        if rank == 0:
+            q.put([o.numpy().copy() for o in out])
+        else:
+            assert out is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_gather_two_ranks():
+    for counts in ([7, 3], [0, 11], [4, 0]):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, counts, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        got = q.get(timeout=120)
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+        for r in range(2):
+            np.testing.assert_array_equal(got[r], _records(r, counts[r])[: counts[r]])
+
+
+def test_shard_bins_partition():
+    for world in (1, 2, 4, 8):
+        seen = sorted(b for r in range(world) for b in gather.shard_bins(384, world, r))
+        assert seen == list(range(384))

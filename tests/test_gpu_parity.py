@@ -236,3 +236,41 @@ def test_clip_boundary(ctx, oracle):
     for i in range(len(rec)):
         n = wrec["cigar_len"][i] + 1
         assert bytes(gcig[i, :n]) == bytes(wcig[i, :n]), i
+
+
+def test_emit_lev_records(ctx, oracle):
+    """Accepted candidates -> 12-byte mapping records in task order (wamd_emit_lev_records_dev)."""
+    import torch
+    codes, packed, (blob, off, lens), tasks = common.distance_workload(150, 12, 5000, seed=71)
+    _, want = oracle.distance(packed, blob, off, lens, 0, tasks, -1)
+    n = len(tasks)
+    dev = torch.device("cuda", 0)
+    reads = ctx.upload_reads(blob, off, lens, 0)
+    d_tasks = torch.from_numpy(tasks.view(np.uint8).copy()).to(dev)
+    d_res = torch.zeros(2 * n, dtype=torch.int32, device=dev)
+    pos = (tasks["ref_pos"] + 12).astype(np.uint32)
+    direction = (np.arange(n) % 3 != 0).astype(np.uint8)
+    d_pos = torch.from_numpy(pos.view(np.int32).copy()).to(dev)
+    d_dir = torch.from_numpy(direction).to(dev)
+    d_rec = torch.zeros((n, 12), dtype=torch.uint8, device=dev)
+    d_cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    d_scr = torch.zeros(ctx.records_scratch_bytes(n), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    ctx.dynamic_programming_dev(reads, d_tasks, n, d_res)
+    ctx.emit_lev_records_dev(n, d_tasks, d_res, d_pos, d_dir, d_rec, d_cnt, d_scr)
+    ctx.synchronize()
+    assert ctx.take_flags() == 0
+    reads.free()
+    ok = np.nonzero(want["edit_distance"] <= 12)[0]
+    assert int(d_cnt.item()) == len(ok)
+    rec = d_rec.cpu().numpy()[: len(ok)]
+    # expected bytes: read_idx LE, then the reference's 5-byte lev record
+    m = np.zeros(len(ok), api.MAPPING)
+    m["type"] = 0
+    m["pos"] = pos[ok]
+    m["no_mismatches"] = want["edit_distance"][ok]
+    _, wire, sizes = oracle.serialize(m, direction[ok])
+    assert (sizes == 5).all()
+    np.testing.assert_array_equal(rec[:, :4].copy().view("<u4")[:, 0], tasks["read_idx"][ok])
+    np.testing.assert_array_equal(rec[:, 4:9], wire[:, :5])
+    assert (rec[:, 9:] == 0).all()

@@ -64,7 +64,7 @@ EXPORTS = [
     "wamd_levdiag_dev", "wamd_align", "wamd_align_dev", "wamd_align_workspace_bytes",
     "wamd_indel_match", "wamd_indel_match_dev", "wamd_indel_ext_cigar", "wamd_indel_ext_cigar_dev",
     "wamd_clip_boundary", "wamd_clip_boundary_dev", "wamd_serialize_mappings",
-    "wamd_serialize_mappings_dev",
+    "wamd_serialize_mappings_dev", "wamd_records_scratch_bytes", "wamd_emit_lev_records_dev",
 ]
 
 
@@ -105,6 +105,7 @@ def lib():
         L.wamd_ctx_stream.restype = C.c_void_p
         L.wamd_align_workspace_bytes.restype = C.c_uint64
         L.wamd_reads_count.restype = C.c_uint32
+        L.wamd_records_scratch_bytes.restype = C.c_uint64
         _lib = L
     return _lib
 
@@ -270,6 +271,15 @@ class Context:
     def lev_diag_dev(self, reads, d_tasks, n, d_results, stream=None):
         _check(lib().wamd_levdiag_dev(self.h, reads.h, _ptr(d_tasks), C.c_uint32(n),
                                       _ptr(d_results), C.c_void_p(stream or 0)))
+
+    def records_scratch_bytes(self, n):
+        return int(lib().wamd_records_scratch_bytes(C.c_uint32(n)))
+
+    def emit_lev_records_dev(self, n, d_tasks, d_results, d_record_pos, d_direction, d_records, d_count,
+                             d_scratch, stream=None):
+        _check(lib().wamd_emit_lev_records_dev(self.h, C.c_uint32(n), _ptr(d_tasks), _ptr(d_results),
+                                               _ptr(d_record_pos), _ptr(d_direction), _ptr(d_records),
+                                               _ptr(d_count), _ptr(d_scratch), C.c_void_p(stream or 0)))
 
     def align_workspace_bytes(self, reads, n):
         return int(lib().wamd_align_workspace_bytes(reads.h, C.c_uint32(n)))

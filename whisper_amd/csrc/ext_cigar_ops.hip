@@ -437,6 +437,104 @@ __global__ __launch_bounds__(256) void serialize_kernel(uint32_t n, const wamd_m
     sizes[gid] = (uint8_t)k;
 }
 
+// ---- accepted candidates -> mapping records, deterministic order ---------------------
+// pass 1: accepted candidates per 256-task block; pass 2: exclusive scan of the block counts
+// (one workgroup); pass 3: every block writes its records at its offset, in task order.
+__global__ __launch_bounds__(256) void records_count_kernel(uint32_t n, const wamd_dist_task* __restrict__ tasks,
+                                                            const wamd_dist_result* __restrict__ res,
+                                                            uint32_t* __restrict__ block_counts)
+{
+    __shared__ uint32_t wave_cnt[4];
+    const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
+    const bool ok = gid < n && res[gid].edit_distance <= tasks[gid].max_ed;
+    const uint64_t b = __ballot(ok);
+    if ((threadIdx.x & 63) == 0)
+        wave_cnt[threadIdx.x >> 6] = (uint32_t)__popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0)
+        block_counts[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+}
+
+__global__ __launch_bounds__(1024) void records_scan_kernel(uint32_t nb, uint32_t* __restrict__ block_counts,
+                                                            uint32_t* __restrict__ total)
+{
+    __shared__ uint32_t part[1024];
+    const uint32_t t = threadIdx.x;
+    const uint32_t per = (nb + 1023) / 1024;
+    const uint32_t lo = t * per, hi = min(nb, lo + per);
+    uint32_t s = 0;
+    for (uint32_t i = lo; i < hi; ++i)
+        s += block_counts[i];
+    part[t] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {   // Hillis-Steele inclusive scan
+        const uint32_t v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = t ? part[t - 1] : 0;
+    for (uint32_t i = lo; i < hi; ++i) {
+        const uint32_t c = block_counts[i];
+        block_counts[i] = run;
+        run += c;
+    }
+    if (t == 1023)
+        *total = part[1023];
+}
+
+__global__ __launch_bounds__(256) void records_write_kernel(uint32_t n, const wamd_dist_task* __restrict__ tasks,
+                                                            const wamd_dist_result* __restrict__ res,
+                                                            const uint32_t* __restrict__ record_pos,
+                                                            const uint8_t* __restrict__ direction,
+                                                            const uint32_t* __restrict__ block_offsets,
+                                                            uint8_t* __restrict__ records)
+{
+    __shared__ uint32_t wave_cnt[4];
+    const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t ed = 0;
+    bool ok = false;
+    if (gid < n) {
+        ed = res[gid].edit_distance;
+        ok = ed <= tasks[gid].max_ed;
+    }
+    const uint64_t b = __ballot(ok);
+    if (lane == 0)
+        wave_cnt[wave] = (uint32_t)__popcll(b);
+    __syncthreads();
+    if (!ok)
+        return;
+    uint32_t rank = (uint32_t)__popcll(b & ((1ull << lane) - 1));
+    for (uint32_t w = 0; w < wave; ++w)
+        rank += wave_cnt[w];
+    const uint32_t pos = record_pos[gid];
+    // candidate_mapping_t::serialize for type lev, results.cpp:161-173
+    const uint32_t flag = (direction[gid] ? 0x80u : 0u) + 0x40u + (ed & 0x3fu);
+    uint32_t* o = reinterpret_cast<uint32_t*>(records + (uint64_t)(block_offsets[blockIdx.x] + rank) * 12);
+    o[0] = tasks[gid].read_idx;
+    o[1] = __builtin_bswap32(pos);
+    o[2] = flag;
+}
+
+uint64_t records_scratch_bytes(uint32_t n) { return ((uint64_t)(n + 255) / 256 + 1) * sizeof(uint32_t) + 256; }
+
+int launch_emit_lev_records(wamd_ctx* ctx, uint32_t n, const wamd_dist_task* d_tasks,
+                            const wamd_dist_result* d_results, const uint32_t* d_record_pos,
+                            const uint8_t* d_direction, uint8_t* d_records, uint32_t* d_count, void* d_scratch,
+                            hipStream_t s)
+{
+    WAMD_HIP(hipSetDevice(ctx->device));
+    const uint32_t nb = (n + 255) / 256;
+    uint32_t* counts = (uint32_t*)d_scratch;
+    hipLaunchKernelGGL(records_count_kernel, dim3(nb), dim3(256), 0, s, n, d_tasks, d_results, counts);
+    hipLaunchKernelGGL(records_scan_kernel, dim3(1), dim3(1024), 0, s, nb, counts, d_count);
+    hipLaunchKernelGGL(records_write_kernel, dim3(nb), dim3(256), 0, s, n, d_tasks, d_results, d_record_pos,
+                       d_direction, counts, d_records);
+    WAMD_HIP(hipGetLastError());
+    return WAMD_OK;
+}
+
 int launch_indel_ext_cigar(wamd_ctx* ctx, const wamd_reads* r, const wamd_indel_cigar_task* d_tasks,
                            uint32_t n, wamd_indel_cigar_result* d_results, uint8_t* d_cigars,
                            uint32_t cigar_stride, hipStream_t s)

@@ -698,4 +698,24 @@ int wamd_serialize_mappings(wamd_ctx* ctx, uint32_t n, const wamd_mapping* mappi
     return WAMD_OK;
 }
 
+uint64_t wamd_records_scratch_bytes(uint32_t n) { return records_scratch_bytes(n); }
+
+int wamd_emit_lev_records_dev(wamd_ctx* ctx, uint32_t n, const wamd_dist_task* d_tasks,
+                              const wamd_dist_result* d_results, const uint32_t* d_record_pos,
+                              const uint8_t* d_direction, uint8_t* d_records, uint32_t* d_count, void* d_scratch,
+                              void* stream)
+{
+    if (!ctx || !d_count)
+        return WAMD_ERR_INVALID_ARG;
+    if (n == 0) {
+        WAMD_HIP(hipMemsetAsync(d_count, 0, sizeof(uint32_t), pick(ctx, stream)));
+        return WAMD_OK;
+    }
+    if (!d_tasks || !d_results || !d_record_pos || !d_direction || !d_records || !d_scratch ||
+        ((uintptr_t)d_records & 3u) || ((uintptr_t)d_scratch & 3u))
+        return WAMD_ERR_INVALID_ARG;
+    return launch_emit_lev_records(ctx, n, d_tasks, d_results, d_record_pos, d_direction, d_records, d_count,
+                                   d_scratch, pick(ctx, stream));
+}
+
 } // extern "C"

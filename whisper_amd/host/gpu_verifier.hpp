@@ -1,0 +1,216 @@
+// gpu_verifier.hpp - host-side mirror of the reference's verifier objects over the C-ABI.
+//
+// The reference calls one verifier per candidate from inside its per-thread loops
+// (mapper/mapping_core_sa.cpp:215-348, mapper/sam_matching.cpp:689-752).  These classes
+// keep the reference's method names and argument meaning, but a call only ENQUEUES the
+// candidate and returns a ticket; flush() verifies the whole batch on the GPU through
+// include/whisper_amd.h, after which the results are read back by ticket in the order the
+// loop enqueued them.  One object per worker thread, as in the reference
+// (mapper/mapping_core.cpp:154-191); objects are not thread-safe, a wamd_ctx may be shared.
+//
+// Header-only C++17, no dependency besides the C-ABI; errors become std::runtime_error
+// like the reference's own (mapper/LevMyers64.cpp:244-252).
+#pragma once
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/whisper_amd.h"
+
+namespace whisper_amd {
+
+using uchar_t = unsigned char;
+using ref_pos_t = uint32_t;
+enum class genome_t { direct, rev_comp };   // common/defs.h:79
+
+inline void check(int rc, const char* what)
+{
+    if (rc != WAMD_OK)
+        throw std::runtime_error(std::string(what) + ": " + wamd_last_error());
+}
+
+// CReference::GetData() uploaded once per device; replaces setReference() everywhere.
+class GpuReference {
+public:
+    GpuReference(int device, const uchar_t* ref_ptr, uint64_t packed_bytes, uint32_t ref_size, uint32_t cur_offset)
+    {
+        check(wamd_ctx_create(device, ref_ptr, packed_bytes, ref_size, cur_offset, &ctx_), "wamd_ctx_create");
+    }
+    ~GpuReference() { wamd_ctx_destroy(ctx_); }
+    GpuReference(const GpuReference&) = delete;
+    GpuReference& operator=(const GpuReference&) = delete;
+    // what a new stage changes (mapper/mapping_core.cpp:156: SetReference(ref, size, start_pos))
+    void setReference(uint32_t ref_size, uint32_t cur_offset)
+    {
+        check(wamd_ctx_set_reference_params(ctx_, ref_size, cur_offset), "wamd_ctx_set_reference_params");
+    }
+    void setMaxTextLen(uint32_t max_text_len) { check(wamd_ctx_set_max_text_len(ctx_, max_text_len), "max_text_len"); }
+    wamd_ctx* ctx() const { return ctx_; }
+
+private:
+    wamd_ctx* ctx_ = nullptr;
+};
+
+// Mirrors LevMyers (mapper/LevMyers.h:27-68) and CEditDist::LevDiag (mapper/edit_dist.h:50-51)
+// for the mapping stages: reads are nibble-packed, only the edit distance is consumed.
+class GpuLevMyers {
+public:
+    explicit GpuLevMyers(GpuReference& ref) : ref_(ref) {}
+
+    // LevMyers::preprocess(seq, seq_len, orientation): the read every following
+    // dynamicProgramming()/LevDiag() call verifies (mapper/mapping_core_sa.cpp:212-213).
+    bool preprocess(const uchar_t* seq, uint32_t seq_len, genome_t orientation)
+    {
+        offsets_.push_back(blob_.size());
+        lens_.push_back(seq_len);
+        blob_.insert(blob_.end(), seq, seq + (seq_len + 1) / 2);
+        cur_read_ = (uint32_t)lens_.size() - 1;
+        cur_flags_ = orientation == genome_t::rev_comp ? WAMD_TASK_FLAG_REV_COMP : 0;
+        return true;
+    }
+
+    // LevMyers::dynamicProgramming(ref_pos, max_distance_in_ref, max_mate_edit_distance, pos, ed):
+    // enqueue; returns the ticket to read the result with after flush().
+    size_t dynamicProgramming(ref_pos_t ref_pos, uint32_t max_distance_in_ref, uint32_t max_mate_edit_distance)
+    {
+        wamd_dist_task t{};
+        t.read_idx = cur_read_;
+        t.ref_pos = ref_pos;
+        t.max_distance_in_ref = max_distance_in_ref;
+        t.max_ed = (uint16_t)max_mate_edit_distance;
+        t.variant = WAMD_VARIANT_AUTO;   // by read length, mapping_core_sa.cpp:207-210
+        t.flags = (uint8_t)cur_flags_;
+        dist_tasks_.push_back(t);
+        return dist_tasks_.size() - 1;
+    }
+
+    // CEditDist::LevDiag(pattern, len, position_in_text, fixed_left, fixed_right, max_mismatches, dir_gen_flag)
+    size_t LevDiag(uint32_t position_in_text, uint32_t fixed_left, uint32_t fixed_right, uint32_t max_mismatches,
+                   bool dir_gen_flag)
+    {
+        wamd_levdiag_task t{};
+        t.read_idx = cur_read_;
+        t.position_in_text = position_in_text;
+        t.fixed_left = (uint16_t)fixed_left;
+        t.fixed_right = (uint16_t)fixed_right;
+        t.max_mismatches = (uint16_t)max_mismatches;
+        t.dir_gen_flag = dir_gen_flag ? 1 : 0;
+        lev_tasks_.push_back(t);
+        return lev_tasks_.size() - 1;
+    }
+
+    // Verifies everything enqueued since the last flush (one bin of one stage is the natural
+    // unit: results never influence which candidates are enumerated).
+    void flush()
+    {
+        dist_results_.assign(dist_tasks_.size(), wamd_dist_result{});
+        lev_results_.assign(lev_tasks_.size(), 0u);
+        if (lens_.empty())
+            return;
+        offsets_.push_back(blob_.size());
+        wamd_reads* reads = nullptr;
+        check(wamd_reads_upload(ref_.ctx(), blob_.data(), offsets_.data(), lens_.data(), (uint32_t)lens_.size(),
+                                WAMD_READS_NIBBLE, 3, &reads), "wamd_reads_upload");
+        int rc = WAMD_OK;
+        if (!dist_tasks_.empty())
+            rc = wamd_verify_distance(ref_.ctx(), reads, dist_tasks_.data(), (uint32_t)dist_tasks_.size(),
+                                      WAMD_LAST_SYMBOL_FROM_READ, dist_results_.data());
+        if (rc == WAMD_OK && !lev_tasks_.empty())
+            rc = wamd_levdiag(ref_.ctx(), reads, lev_tasks_.data(), (uint32_t)lev_tasks_.size(), lev_results_.data());
+        wamd_reads_free(reads);
+        blob_.clear();
+        offsets_.clear();
+        lens_.clear();
+        dist_tasks_.clear();
+        lev_tasks_.clear();
+        check(rc, "verification batch");
+    }
+
+    // the bool / pos / edit_distance dynamicProgramming() would have handed back
+    bool result(size_t ticket, ref_pos_t& pos, uint32_t& edit_distance) const
+    {
+        const wamd_dist_result& r = dist_results_.at(ticket);
+        pos = r.pos;
+        edit_distance = r.edit_distance;
+        return r.pos != 0 || r.edit_distance == 0;
+    }
+    uint32_t levDiagResult(size_t ticket) const { return lev_results_.at(ticket); }
+
+private:
+    GpuReference& ref_;
+    std::vector<uchar_t> blob_;
+    std::vector<uint64_t> offsets_;
+    std::vector<uint32_t> lens_;
+    std::vector<wamd_dist_task> dist_tasks_;
+    std::vector<wamd_levdiag_task> lev_tasks_;
+    std::vector<wamd_dist_result> dist_results_;
+    std::vector<uint32_t> lev_results_;
+    uint32_t cur_read_ = 0;
+    uint32_t cur_flags_ = 0;
+};
+
+// Mirrors the post-processing use: preprocessRawSeq + dynamicProgramming + getExtCigar
+// (+ refine_ext_cigar), mapper/sam_matching.cpp:689-752 and 401-426.
+class GpuLevMyersAligner {
+public:
+    GpuLevMyersAligner(GpuReference& ref, uint32_t max_cigar_len) : ref_(ref), stride_((max_cigar_len + 3) / 4 * 4) {}
+
+    bool preprocessRawSeq(const uchar_t* seq, uint32_t seq_len, genome_t orientation)
+    {
+        offsets_.push_back(blob_.size());
+        lens_.push_back(seq_len);
+        blob_.insert(blob_.end(), seq, seq + seq_len);
+        cur_read_ = (uint32_t)lens_.size() - 1;
+        cur_flags_ = orientation == genome_t::rev_comp ? WAMD_TASK_FLAG_REV_COMP : 0;
+        return true;
+    }
+    size_t dynamicProgramming(ref_pos_t ref_pos, uint32_t max_distance_in_ref, uint32_t max_mate_edit_distance)
+    {
+        wamd_dist_task t{};
+        t.read_idx = cur_read_;
+        t.ref_pos = ref_pos;
+        t.max_distance_in_ref = max_distance_in_ref;
+        t.max_ed = (uint16_t)max_mate_edit_distance;
+        t.flags = (uint8_t)cur_flags_;
+        tasks_.push_back(t);
+        return tasks_.size() - 1;
+    }
+    void flush(bool enable_short_indel_refinement)
+    {
+        results_.assign(tasks_.size(), wamd_align_result{});
+        cigars_.assign(tasks_.size() * (size_t)stride_, 0);
+        if (tasks_.empty())
+            return;
+        offsets_.push_back(blob_.size());
+        wamd_reads* reads = nullptr;
+        check(wamd_reads_upload(ref_.ctx(), blob_.data(), offsets_.data(), lens_.data(), (uint32_t)lens_.size(),
+                                WAMD_READS_ASCII, 3, &reads), "wamd_reads_upload");
+        // CSamGenerator's objects only ever see preprocessRawSeq: last_symbol stays 0
+        int rc = wamd_align(ref_.ctx(), reads, tasks_.data(), (uint32_t)tasks_.size(), 0,
+                            enable_short_indel_refinement ? 1 : 0, results_.data(), cigars_.data(), stride_);
+        wamd_reads_free(reads);
+        blob_.clear();
+        offsets_.clear();
+        lens_.clear();
+        tasks_.clear();
+        check(rc, "wamd_align");
+    }
+    const wamd_align_result& result(size_t ticket) const { return results_.at(ticket); }
+    const uchar_t* extCigar(size_t ticket) const { return cigars_.data() + ticket * (size_t)stride_; }
+
+private:
+    GpuReference& ref_;
+    uint32_t stride_;
+    std::vector<uchar_t> blob_;
+    std::vector<uint64_t> offsets_;
+    std::vector<uint32_t> lens_;
+    std::vector<wamd_dist_task> tasks_;
+    std::vector<wamd_align_result> results_;
+    std::vector<uchar_t> cigars_;
+    uint32_t cur_read_ = 0;
+    uint32_t cur_flags_ = 0;
+};
+
+} // namespace whisper_amd
