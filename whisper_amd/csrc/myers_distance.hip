@@ -2,41 +2,161 @@
 //
 // Replaces LevMyers{64,128,256}::dynamicProgramming in "distance only" mode
 // (mapping stages: mapper/mapping_core_sa.cpp:237/289; also the first pass of the
-// alignment path).  The recurrence is the Myers/Hyyro block algorithm exactly as
-// the reference states it (mapper/LevMyers64.cpp:312-325): no carry through the
-// add between 64-bit words, HN>>63 enters Eq and VP of the next word, HP>>63 the
-// shifted HP.
+// alignment path).  The DP is the one the reference computes with the Myers/Hyyro block
+// recurrence (mapper/LevMyers64.cpp:312-325); since that recurrence is exact, any exact
+// bit-parallel evaluation of the same columns yields the same HP/HN/D0 bits in the score
+// row, and those bits are all the reference's bookkeeping reads.
 //
 // MI355X mapping
-//   * one task per lane, all words of the bit-vectors in that lane's VGPRs:
-//     carries between words never leave the lane, so the reference's
-//     anti-diagonal skew (LevMyers256.hpp:138-159) is not needed; what the skew
-//     changes observably - iteration count, sentinel iterations, early exit on
-//     the iteration index - is carried over arithmetically;
-//   * pattern-match vectors live in LDS, laid out [row][word][thread] so that a
-//     wave's 64 lanes read 64 consecutive 8-byte slots whatever row (text
-//     symbol) each lane asks for: ds_read_b64 without bank conflicts;
-//   * the genome stays in the reference's 4-bit packing in HBM; every lane
-//     streams its own window dword by dword (8 symbols), two dwords ahead, and
-//     all lanes reload on the same iteration so the loop stays wave-uniform;
-//   * no matrix is stored: the kernel is VALU-integer bound
-//     (about 45 lane-ops per 64-bit word-column).
+//   * one task per lane; the whole bit-vector (NW dwords of VP and VN) lives in that
+//     lane's VGPRs, so the add carries straight through v_addc_co chains and the two
+//     shifts are v_alignbit funnels: no per-word carry bookkeeping and none of the
+//     reference's anti-diagonal skew (LevMyers256.hpp:138-159).  What the skew changes
+//     observably - iteration count, sentinel iterations, early exit on the iteration
+//     index - is carried over arithmetically;
+//   * vectors are TOP-aligned (reads_prepare.hip): the read's last symbol is bit 31 of
+//     the top dword whatever its length, the rows below its first symbol are "phantom"
+//     rows that match every text symbol and start with VP = 0, which keeps D = 0 along
+//     them - the semi-global boundary the real row 0 needs.  The score bits are then
+//     always the sign bits of the top dword's HP/HN/D0;
+//   * pattern-match vectors for A,C,G,T live in LDS as [dword][symbol][lane]: a wave's 64
+//     lanes read 64 consecutive dwords whatever symbol each lane asks for
+//     (conflict-free ds_read_b32), and the symbol only shifts into the address;
+//   * the genome stays in the reference's 4-bit packing in HBM; every lane fetches its
+//     window TEXT_CHUNK dwords at a time (back-to-back loads of one or two cache lines,
+//     one batch ahead) and keeps them in registers;
+//   * groups of 8 columns run on a branch-free fast path when the wave is uniform enough
+//     (same variant, no lane at its last columns, only A/C/G/T in the text): score,
+//     minimum, tie-break, early exit and freezing of finished lanes are all arithmetic
+//     on a packed (distance, tie flag, column) key.  Everything else - text symbols >= 4,
+//     ragged ends, mixed variants, oversized windows - takes a per-lane slow group with
+//     the reference's bookkeeping spelled out (LevMyers256.hpp:174-234,
+//     LevMyers128.hpp:175-221, LevMyers64.cpp:328-366).
 #include "wamd_internal.h"
 
 namespace wamd {
 
-struct LaneTask {
-    uint32_t m;          // read length
-    uint32_t wn;         // word holding the score bit
-    uint32_t sb;         // score bit inside that word
-    uint32_t n_cols;     // text columns the score word sees
-    uint32_t exit_t;     // W + 1 - wn + k   (early exit: curr_ed + col > exit_t)
-    uint32_t k;
-    uint32_t ref_pos;
-    uint32_t last_sym;
-    uint32_t presence;
-    bool skewed, is256, rev;
+constexpr int TEXT_CHUNK = 8;   // genome dwords (8 columns each) fetched per batch and lane
+
+enum { RULE_M64 = 0, RULE_M128 = 1, RULE_M256 = 2 };
+
+// a value the compiler must keep in a VGPR: VALU ops with an SGPR operand issue at the
+// slow (VOP3) rate on gfx950, see scripts/ubench/valu_rates.hip
+__device__ __forceinline__ uint32_t in_vgpr(uint32_t x)
+{
+    uint32_t r;
+    asm("v_mov_b32 %0, %1" : "=v"(r) : "s"(x));
+    return r;
+}
+
+// One text column over the whole NW-dword vector (LevMyers64.cpp:312-325 as a single
+// wide word).  Returns HP, HN and D0 of the top dword (score row = bit 31).
+template <int NW>
+__device__ __forceinline__ void column_core(const uint32_t (&eq)[NW], uint32_t (&VP)[NW], uint32_t (&VN)[NW],
+                                            uint32_t& hp_top, uint32_t& hn_top, uint32_t& d0_top)
+{
+    uint32_t carry = 0, hp_prev = 0, hn_prev = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const uint32_t vp = VP[w], vn = VN[w];
+        uint32_t cout;
+        const uint32_t sum = __builtin_addc(eq[w] & vp, vp, carry, &cout);
+        carry = cout;
+        const uint32_t d0 = (sum ^ vp) | eq[w] | vn;
+        const uint32_t hp = vn | ~(d0 | vp);
+        const uint32_t hn = d0 & vp;
+        const uint32_t hps = w ? __builtin_amdgcn_alignbit(hp, hp_prev, 31) : hp + hp;
+        const uint32_t hns = w ? __builtin_amdgcn_alignbit(hn, hn_prev, 31) : hn + hn;
+        VP[w] = hns | ~(d0 | hps);
+        VN[w] = d0 & hps;
+        hp_prev = hp;
+        hn_prev = hn;
+        if (w == NW - 1) {
+            hp_top = hp;
+            hn_top = hn;
+            d0_top = d0;
+        }
+    }
+}
+
+// phantom-row mask of dword j for a read of m symbols in an NW-dword vector
+template <int NW>
+__device__ __forceinline__ uint32_t phantom_mask(uint32_t m, int j)
+{
+    const uint32_t s = 32u * NW - m;   // phantom rows
+    const uint32_t lo = 32u * (uint32_t)j;
+    return s >= lo + 32u ? ~0u : (s <= lo ? 0u : ((1u << (s - lo)) - 1u));
+}
+
+// Per-lane state between groups.  `plain` bookkeeping is the reference's own variables;
+// the fast path packs it (see group_fast).
+struct Lane {
+    uint32_t m, wn, n_cols, exit_t, k, last_sym, presence;
+    uint32_t rule;           // RULE_*
+    bool rev;
+    // plain bookkeeping
+    uint32_t curr_ed, min_ed, min_pos;
+    bool stopped;
 };
+
+// ---- fast group: 8 columns, wave-uniform rule, text symbols all < 4, no lane ends ------------
+//   E     = curr_ed + column            (so the early exit "curr_ed + col > exit_t" is E > exit_t)
+//   key   = min_ed << 17 | 0 << 16 | (0xffff - min_pos)
+//   cand  = ced    << 17 | t << 16 | (0xffff - col)     t = 1 when a tie may NOT move min_pos
+//   key'  = min(key, cand) & ~(1 << 16): a smaller distance always wins, an equal one wins
+//           exactly when t = 0 (later column = smaller low half)
+//   deadf : bit 31 set once the lane has left the loop (early exit, or past its last column:
+//           n_left = n_cols - base); it lifts cand above every key
+template <int NW, int BLOCK, int RULE>
+__device__ __forceinline__ void group_fast(const char* lds_lane, uint32_t syms, uint32_t base, uint32_t lsrep,
+                                           uint32_t exit_t, uint32_t n_left, uint32_t rowmask, uint32_t sgn,
+                                           uint32_t (&VP)[NW], uint32_t (&VN)[NW], uint32_t& E, uint32_t& key,
+                                           uint32_t& deadf)
+{
+    constexpr int RSH = BLOCK == 256 ? 10 : (BLOCK == 128 ? 9 : 8);   // log2(row stride in bytes)
+    const uint32_t symsA = syms << 12;
+    uint32_t nz = 0, nzA = 0;
+    if (RULE == RULE_M256) {
+        // bit 4u = (text symbol u != last_symbol), LevMyers256.hpp:191-196
+        uint32_t t = syms ^ lsrep;
+        t |= t >> 1;
+        t |= t >> 2;
+        nz = t & 0x11111111u;
+        nzA = nz << 16;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        // symbol u, shifted to the row-stride position of the LDS byte address
+        const uint32_t srow = u < 5 ? symsA >> (12 + 4 * u - RSH) : syms >> (4 * u - RSH);
+        const char* rowp = lds_lane + (srow & rowmask);
+        uint32_t eq[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+            eq[w] = *reinterpret_cast<const uint32_t*>(rowp + w * (4 * BLOCK * 4));
+        uint32_t hp, hn, d0;
+        column_core<NW>(eq, VP, VN, hp, hn, d0);
+
+        const uint32_t col = base + u + 1;
+        const uint32_t nhn = ~hn;
+        E += hp >> 31;
+        E += nhn >> 31;   // + 1 for the column, - 1 when HN is set
+        uint32_t cand = (E << 17) + ((0u - (col << 17)) + (0xffffu - col));
+        if (RULE == RULE_M256) {
+            // a tie moves min_pos unless D0 is set and the text symbol differs from last_symbol
+            const uint32_t nzs = u < 4 ? nzA >> (4 * u) : nz >> (4 * u - 16);
+            cand |= (d0 >> 15) & nzs & 0x10000u;
+        } else {
+            // a tie moves min_pos only from the previous column (LevMyers128.hpp:205, LevMyers64.cpp:349)
+            const uint32_t x = (key ^ (0x10000u - col)) & 0xffffu;
+            cand |= (x + 0xffffu) & 0x10000u;
+        }
+        deadf |= n_left - (uint32_t)(u + 1);   // negative past the lane's last column
+        cand |= deadf & sgn;
+        key = min(key, cand) & ~0x10000u;
+        if (RULE != RULE_M64)
+            deadf |= (exit_t - E) & nhn;   // ced + col > exit_t and HN clear (LevMyers256.hpp:232-233)
+    }
+}
 
 template <int NW, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void myers_distance_kernel(
@@ -44,22 +164,22 @@ __global__ __launch_bounds__(BLOCK) void myers_distance_kernel(
     int last_symbol, uint32_t max_text_len, wamd_dist_result* __restrict__ results,
     uint32_t* __restrict__ flags)
 {
-    // rows 0..3 = text symbols A,C,G,T; row 4 = zeros (every other text symbol)
-    __shared__ uint64_t pm_lds[5 * NW * BLOCK];
+    // [dword][symbol A,C,G,T][lane]
+    __shared__ uint32_t pm_lds[NW * 4 * BLOCK];
 
     const uint32_t tid = threadIdx.x;
     const uint32_t gid = blockIdx.x * BLOCK + tid;
     bool valid = gid < n;
 
-    LaneTask t{};
+    Lane t{};
     uint32_t err = 0;
-    uint32_t read_idx = 0;
+    uint32_t read_idx = 0, ref_pos = 0;
     if (valid) {
         const wamd_dist_task task = tasks[gid];
         read_idx = task.read_idx;
         const uint32_t W = task.max_distance_in_ref;
         t.k = task.max_ed;
-        t.ref_pos = task.ref_pos;
+        ref_pos = task.ref_pos;
         t.rev = task.flags & WAMD_TASK_FLAG_REV_COMP;
         if (read_idx >= rv.n) {
             err = FLAG_READ_IDX;
@@ -72,21 +192,20 @@ __global__ __launch_bounds__(BLOCK) void myers_distance_kernel(
             uint32_t variant = task.variant;
             if (variant == WAMD_VARIANT_AUTO)   // mapping_core_sa.cpp:207-210
                 variant = t.m < 128 ? WAMD_VARIANT_M128 : (t.m < 256 ? WAMD_VARIANT_M256 : WAMD_VARIANT_M64);
-            t.wn = (t.m - 1) / 64;
-            t.sb = (t.m - 1) % 64;
-            t.skewed = variant != WAMD_VARIANT_M64;
-            t.is256 = variant == WAMD_VARIANT_M256;
+            t.wn = (t.m - 1) / 64;   // the reference's 64-bit word of the score bit
             if (variant > WAMD_VARIANT_M256 || (variant == WAMD_VARIANT_M128 && t.m > 128) ||
-                (variant == WAMD_VARIANT_M256 && t.m > 256) || t.wn >= (uint32_t)NW) {
+                (variant == WAMD_VARIANT_M256 && t.m > 256) || t.m > 32u * NW) {
                 err = FLAG_VARIANT;
             } else {
+                t.rule = variant == WAMD_VARIANT_M64 ? RULE_M64
+                                                     : (variant == WAMD_VARIANT_M256 ? RULE_M256 : RULE_M128);
                 // skewed variants iterate j = 1..W+1 and the score lane runs wn columns
                 // behind (LevMyers256.hpp:138,180); M64 iterates j = 1..W (LevMyers64.cpp:257)
-                t.n_cols = t.skewed ? (W + 1 - t.wn) : W;
-                if (t.skewed && W + 1 < t.wn)
+                t.n_cols = t.rule != RULE_M64 ? (W + 1 - t.wn) : W;
+                if (t.rule != RULE_M64 && W + 1 < t.wn)
                     t.n_cols = 0;
                 t.exit_t = W + 1 - t.wn + t.k;
-                if ((uint64_t)t.ref_pos + t.n_cols > g.n_symbols)
+                if ((uint64_t)ref_pos + t.n_cols > g.n_symbols)
                     err = FLAG_RANGE;
             }
         }
@@ -97,20 +216,31 @@ __global__ __launch_bounds__(BLOCK) void myers_distance_kernel(
             valid = false;
         }
     }
+    if (!valid) {
+        t = Lane{};
+        t.m = 1;
+        ref_pos = 0;
+        read_idx = 0;
+    }
 
-    // ---- this lane's pattern-match vectors -> LDS ---------------------------------
-    uint64_t* my_pm = pm_lds + tid;
+    // ---- this lane's pattern-match vectors -> LDS; VP = 1 on real rows, 0 on phantom rows ----
+    uint32_t VP[NW], VN[NW];
     {
         const uint32_t slot = valid ? (uint32_t)(t.rev ? rv.slot_rc : rv.slot_direct) : 0;
-        const uint64_t* src = rv.pm + ((uint64_t)read_idx * rv.n_orient + slot) * 4 * rv.words;
+        const uint32_t pad = NW - rv.words32;   // launcher: NW >= words32
+        const uint32_t* src = rv.pm32 + ((uint64_t)read_idx * rv.n_orient + slot) * 4 * rv.words32;
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+        for (int j = 0; j < NW; ++j) {
 #pragma unroll
-            for (int w = 0; w < NW; ++w)
-                my_pm[(c * NW + w) * BLOCK] = (valid && (uint32_t)w <= t.wn) ? src[c * rv.words + w] : 0;
-#pragma unroll
-        for (int w = 0; w < NW; ++w)
-            my_pm[(4 * NW + w) * BLOCK] = 0;
+            for (int c = 0; c < 4; ++c) {
+                uint32_t v = ~0u;   // dwords below the batch's own vectors: phantom rows
+                if (valid && (uint32_t)j >= pad)
+                    v = src[c * rv.words32 + ((uint32_t)j - pad)];
+                pm_lds[(j * 4 + c) * BLOCK + tid] = v;
+            }
+            VP[j] = ~phantom_mask<NW>(t.m, j);
+            VN[j] = 0;
+        }
         if (valid) {
             const uint32_t meta = rv.meta[(uint64_t)read_idx * rv.n_orient + slot];
             t.presence = meta & 0xffffu;
@@ -118,135 +248,179 @@ __global__ __launch_bounds__(BLOCK) void myers_distance_kernel(
         }
     }
 
-    uint32_t min_ed = t.m, min_pos = 0, curr_ed = t.m;
-    bool stopped = !valid;
+    t.min_ed = t.m;
+    t.min_pos = 0;
+    t.curr_ed = t.m;
+    t.stopped = !valid;
 
-    // ---- sentinel iterations of the skewed variants (j = 1..wn): the score lane
-    // still sees "no symbol", only the bookkeeping runs
-    // (LevMyers256.hpp:120-122, 206-234; LevMyers128.hpp:115, 199-221)
-    if (valid && t.skewed) {
+    // ---- sentinel iterations of the skewed variants (j = 1..wn): the score lane still sees
+    // "no symbol", only the bookkeeping runs (LevMyers256.hpp:120-122, 206-234;
+    // LevMyers128.hpp:115, 199-221)
+    if (valid && t.rule != RULE_M64) {
         for (uint32_t j = 1; j <= t.wn && j <= t.n_cols + t.wn; ++j) {
-            if (t.is256)
-                min_pos = j - t.wn;
-            else if (min_pos + 1 == j - t.wn)
-                min_pos = j - t.wn;
-            if (curr_ed + j > t.exit_t + t.wn) {   // curr_ed > W + 1 - j + k
-                stopped = true;
+            if (t.rule == RULE_M256)
+                t.min_pos = j - t.wn;
+            else if (t.min_pos + 1 == j - t.wn)
+                t.min_pos = j - t.wn;
+            if (t.curr_ed + j > t.exit_t + t.wn) {   // curr_ed > W + 1 - j + k
+                t.stopped = true;
                 break;
             }
         }
     }
-
-    uint64_t VP[NW], VN[NW];
-#pragma unroll
-    for (int w = 0; w < NW; ++w) {
-        VP[w] = ~0ull;
-        VN[w] = 0;
+    if (valid && (t.stopped || t.n_cols == 0)) {
+        // finished before the first text column
+        results[gid].edit_distance = t.min_ed;
+        results[gid].pos = t.min_ed > t.k ? 0u : t.min_pos;
+        valid = false;
+        t.stopped = true;
     }
 
-    // is the score word the same (the top one) for every lane of this wave?
-    const bool top_word = __all(!valid || t.wn == (uint32_t)(NW - 1));
-    const uint32_t sb_lo = t.sb & 31u;
-    const bool sb_hi = t.sb >= 32u;
+    // ---- wave-uniform facts ------------------------------------------------------------------
+    const uint64_t live0 = __ballot(valid);
+    const uint32_t rule0 =
+        __builtin_amdgcn_readfirstlane(__shfl((int)t.rule, live0 ? __ffsll((long long)live0) - 1 : 0));
+    const bool uniform_rule = __all(!valid || t.rule == rule0);
+    // the packed key holds 15 bits of distance + column and 16 bits of column
+    const bool fits = __all(!valid || t.m + t.n_cols < 32000u);
+    const bool can_fast = uniform_rule && fits;
 
-    // ---- text stream: three swapped dwords in flight --------------------------------
-    const uint32_t shift = (t.ref_pos & 7u) * 4u;
-    uint32_t didx = t.ref_pos >> 3;
-    uint32_t d_lo = load_genome_dword(g, didx);
-    uint32_t d_hi = load_genome_dword(g, didx + 1);
-    uint32_t d_nx = load_genome_dword(g, didx + 2);
-    didx += 3;
+    const uint32_t lsrep = t.last_sym * 0x11111111u;
+    const uint32_t rowmask = in_vgpr(3u << (BLOCK == 256 ? 10 : (BLOCK == 128 ? 9 : 8)));
+    const uint32_t sgn = in_vgpr(0x80000000u);
+    const char* lds_lane = reinterpret_cast<const char*>(pm_lds) + tid * 4;
+    const uint8_t* my_codes = rv.codes + rv.code_off[read_idx];
 
-    const uint8_t* my_codes = valid ? rv.codes + rv.code_off[read_idx] : nullptr;
-
-    for (uint32_t base = 0; __any(!stopped && base < t.n_cols); base += 8) {
-        uint32_t syms = __builtin_amdgcn_alignbit(d_hi, d_lo, shift);
-        d_lo = d_hi;
-        d_hi = d_nx;
-        d_nx = load_genome_dword(g, didx++);
-
+    // ---- text stream: R = nibble-swapped dwords of the current chunk (+1 for the funnel),
+    // NX = raw dwords of the next one, already in flight
+    const uint32_t shift = (ref_pos & 7u) * 4u;
+    uint32_t didx = ref_pos >> 3;
+    uint32_t R[TEXT_CHUNK + 1], NX[TEXT_CHUNK];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const uint32_t col = base + u + 1;
-            const uint32_t c = (syms >> (4 * u)) & 15u;
-            const uint32_t row = c < 4u ? c : 4u;
+    for (int c = 0; c <= TEXT_CHUNK; ++c)
+        R[c] = load_genome_dword(g, didx + c);
+    didx += TEXT_CHUNK + 1;
 
-            // a text symbol >= 4 matches only a read holding that very code, which
-            // real data never does (genome: 5/15, reads: 4/6); stay exact anyway
-            const bool exotic = c >= 4u && ((t.presence >> c) & 1u) && !stopped && col <= t.n_cols;
-            if (exotic) {
-                for (uint32_t w = 0; w <= t.wn; ++w) {
-                    uint64_t eq = 0;
-                    const uint32_t lo = w * 64, hi = min(t.m, lo + 64);
-                    for (uint32_t i = lo; i < hi; ++i) {
-                        const uint32_t rcode = t.rev ? rc_code(packed_symbol(my_codes, t.m - 1 - i))
-                                                     : packed_symbol(my_codes, i);
-                        eq |= (uint64_t)(rcode == c) << (i - lo);
-                    }
-                    my_pm[(4 * NW + w) * BLOCK] = eq;
-                }
-            }
+    bool packed = false;   // wave-uniform: which bookkeeping form is current
+    uint32_t E = 0, key = 0, deadf = 0;
+    uint32_t base = 0;
 
-            const uint64_t* eqrow = my_pm + row * (NW * BLOCK);
-            uint64_t hn_in = 0, hp_in = 0;
-            uint64_t sD0 = 0, sHP = 0, sHN = 0;
+    for (;;) {
+        // next chunk's loads go out before this chunk's columns
 #pragma unroll
-            for (int w = 0; w < NW; ++w) {
-                // LevMyers64.cpp:312-325
-                uint64_t X = eqrow[w * BLOCK] | hn_in;
-                const uint64_t vp = VP[w], vn = VN[w];
-                const uint64_t D0 = (((X & vp) + vp) ^ vp) | X | vn;
-                const uint64_t HP = vn | ~(D0 | vp);
-                const uint64_t HN = D0 & vp;
-                X = (HP << 1) | hp_in;
-                VP[w] = (HN << 1) | ~(D0 | X) | hn_in;
-                VN[w] = D0 & X;
-                hn_in = HN >> 63;
-                hp_in = HP >> 63;
-                if (top_word) {
-                    if (w == NW - 1) {
-                        sD0 = D0;
-                        sHP = HP;
-                        sHN = HN;
-                    }
-                } else if ((uint32_t)w == t.wn) {
-                    sD0 = D0;
-                    sHP = HP;
-                    sHN = HN;
-                }
+        for (int c = 0; c < TEXT_CHUNK; ++c) {
+            const uint32_t idx = didx + c;
+            NX[c] = g.dwords[idx < g.last_dword ? idx : g.last_dword];
+        }
+        didx += TEXT_CHUNK;
+
+        bool done = false;
+        for (int gi = 0; gi < TEXT_CHUNK; ++gi, base += 8) {
+            const bool alive = packed ? (int32_t)deadf >= 0 : !t.stopped;
+            if (!__any(alive)) {
+                done = true;
+                break;
             }
-            if (exotic) {
-                for (uint32_t w = 0; w <= t.wn; ++w)
-                    my_pm[(4 * NW + w) * BLOCK] = 0;
+            const uint32_t syms = __builtin_amdgcn_alignbit(R[1], R[0], shift);
+#pragma unroll
+            for (int c = 0; c < TEXT_CHUNK; ++c)
+                R[c] = R[c + 1];
+
+            const bool fast = can_fast && !__any(alive && (syms & 0xccccccccu));
+            if (fast) {
+                if (!packed) {
+                    E = t.curr_ed + base;
+                    key = (t.min_ed << 17) | (0xffffu - t.min_pos);
+                    deadf = t.stopped ? 0x80000000u : 0u;
+                    packed = true;
+                }
+                if (rule0 == RULE_M256)
+                    group_fast<NW, BLOCK, RULE_M256>(lds_lane, syms, base, lsrep, t.exit_t, t.n_cols - base, rowmask, sgn, VP, VN, E,
+                                                     key, deadf);
+                else if (rule0 == RULE_M128)
+                    group_fast<NW, BLOCK, RULE_M128>(lds_lane, syms, base, lsrep, t.exit_t, t.n_cols - base, rowmask, sgn, VP, VN, E,
+                                                     key, deadf);
+                else
+                    group_fast<NW, BLOCK, RULE_M64>(lds_lane, syms, base, lsrep, t.exit_t, t.n_cols - base, rowmask, sgn, VP, VN, E,
+                                                    key, deadf);
+                continue;
             }
 
-            // ---- score bookkeeping (LevMyers256.hpp:174-234, LevMyers128.hpp:175-221,
-            // LevMyers64.cpp:328-366)
-            const uint32_t hnb = ((sb_hi ? (uint32_t)(sHN >> 32) : (uint32_t)sHN) >> sb_lo) & 1u;
-            const uint32_t hpb = ((sb_hi ? (uint32_t)(sHP >> 32) : (uint32_t)sHP) >> sb_lo) & 1u;
-            const uint32_t d0b = ((sb_hi ? (uint32_t)(sD0 >> 32) : (uint32_t)sD0) >> sb_lo) & 1u;
-            const bool act = !stopped && col <= t.n_cols;
-            const uint32_t ced = curr_ed + hpb - hnb;
-            const bool lt = ced < min_ed;
-            const bool eq = ced == min_ed;
-            const bool move = eq && (t.is256 ? (!d0b || c == t.last_sym) : (min_pos + 1 == col));
-            if (act) {
-                curr_ed = ced;
-                if (lt)
-                    min_ed = ced;
-                if (lt || move)
-                    min_pos = col;
-                // early exit on the iteration index j = col + wn
-                // (LevMyers256.hpp:232-233, LevMyers128.hpp:125, 219-220)
-                if (t.skewed && !hnb && ced + col > t.exit_t)
-                    stopped = true;
+            // ---- slow group: per-lane bookkeeping, any text symbol ----------------------------
+            if (packed) {
+                if (!t.stopped) {   // lanes that were finished when packing keep their values
+                    t.curr_ed = E - base;
+                    t.min_ed = key >> 17;
+                    t.min_pos = 0xffffu - (key & 0xffffu);
+                    t.stopped = (int32_t)deadf < 0;
+                }
+                packed = false;
+            }
+#pragma unroll 1
+            for (uint32_t u = 0; u < 8; ++u) {
+                const uint32_t col = base + u + 1;
+                const uint32_t c = (syms >> (4 * u)) & 15u;
+                const bool act = !t.stopped && col <= t.n_cols;
+                // a text symbol >= 4 matches only a read holding that very code, which real
+                // data never does (genome: 5/15, reads: 4/6); stay exact anyway
+                const bool exotic = act && c >= 4u && ((t.presence >> c) & 1u);
+                uint32_t eq[NW];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    uint32_t v = phantom_mask<NW>(t.m, w);
+                    if (c < 4u)
+                        v = pm_lds[(w * 4 + c) * BLOCK + tid];
+                    if (exotic) {
+                        const int32_t first = 32 * w - (int32_t)(32u * NW - t.m);
+                        for (int32_t b = 0; b < 32; ++b) {
+                            const int32_t i = first + b;
+                            if (i < 0 || i >= (int32_t)t.m)
+                                continue;
+                            const uint32_t rcode = t.rev ? rc_code(packed_symbol(my_codes, t.m - 1 - (uint32_t)i))
+                                                         : packed_symbol(my_codes, (uint32_t)i);
+                            v |= (uint32_t)(rcode == c) << b;
+                        }
+                    }
+                    eq[w] = v;
+                }
+                uint32_t hp, hn, d0;
+                column_core<NW>(eq, VP, VN, hp, hn, d0);
+
+                const uint32_t hnb = hn >> 31, hpb = hp >> 31, d0b = d0 >> 31;
+                const uint32_t ced = t.curr_ed + hpb - hnb;
+                const bool lt = ced < t.min_ed;
+                const bool tie = ced == t.min_ed;
+                const bool move = tie && (t.rule == RULE_M256 ? (!d0b || c == t.last_sym) : (t.min_pos + 1 == col));
+                if (act) {
+                    t.curr_ed = ced;
+                    if (lt)
+                        t.min_ed = ced;
+                    if (lt || move)
+                        t.min_pos = col;
+                    // early exit on the iteration index j = col + wn
+                    // (LevMyers256.hpp:232-233, LevMyers128.hpp:125, 219-220)
+                    if (t.rule != RULE_M64 && !hnb && ced + col > t.exit_t)
+                        t.stopped = true;
+                }
+                if (col >= t.n_cols)
+                    t.stopped = true;   // last column of this lane
             }
         }
+        if (done)
+            break;
+        // rotate the prefetched chunk in: R[0] already holds the funnel's low dword
+#pragma unroll
+        for (int c = 0; c < TEXT_CHUNK; ++c)
+            R[c + 1] = nibble_swap(NX[c]);
     }
 
+    if (packed && !t.stopped) {
+        t.min_ed = key >> 17;
+        t.min_pos = 0xffffu - (key & 0xffffu);
+    }
     if (valid) {
-        results[gid].edit_distance = min_ed;
-        results[gid].pos = min_ed > t.k ? 0u : min_pos;
+        results[gid].edit_distance = t.min_ed;
+        results[gid].pos = t.min_ed > t.k ? 0u : t.min_pos;
     }
 }
 
@@ -266,22 +440,30 @@ int launch_distance(wamd_ctx* ctx, const wamd_reads* r, const wamd_dist_task* d_
                     int last_symbol, wamd_dist_result* d_results, hipStream_t s)
 {
     WAMD_HIP(hipSetDevice(ctx->device));
+    if (n == 0)
+        return WAMD_OK;
     const GenomeView g = genome_view(ctx);
     const ReadsView rv = r->view();
     const uint32_t mt = ctx->max_text_len;
     uint32_t* f = ctx->d_flags;
-    switch (rv.words) {
-    case 1: return launch_one<1, 256>(g, rv, d_tasks, n, last_symbol, mt, d_results, f, s);
-    case 2: return launch_one<2, 256>(g, rv, d_tasks, n, last_symbol, mt, d_results, f, s);
-    case 3: return launch_one<3, 256>(g, rv, d_tasks, n, last_symbol, mt, d_results, f, s);
-    case 4: return launch_one<4, 256>(g, rv, d_tasks, n, last_symbol, mt, d_results, f, s);
-    default: break;
-    }
-    if (rv.words <= 8)
-        return launch_one<8, 64>(g, rv, d_tasks, n, last_symbol, mt, d_results, f, s);
-    if (rv.words <= 16)
-        return launch_one<16, 64>(g, rv, d_tasks, n, last_symbol, mt, d_results, f, s);
-    set_error("reads of %u words are not supported", rv.words);
+#define WAMD_DIST_CASE(NW, BLOCK) \
+    if (rv.words32 <= NW)         \
+        return launch_one<NW, BLOCK>(g, rv, d_tasks, n, last_symbol, mt, d_results, f, s);
+    WAMD_DIST_CASE(1, 256)
+    WAMD_DIST_CASE(2, 256)
+    WAMD_DIST_CASE(3, 256)
+    WAMD_DIST_CASE(4, 256)
+    WAMD_DIST_CASE(5, 256)
+    WAMD_DIST_CASE(6, 256)
+    WAMD_DIST_CASE(7, 256)
+    WAMD_DIST_CASE(8, 256)
+    WAMD_DIST_CASE(10, 64)
+    WAMD_DIST_CASE(12, 64)
+    WAMD_DIST_CASE(16, 64)
+    WAMD_DIST_CASE(24, 64)
+    WAMD_DIST_CASE(32, 64)
+#undef WAMD_DIST_CASE
+    set_error("reads of %u dwords are not supported", rv.words32);
     return WAMD_ERR_TOO_LONG;
 }
 

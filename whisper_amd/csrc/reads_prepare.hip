@@ -85,6 +85,42 @@ __global__ __launch_bounds__(256) void pattern_vectors_kernel(ReadsView rv, uint
         atomicOr(meta + (read * (uint64_t)rv.n_orient + slot), presence);
 }
 
+// one thread per (read, slot, dword) of the top-aligned 32-bit vectors
+__global__ __launch_bounds__(256) void pattern_vectors32_kernel(ReadsView rv, uint32_t* __restrict__ pm32)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t j = (uint32_t)(t % rv.words32);
+    const uint64_t rs = t / rv.words32;
+    const uint32_t slot = (uint32_t)(rs % rv.n_orient);
+    const uint32_t read = (uint32_t)(rs / rv.n_orient);
+    if (read >= rv.n)
+        return;
+    const bool rc = ((int32_t)slot == rv.slot_rc);
+    const uint32_t len = rv.lens[read];
+    const uint8_t* codes = rv.codes + rv.code_off[read];
+    const int32_t phantom = (int32_t)(32 * rv.words32 - len);   // rows below the read's first symbol
+    uint32_t row[4] = {0, 0, 0, 0};
+    for (int32_t b = 0; b < 32; ++b) {
+        const int32_t i = (int32_t)(32 * j) + b - phantom;
+        const uint32_t bit = 1u << b;
+        if (i < 0) {
+            // a phantom row matches every text symbol: D stays 0 down to the read's row 0
+            row[0] |= bit;
+            row[1] |= bit;
+            row[2] |= bit;
+            row[3] |= bit;
+        } else {
+            const uint32_t c = rc ? rc_code(packed_symbol(codes, len - 1 - (uint32_t)i))
+                                  : packed_symbol(codes, (uint32_t)i);
+            if (c < 4)
+                row[c] |= bit;
+        }
+    }
+    uint32_t* dst = pm32 + ((uint64_t)(read * (uint64_t)rv.n_orient + slot) * 4) * rv.words32 + j;
+    for (int c = 0; c < 4; ++c)
+        dst[(uint64_t)c * rv.words32] = row[c];
+}
+
 int launch_reads_prepare(wamd_ctx* ctx, wamd_reads* r, const uint8_t* d_raw,
                          const uint64_t* d_raw_off, hipStream_t s)
 {
@@ -104,6 +140,13 @@ int launch_reads_prepare(wamd_ctx* ctx, wamd_reads* r, const uint8_t* d_raw,
         const uint32_t blocks = (uint32_t)((threads + 255) / 256);
         hipLaunchKernelGGL(pattern_vectors_kernel, dim3(blocks), dim3(256), 0, s, rv, r->d_pm,
                            r->d_meta);
+        WAMD_HIP(hipGetLastError());
+    }
+    {
+        ReadsView rv = r->view();
+        const uint64_t threads = (uint64_t)r->n * rv.n_orient * rv.words32;
+        const uint32_t blocks = (uint32_t)((threads + 255) / 256);
+        hipLaunchKernelGGL(pattern_vectors32_kernel, dim3(blocks), dim3(256), 0, s, rv, r->d_pm32);
         WAMD_HIP(hipGetLastError());
     }
     return WAMD_OK;

@@ -102,9 +102,11 @@ wamd::ReadsView wamd_reads::view() const
     v.code_off = d_code_off;
     v.lens = d_lens;
     v.pm = d_pm;
+    v.pm32 = d_pm32;
     v.meta = d_meta;
     v.n = n;
     v.words = words;
+    v.words32 = words32;
     v.n_orient = (orientations == 3) ? 2 : 1;
     v.slot_direct = (orientations & 1) ? 0 : -1;
     v.slot_rc = (orientations & 2) ? ((orientations & 1) ? 1 : 0) : -1;
@@ -312,6 +314,7 @@ int wamd_reads_upload(wamd_ctx* ctx, const uint8_t* data, const uint64_t* offset
     r->orientations = orientations;
     r->max_len = max_len;
     r->words = max_len ? (max_len - 1) / 64 + 1 : 1;
+    r->words32 = max_len ? (max_len - 1) / 32 + 1 : 1;
     r->codes_bytes = acc;
     const uint32_t n_orient = orientations == 3 ? 2 : 1;
     int rc = WAMD_OK;
@@ -321,10 +324,12 @@ int wamd_reads_upload(wamd_ctx* ctx, const uint8_t* data, const uint64_t* offset
         hipError_t e;
         hipStream_t s = ctx->stream;
         const uint64_t pm_bytes = (uint64_t)n * n_orient * 4 * r->words * sizeof(uint64_t);
+        const uint64_t pm32_bytes = (uint64_t)n * n_orient * 4 * r->words32 * sizeof(uint32_t);
         if ((e = hipMalloc(&r->d_codes, acc + 64)) != hipSuccess ||
             (e = hipMalloc(&r->d_code_off, ((size_t)n + 1) * sizeof(uint64_t))) != hipSuccess ||
             (e = hipMalloc(&r->d_lens, ((size_t)n + 1) * sizeof(uint32_t))) != hipSuccess ||
             (e = hipMalloc(&r->d_pm, pm_bytes + 64)) != hipSuccess ||
+            (e = hipMalloc(&r->d_pm32, pm32_bytes + 64)) != hipSuccess ||
             (e = hipMalloc(&r->d_meta, ((size_t)n * n_orient + 1) * sizeof(uint32_t))) != hipSuccess ||
             (e = hipMalloc(&d_raw, raw_end + 64)) != hipSuccess ||
             (e = hipMalloc(&d_raw_off, ((size_t)n + 1) * sizeof(uint64_t))) != hipSuccess) {
@@ -374,6 +379,7 @@ int wamd_reads_free(wamd_reads* r)
     if (r->d_code_off) (void)hipFree(r->d_code_off);
     if (r->d_lens) (void)hipFree(r->d_lens);
     if (r->d_pm) (void)hipFree(r->d_pm);
+    if (r->d_pm32) (void)hipFree(r->d_pm32);
     if (r->d_meta) (void)hipFree(r->d_meta);
     delete r;
     return WAMD_OK;

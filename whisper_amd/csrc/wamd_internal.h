@@ -30,6 +30,10 @@ constexpr uint32_t RESULT_ERROR = 0xFFFFFFFFu;
 // pm    : pattern-match bit-vectors, rows for text symbols 0..3 only (a text symbol
 //         >= 4 can only match a read holding that same code, which `presence` tells):
 //         pm[((read * n_orient + slot) * 4 + c) * words + w]
+// pm32  : the same vectors as 32-bit dwords for the distance kernel, TOP-aligned: symbol
+//         len-1 of the read sits in bit 31 of dword words32-1, the unused low bits
+//         ("phantom rows" before the read's first symbol) are 1 in every row:
+//         pm32[((read * n_orient + slot) * 4 + c) * words32 + j]
 // meta  : per (read, slot): bits 0..15 presence of each code in the read,
 //         bits 16..19 last symbol in that orientation (LevMyers64.cpp:182/192)
 struct ReadsView {
@@ -37,9 +41,11 @@ struct ReadsView {
     const uint64_t* code_off;
     const uint32_t* lens;
     const uint64_t* pm;
+    const uint32_t* pm32;
     const uint32_t* meta;
     uint32_t n;
     uint32_t words;        // 64-bit words per bit-vector in this batch (max over reads)
+    uint32_t words32;      // dwords per top-aligned bit-vector (ceil(max_len / 32))
     uint32_t n_orient;     // 1 or 2 slots per read
     int32_t slot_direct;   // slot index of the direct orientation, -1 if absent
     int32_t slot_rc;
@@ -83,6 +89,8 @@ struct wamd_reads {
     uint64_t* d_code_off;
     uint32_t* d_lens;
     uint64_t* d_pm;
+    uint32_t* d_pm32;
+    uint32_t words32;
     uint32_t* d_meta;
     uint64_t codes_bytes;
     wamd::ReadsView view() const;
@@ -143,7 +151,7 @@ __device__ __forceinline__ uint32_t nibble_swap(uint32_t d)
 __device__ __forceinline__ uint32_t load_genome_dword(const GenomeView& g, uint32_t idx)
 {
     idx = idx < g.last_dword ? idx : g.last_dword;
-    return nibble_swap(__builtin_nontemporal_load(g.dwords + idx));
+    return nibble_swap(g.dwords[idx]);
 }
 
 // one symbol of a packed sequence (GET_CHAR_FROM_GENOME / _PATTERN, LevMyers64.cpp:22-26)
