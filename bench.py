@@ -31,10 +31,13 @@ from whisper_amd import api, gather, synth  # noqa: E402
 
 M, K_ERR = 150, 12
 W = M + 2 * K_ERR
-# algorithmic VALU work of one S1 task = n_cols x (words x 40 + 8) 32-bit lane-ops
-WORDS = (M - 1) // 64 + 1
-N_COLS = W + 1
-LANE_OPS_PER_TASK = N_COLS * (WORDS * 40 + 8)
+# Algorithmic VALU work of one S1 task (DESIGN.md "distance kernel"): per text column the
+# recurrence takes 10 instructions per 32-bit dword of the bit-vector (and, add-with-carry,
+# 3 x bitop3, or, 2 x and, 2 x funnel shift) and the score / minimum / tie-break / early-exit
+# bookkeeping 20, over the W + 1 - wn columns LevMyers256 iterates (LevMyers256.hpp:138).
+DWORDS = (M - 1) // 32 + 1
+N_COLS = W + 1 - (M - 1) // 64
+LANE_OPS_PER_TASK = N_COLS * (DWORDS * 10 + 20)
 # algorithmic bytes per task: 2-bit read + 2-bit window + 16 B task + 4 B result
 BYTES_PER_TASK = (M + 3) // 4 + (W + 3 + 3) // 4 + 16 + 4
 # MI355X: 256 CUs x 4 SIMD x 32 lanes/clk x 2.4 GHz (MI355X_MICROARCH.md: SIMD-32, 2400 MHz)
@@ -49,12 +52,12 @@ def env_int(name, default):
         return default
 
 
-def build_workload(device, n_tasks, genome_symbols, seed):
+def build_workload(device, n_tasks, genome_symbols, seed, true_frac=0.5):
     """Genome, reads and tasks of shape S1, generated on the GPU; returns host copies of
     what the upload entry points take plus the device task array."""
     codes = synth.make_genome(genome_symbols, seed=0xC0FFEE, device=device)
     packed = synth.pack_nibbles(codes)
-    rd = synth.make_reads(codes, n_tasks, M, K_ERR, seed, chunk=1 << 17)
+    rd = synth.make_reads(codes, n_tasks, M, K_ERR, seed, true_frac=true_frac, chunk=1 << 17)
     blob, off, lens = synth.pack_reads(rd["codes"], 0)
     tasks = synth.distance_tasks(rd, M, K_ERR)
     ref_size = codes.numel()
@@ -105,6 +108,8 @@ def main():
     ap.add_argument("--genome-symbols", type=int, default=1 << 28)
     ap.add_argument("--cpu-sample", type=int, default=1 << 24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--true-frac", type=float, default=0.5,
+                    help="fraction of candidates planted at their locus (S1 = 0.5; other values are experiments)")
     args = ap.parse_args()
 
     rank = env_int("RANK", 0)
@@ -124,7 +129,7 @@ def main():
 
     n = args.tasks
     packed, ref_size, blob, off, lens, tasks = build_workload(device, n, args.genome_symbols,
-                                                              seed=1234 + rank)
+                                                              seed=1234 + rank, true_frac=args.true_frac)
     ctx = api.Context(packed, ref_size=ref_size, cur_offset=0, device=local)   # genome borrowed on device
     ctx.set_max_text_len(M + 2 * K_ERR + 2)   # mapping_core.cpp:158-160
     reads = ctx.upload_reads(blob, off, lens, api.READS_NIBBLE, orientations=3)
@@ -210,8 +215,8 @@ def main():
             "config": {
                 "workload": "S1: LevMyers256 distance verification, 150 bp reads, k = 12, W = 174 "
                             "(sensitive stages of BASELINE configs[1]); %d candidates per GPU per step, "
-                            "%d-symbol random genome with N runs, 50%% true candidates with 0..15 edits, "
-                            "50%% reverse strand" % (n, args.genome_symbols),
+                            "%d-symbol random genome with N runs, %d%% true candidates with 0..15 edits, "
+                            "50%% reverse strand" % (n, args.genome_symbols, round(100 * args.true_frac)),
                 "candidates_per_gpu": n,
                 "accepted_fraction": accepted / n,
                 "parallelism": "bins sharded over %d GPU(s), no data-path collective; "
@@ -222,7 +227,7 @@ def main():
         a_ops = n * LANE_OPS_PER_TASK / (kernel_ms * 1e-3)
         out["roofline"] = {
             "bound": "valu",
-            "kernel": "myers_distance_kernel<3,256>",
+            "kernel": "myers_distance_kernel<%d,256>" % DWORDS,
             "achieved": a_ops / 1e12,
             "peak": PEAK_VALU_LANEOPS / 1e12,
             "unit": "T lane-op/s (32-bit integer VALU)",

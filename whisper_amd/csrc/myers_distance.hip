@@ -49,34 +49,114 @@ __device__ __forceinline__ uint32_t in_vgpr(uint32_t x)
     return r;
 }
 
+// ---- hand-picked VALU forms --------------------------------------------------------------
+// Measured on gfx950 (scripts/ubench/valu_rates.hip, cycles per wave-instruction at 4 waves
+// per SIMD): and/or/xor/not/add/sub/lshr/ashr with VGPR or literal operands 2.6; v_bitop3
+// 3.2; every other VOP3 form, min/max, left shifts, carry adds and any VOP2 with an SGPR
+// operand 4.3.  The compiler prices them all alike and fuses into v_bitop3 / v_or3 / v_add3
+// wherever it can, so the hot expressions are spelled as the instructions they should be.
+#define WAMD_VOP2(name, insn)                                                     \
+    __device__ __forceinline__ uint32_t name(uint32_t a, uint32_t b)              \
+    {                                                                             \
+        uint32_t r;                                                               \
+        asm(insn " %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));                       \
+        return r;                                                                 \
+    }
+WAMD_VOP2(v_and, "v_and_b32")
+WAMD_VOP2(v_or, "v_or_b32")
+WAMD_VOP2(v_add, "v_add_u32")
+WAMD_VOP2(v_sub, "v_sub_u32")
+WAMD_VOP2(v_min, "v_min_u32")
+#undef WAMD_VOP2
+__device__ __forceinline__ uint32_t v_not(uint32_t a)
+{
+    uint32_t r;
+    asm("v_not_b32 %0, %1" : "=v"(r) : "v"(a));
+    return r;
+}
+template <int SH>
+__device__ __forceinline__ uint32_t v_lshr(uint32_t a)
+{
+    static_assert(SH >= 0 && SH < 32, "shift out of range");
+    if (SH == 0)
+        return a;
+    uint32_t r;
+    asm("v_lshrrev_b32 %0, %1, %2" : "=v"(r) : "n"(SH), "v"(a));
+    return r;
+}
+template <uint32_t LIT>
+__device__ __forceinline__ uint32_t v_and_lit(uint32_t a)
+{
+    uint32_t r;
+    asm("v_and_b32 %0, %1, %2" : "=v"(r) : "n"(LIT), "v"(a));
+    return r;
+}
+template <uint32_t LIT>
+__device__ __forceinline__ uint32_t v_add_lit(uint32_t a)
+{
+    uint32_t r;
+    asm("v_add_u32 %0, %1, %2" : "=v"(r) : "n"(LIT), "v"(a));
+    return r;
+}
+// v_bitop3_b32: result bit = TT[(a << 2) | (b << 1) | c]; with a = 0xf0, b = 0xcc, c = 0xaa the
+// table of an expression is the expression evaluated on those three constants.
+template <int TT>
+__device__ __forceinline__ uint32_t v_bitop3(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:%4" : "=v"(r) : "v"(a), "v"(b), "v"(c), "n"(TT));
+    return r;
+}
+constexpr int TT_XOR_OR = (0xf0 ^ 0xcc) | 0xaa;            // (a ^ b) | c
+constexpr int TT_OR_NOR = 0xf0 | (~(0xcc | 0xaa) & 0xff);  // a | ~(b | c)
+constexpr int TT_OR_AND = 0xf0 | (0xcc & 0xaa);            // a | (b & c)
+constexpr int TT_AND3 = 0xf0 & 0xcc & 0xaa;                // a & b & c
+
 // One text column over the whole NW-dword vector (LevMyers64.cpp:312-325 as a single
 // wide word).  Returns HP, HN and D0 of the top dword (score row = bit 31).
 template <int NW>
 __device__ __forceinline__ void column_core(const uint32_t (&eq)[NW], uint32_t (&VP)[NW], uint32_t (&VN)[NW],
                                             uint32_t& hp_top, uint32_t& hn_top, uint32_t& d0_top)
 {
-    uint32_t carry = 0, hp_prev = 0, hn_prev = 0;
+    // stage-major order: the dwords of one stage are independent, so no instruction has to
+    // wait for its neighbour's result (the compiler pads a dependent pair of asm ops)
+    uint32_t x[NW], d0[NW], hp[NW], hn[NW], hps[NW], hns[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+        x[w] = v_and(eq[w], VP[w]);
+    uint32_t carry = 0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
-        const uint32_t vp = VP[w], vn = VN[w];
         uint32_t cout;
-        const uint32_t sum = __builtin_addc(eq[w] & vp, vp, carry, &cout);
+        x[w] = __builtin_addc(x[w], VP[w], carry, &cout);
         carry = cout;
-        const uint32_t d0 = (sum ^ vp) | eq[w] | vn;
-        const uint32_t hp = vn | ~(d0 | vp);
-        const uint32_t hn = d0 & vp;
-        const uint32_t hps = w ? __builtin_amdgcn_alignbit(hp, hp_prev, 31) : hp + hp;
-        const uint32_t hns = w ? __builtin_amdgcn_alignbit(hn, hn_prev, 31) : hn + hn;
-        VP[w] = hns | ~(d0 | hps);
-        VN[w] = d0 & hps;
-        hp_prev = hp;
-        hn_prev = hn;
-        if (w == NW - 1) {
-            hp_top = hp;
-            hn_top = hn;
-            d0_top = d0;
-        }
     }
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+        x[w] = v_bitop3<TT_XOR_OR>(x[w], VP[w], eq[w]);
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+        d0[w] = v_or(x[w], VN[w]);
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+        hp[w] = v_bitop3<TT_OR_NOR>(VN[w], d0[w], VP[w]);
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+        hn[w] = v_and(d0[w], VP[w]);
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        hps[w] = w ? __builtin_amdgcn_alignbit(hp[w], hp[w ? w - 1 : 0], 31) : v_add(hp[w], hp[w]);
+        hns[w] = w ? __builtin_amdgcn_alignbit(hn[w], hn[w ? w - 1 : 0], 31) : v_add(hn[w], hn[w]);
+    }
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+        VP[w] = v_bitop3<TT_OR_NOR>(hns[w], d0[w], hps[w]);
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+        VN[w] = v_and(d0[w], hps[w]);
+    hp_top = hp[NW - 1];
+    hn_top = hn[NW - 1];
+    d0_top = d0[NW - 1];
 }
 
 // phantom-row mask of dword j for a read of m symbols in an NW-dword vector
@@ -107,55 +187,134 @@ struct Lane {
 //           exactly when t = 0 (later column = smaller low half)
 //   deadf : bit 31 set once the lane has left the loop (early exit, or past its last column:
 //           n_left = n_cols - base); it lifts cand above every key
-template <int NW, int BLOCK, int RULE>
-__device__ __forceinline__ void group_fast(const char* lds_lane, uint32_t syms, uint32_t base, uint32_t lsrep,
-                                           uint32_t exit_t, uint32_t n_left, uint32_t rowmask, uint32_t sgn,
-                                           uint32_t (&VP)[NW], uint32_t (&VN)[NW], uint32_t& E, uint32_t& key,
-                                           uint32_t& deadf)
+struct FastGroup {
+    uint32_t lane_addr, syms, symsA, nz, nzA, gconst, nbase;   // per group
+    uint32_t exit_t, n_left, rowmask, sgn, bit16;              // per lane / constants held in VGPRs
+};
+
+// LDS reads of the pattern-match vectors for symbol U of the group
+template <int NW, int BLOCK, int U>
+__device__ __forceinline__ void load_eq(const FastGroup& f, uint32_t (&eq)[NW])
 {
+    typedef const __attribute__((address_space(3))) uint32_t* lds_ptr;
     constexpr int RSH = BLOCK == 256 ? 10 : (BLOCK == 128 ? 9 : 8);   // log2(row stride in bytes)
-    const uint32_t symsA = syms << 12;
-    uint32_t nz = 0, nzA = 0;
+    // symbol U moved to the row-stride position of the LDS byte address
+    const uint32_t srow = U < 5 ? v_lshr<(U < 5 ? 12 + 4 * U - RSH : 0)>(f.symsA) : v_lshr<(U < 5 ? 0 : 4 * U - RSH)>(f.syms);
+    const uint32_t addr = v_bitop3<TT_OR_AND>(f.lane_addr, srow, f.rowmask);
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+        eq[w] = *(lds_ptr)(uintptr_t)(addr + (uint32_t)w * (4u * BLOCK * 4u));
+}
+
+template <int NW, int BLOCK, int RULE, bool ENDS, int U>
+__device__ __forceinline__ void fast_column(const FastGroup& f, uint32_t (&eq)[NW], uint32_t (&VP)[NW],
+                                            uint32_t (&VN)[NW], uint32_t& E, uint32_t& key, uint32_t& deadf)
+{
+    // the next column's vectors are requested before this column's arithmetic
+    uint32_t eq_next[NW];
+    if (U < 7)
+        load_eq<NW, BLOCK, (U < 7 ? U + 1 : 0)>(f, eq_next);
+    uint32_t hp, hn, d0;
+    column_core<NW>(eq, VP, VN, hp, hn, d0);
+    if (U < 7) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+            eq[w] = eq_next[w];
+    }
+
+    const uint32_t nhn = v_not(hn);
+    E = v_add(E, v_lshr<31>(hp));
+    E = v_add(E, v_lshr<31>(nhn));   // + 1 for the column, - 1 when HN is set
+    uint32_t cand = v_add_lit<0u - ((uint32_t)(U + 1) << 17) - (uint32_t)(U + 1)>((E << 17) + f.gconst);
+    if (RULE == RULE_M256) {
+        // a tie moves min_pos unless D0 is set and the text symbol differs from last_symbol
+        const uint32_t nzs = U < 4 ? v_lshr<(U < 4 ? 4 * U : 0)>(f.nzA) : v_lshr<(U < 4 ? 0 : 4 * U - 16)>(f.nz);
+        cand = v_or(cand, v_bitop3<TT_AND3>(v_lshr<15>(d0), nzs, f.bit16));
+    } else {
+        // a tie moves min_pos only from the previous column (LevMyers128.hpp:205,
+        // LevMyers64.cpp:349): key's low half is 0xffff - min_pos, that column's 0x10000 - col
+        const uint32_t x = v_and_lit<0xffffu>(key ^ v_add_lit<0x10000u - (uint32_t)(U + 1)>(f.nbase));
+        cand = v_or(cand, v_and_lit<0x10000u>(v_add_lit<0xffffu>(x)));
+    }
+    if (ENDS)   // negative past the lane's last column
+        deadf = v_or(deadf, v_add_lit<0u - (uint32_t)(U + 1)>(f.n_left));
+    cand = v_bitop3<TT_OR_AND>(cand, deadf, f.sgn);
+    key = v_and_lit<~0x10000u>(v_min(key, cand));
+    if (RULE != RULE_M64)   // ced + col > exit_t and HN clear (LevMyers256.hpp:232-233)
+        deadf = v_bitop3<TT_OR_AND>(deadf, v_sub(f.exit_t, E), nhn);
+}
+
+template <int NW, int BLOCK, int RULE, bool ENDS>
+__device__ __forceinline__ void group_fast(uint32_t lane_addr, uint32_t syms, uint32_t base, uint32_t lsrep,
+                                           uint32_t exit_t, uint32_t n_left, uint32_t rowmask, uint32_t sgn,
+                                           uint32_t bit16, uint32_t (&VP)[NW], uint32_t (&VN)[NW], uint32_t& E,
+                                           uint32_t& key, uint32_t& deadf)
+{
+    FastGroup f;
+    f.lane_addr = lane_addr;
+    f.syms = syms;
+    f.symsA = syms << 12;
+    f.nz = f.nzA = 0;
     if (RULE == RULE_M256) {
         // bit 4u = (text symbol u != last_symbol), LevMyers256.hpp:191-196
         uint32_t t = syms ^ lsrep;
         t |= t >> 1;
         t |= t >> 2;
-        nz = t & 0x11111111u;
-        nzA = nz << 16;
+        f.nz = t & 0x11111111u;
+        f.nzA = f.nz << 16;
     }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        // symbol u, shifted to the row-stride position of the LDS byte address
-        const uint32_t srow = u < 5 ? symsA >> (12 + 4 * u - RSH) : syms >> (4 * u - RSH);
-        const char* rowp = lds_lane + (srow & rowmask);
-        uint32_t eq[NW];
-#pragma unroll
-        for (int w = 0; w < NW; ++w)
-            eq[w] = *reinterpret_cast<const uint32_t*>(rowp + w * (4 * BLOCK * 4));
-        uint32_t hp, hn, d0;
-        column_core<NW>(eq, VP, VN, hp, hn, d0);
+    // cand = (ced << 17) + 0xffff - col with ced = E - col and col = base + u + 1
+    //      = (E << 17) + gconst - ((u + 1) << 17) - (u + 1)
+    f.gconst = in_vgpr((0u - (base << 17)) + (0xffffu - base));
+    f.nbase = in_vgpr(0u - base);
+    f.exit_t = exit_t;
+    f.n_left = n_left;
+    f.rowmask = rowmask;
+    f.sgn = sgn;
+    f.bit16 = bit16;
+    uint32_t eq[NW];
+    load_eq<NW, BLOCK, 0>(f, eq);
+    fast_column<NW, BLOCK, RULE, ENDS, 0>(f, eq, VP, VN, E, key, deadf);
+    fast_column<NW, BLOCK, RULE, ENDS, 1>(f, eq, VP, VN, E, key, deadf);
+    fast_column<NW, BLOCK, RULE, ENDS, 2>(f, eq, VP, VN, E, key, deadf);
+    fast_column<NW, BLOCK, RULE, ENDS, 3>(f, eq, VP, VN, E, key, deadf);
+    fast_column<NW, BLOCK, RULE, ENDS, 4>(f, eq, VP, VN, E, key, deadf);
+    fast_column<NW, BLOCK, RULE, ENDS, 5>(f, eq, VP, VN, E, key, deadf);
+    fast_column<NW, BLOCK, RULE, ENDS, 6>(f, eq, VP, VN, E, key, deadf);
+    fast_column<NW, BLOCK, RULE, ENDS, 7>(f, eq, VP, VN, E, key, deadf);
+}
 
-        const uint32_t col = base + u + 1;
-        const uint32_t nhn = ~hn;
-        E += hp >> 31;
-        E += nhn >> 31;   // + 1 for the column, - 1 when HN is set
-        uint32_t cand = (E << 17) + ((0u - (col << 17)) + (0xffffu - col));
-        if (RULE == RULE_M256) {
-            // a tie moves min_pos unless D0 is set and the text symbol differs from last_symbol
-            const uint32_t nzs = u < 4 ? nzA >> (4 * u) : nz >> (4 * u - 16);
-            cand |= (d0 >> 15) & nzs & 0x10000u;
-        } else {
-            // a tie moves min_pos only from the previous column (LevMyers128.hpp:205, LevMyers64.cpp:349)
-            const uint32_t x = (key ^ (0x10000u - col)) & 0xffffu;
-            cand |= (x + 0xffffu) & 0x10000u;
-        }
-        deadf |= n_left - (uint32_t)(u + 1);   // negative past the lane's last column
-        cand |= deadf & sgn;
-        key = min(key, cand) & ~0x10000u;
-        if (RULE != RULE_M64)
-            deadf |= (exit_t - E) & nhn;   // ced + col > exit_t and HN clear (LevMyers256.hpp:232-233)
-    }
+// What one task asks for, derived exactly as the reference's caller and loop do.
+__device__ __forceinline__ uint32_t decode_task(const wamd_dist_task& task, const ReadsView& rv, const GenomeView& g,
+                                                uint32_t max_text_len, uint32_t max_m, Lane& t)
+{
+    const uint32_t W = task.max_distance_in_ref;
+    t.k = task.max_ed;
+    t.rev = task.flags & WAMD_TASK_FLAG_REV_COMP;
+    if (task.read_idx >= rv.n)
+        return FLAG_READ_IDX;
+    if ((t.rev ? rv.slot_rc : rv.slot_direct) < 0)
+        return FLAG_ORIENT;
+    if (W == 0 || W > max_text_len)
+        return FLAG_TEXT_LEN;   // LevMyers64.cpp:244-252
+    t.m = rv.lens[task.read_idx];
+    uint32_t variant = task.variant;
+    if (variant == WAMD_VARIANT_AUTO)   // mapping_core_sa.cpp:207-210
+        variant = t.m < 128 ? WAMD_VARIANT_M128 : (t.m < 256 ? WAMD_VARIANT_M256 : WAMD_VARIANT_M64);
+    t.wn = (t.m - 1) / 64;   // the reference's 64-bit word of the score bit
+    if (variant > WAMD_VARIANT_M256 || (variant == WAMD_VARIANT_M128 && t.m > 128) ||
+        (variant == WAMD_VARIANT_M256 && t.m > 256) || t.m > max_m)
+        return FLAG_VARIANT;
+    t.rule = variant == WAMD_VARIANT_M64 ? RULE_M64 : (variant == WAMD_VARIANT_M256 ? RULE_M256 : RULE_M128);
+    // skewed variants iterate j = 1..W+1 and the score lane runs wn columns behind
+    // (LevMyers256.hpp:138,180); M64 iterates j = 1..W (LevMyers64.cpp:257)
+    t.n_cols = t.rule != RULE_M64 ? (W + 1 - t.wn) : W;
+    if (t.rule != RULE_M64 && W + 1 < t.wn)
+        t.n_cols = 0;
+    t.exit_t = W + 1 - t.wn + t.k;
+    if ((uint64_t)task.ref_pos + t.n_cols > g.n_symbols)
+        return FLAG_RANGE;
+    return 0;
 }
 
 template <int NW, int BLOCK>
@@ -172,43 +331,12 @@ __global__ __launch_bounds__(BLOCK) void myers_distance_kernel(
     bool valid = gid < n;
 
     Lane t{};
-    uint32_t err = 0;
     uint32_t read_idx = 0, ref_pos = 0;
     if (valid) {
         const wamd_dist_task task = tasks[gid];
+        const uint32_t err = decode_task(task, rv, g, max_text_len, 32u * NW, t);
         read_idx = task.read_idx;
-        const uint32_t W = task.max_distance_in_ref;
-        t.k = task.max_ed;
         ref_pos = task.ref_pos;
-        t.rev = task.flags & WAMD_TASK_FLAG_REV_COMP;
-        if (read_idx >= rv.n) {
-            err = FLAG_READ_IDX;
-        } else if ((t.rev ? rv.slot_rc : rv.slot_direct) < 0) {
-            err = FLAG_ORIENT;
-        } else if (W == 0 || W > max_text_len) {
-            err = FLAG_TEXT_LEN;   // LevMyers64.cpp:244-252
-        } else {
-            t.m = rv.lens[read_idx];
-            uint32_t variant = task.variant;
-            if (variant == WAMD_VARIANT_AUTO)   // mapping_core_sa.cpp:207-210
-                variant = t.m < 128 ? WAMD_VARIANT_M128 : (t.m < 256 ? WAMD_VARIANT_M256 : WAMD_VARIANT_M64);
-            t.wn = (t.m - 1) / 64;   // the reference's 64-bit word of the score bit
-            if (variant > WAMD_VARIANT_M256 || (variant == WAMD_VARIANT_M128 && t.m > 128) ||
-                (variant == WAMD_VARIANT_M256 && t.m > 256) || t.m > 32u * NW) {
-                err = FLAG_VARIANT;
-            } else {
-                t.rule = variant == WAMD_VARIANT_M64 ? RULE_M64
-                                                     : (variant == WAMD_VARIANT_M256 ? RULE_M256 : RULE_M128);
-                // skewed variants iterate j = 1..W+1 and the score lane runs wn columns
-                // behind (LevMyers256.hpp:138,180); M64 iterates j = 1..W (LevMyers64.cpp:257)
-                t.n_cols = t.rule != RULE_M64 ? (W + 1 - t.wn) : W;
-                if (t.rule != RULE_M64 && W + 1 < t.wn)
-                    t.n_cols = 0;
-                t.exit_t = W + 1 - t.wn + t.k;
-                if ((uint64_t)ref_pos + t.n_cols > g.n_symbols)
-                    err = FLAG_RANGE;
-            }
-        }
         if (err) {
             raise_flag(flags, err);
             results[gid].edit_distance = RESULT_ERROR;
@@ -288,11 +416,18 @@ __global__ __launch_bounds__(BLOCK) void myers_distance_kernel(
     const uint32_t lsrep = t.last_sym * 0x11111111u;
     const uint32_t rowmask = in_vgpr(3u << (BLOCK == 256 ? 10 : (BLOCK == 128 ? 9 : 8)));
     const uint32_t sgn = in_vgpr(0x80000000u);
-    const char* lds_lane = reinterpret_cast<const char*>(pm_lds) + tid * 4;
+    const uint32_t bit16 = in_vgpr(0x10000u);
+    // LDS byte address of this lane's slot in row A of dword 0
+    const uint32_t lane_addr =
+        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)pm_lds + tid * 4u;
     const uint8_t* my_codes = rv.codes + rv.code_off[read_idx];
 
     // ---- text stream: R = nibble-swapped dwords of the current chunk (+1 for the funnel),
     // NX = raw dwords of the next one, already in flight
+    bool packed = false;   // wave-uniform: which bookkeeping form is current
+    uint32_t E = 0, key = 0, deadf = 0;
+    uint32_t base = 0;     // columns done (wave-uniform)
+
     const uint32_t shift = (ref_pos & 7u) * 4u;
     uint32_t didx = ref_pos >> 3;
     uint32_t R[TEXT_CHUNK + 1], NX[TEXT_CHUNK];
@@ -300,10 +435,6 @@ __global__ __launch_bounds__(BLOCK) void myers_distance_kernel(
     for (int c = 0; c <= TEXT_CHUNK; ++c)
         R[c] = load_genome_dword(g, didx + c);
     didx += TEXT_CHUNK + 1;
-
-    bool packed = false;   // wave-uniform: which bookkeeping form is current
-    uint32_t E = 0, key = 0, deadf = 0;
-    uint32_t base = 0;
 
     for (;;) {
         // next chunk's loads go out before this chunk's columns
@@ -334,15 +465,28 @@ __global__ __launch_bounds__(BLOCK) void myers_distance_kernel(
                     deadf = t.stopped ? 0x80000000u : 0u;
                     packed = true;
                 }
-                if (rule0 == RULE_M256)
-                    group_fast<NW, BLOCK, RULE_M256>(lds_lane, syms, base, lsrep, t.exit_t, t.n_cols - base, rowmask, sgn, VP, VN, E,
-                                                     key, deadf);
-                else if (rule0 == RULE_M128)
-                    group_fast<NW, BLOCK, RULE_M128>(lds_lane, syms, base, lsrep, t.exit_t, t.n_cols - base, rowmask, sgn, VP, VN, E,
-                                                     key, deadf);
-                else
-                    group_fast<NW, BLOCK, RULE_M64>(lds_lane, syms, base, lsrep, t.exit_t, t.n_cols - base, rowmask, sgn, VP, VN, E,
-                                                    key, deadf);
+                const uint32_t n_left = t.n_cols - base;
+                const bool ends = __any(alive && n_left < 8u);
+#define WAMD_GROUP(RULE, ENDS)                                                                               \
+    group_fast<NW, BLOCK, RULE, ENDS>(lane_addr, syms, base, lsrep, t.exit_t, n_left, rowmask, sgn, bit16, VP, VN, \
+                                      E, key, deadf)
+                if (rule0 == RULE_M256) {
+                    if (ends)
+                        WAMD_GROUP(RULE_M256, true);
+                    else
+                        WAMD_GROUP(RULE_M256, false);
+                } else if (rule0 == RULE_M128) {
+                    if (ends)
+                        WAMD_GROUP(RULE_M128, true);
+                    else
+                        WAMD_GROUP(RULE_M128, false);
+                } else {
+                    if (ends)
+                        WAMD_GROUP(RULE_M64, true);
+                    else
+                        WAMD_GROUP(RULE_M64, false);
+                }
+#undef WAMD_GROUP
                 continue;
             }
 
@@ -414,7 +558,7 @@ __global__ __launch_bounds__(BLOCK) void myers_distance_kernel(
             R[c + 1] = nibble_swap(NX[c]);
     }
 
-    if (packed && !t.stopped) {
+    if (packed && !t.stopped) {   // t.stopped: as it was when the state was packed
         t.min_ed = key >> 17;
         t.min_pos = 0xffffu - (key & 0xffffu);
     }
