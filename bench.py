@@ -99,6 +99,94 @@ def cpu_baseline(packed_host, ref_size, blob, off, lens, tasks, sample, threads)
                        % (len(t), threads, dt)), np.concatenate(parts)
 
 
+def run_extras(ctx, device, genome_symbols, stream, n_small):
+    """Secondary shapes of SURVEY 8d on the same resident genome: one line per kernel family,
+    timed with HIP events on the context's stream (3 launches after one warm-up)."""
+    codes = synth.make_genome(genome_symbols, seed=0xC0FFEE, device=device)
+    out = {}
+
+    def timed(fn, reps=3):
+        fn()
+        ctx.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in evs:
+            a.record(stream)
+            fn()
+            b.record(stream)
+        ctx.synchronize()
+        f = ctx.take_flags()
+        if f:
+            raise SystemExit("device error flags 0x%x in extras" % f)
+        return float(np.mean([a.elapsed_time(b) for a, b in evs]))
+
+    def host(rd_codes, enc):
+        blob, off, lens = synth.pack_reads(rd_codes, enc)
+        return blob.cpu().numpy(), off.cpu().numpy().astype(np.uint64), lens.cpu().numpy().astype(np.uint32)
+
+    # S2: LevDiag, m = 150, k = 5, anchor = segment 2 of stage 5 (mapping_core_sa.cpp:239)
+    n = n_small
+    fl, fr = synth.stage_segments(150, 5)[2]
+    rd = synth.make_reads(codes, n, 150, 5, 77, rc_frac=0.0, protect=(fl, fr), chunk=1 << 17)
+    reads = ctx.upload_reads(*host(rd["codes"], 0), api.READS_NIBBLE, orientations=1)
+    t = synth.levdiag_tasks(rd, 5, fl, fr)
+    d_t = torch.from_numpy(t.view(np.uint8)).to(device)
+    d_r = torch.zeros(n, dtype=torch.int32, device=device)
+    ms = timed(lambda: ctx.lev_diag_dev(reads, d_t, n, d_r))
+    acc = float((d_r.cpu().numpy().view(np.uint32) <= 5).mean())
+    out["S2_levdiag"] = {"shape": "CEditDist::LevDiag m=150 k=5 anchor [%d,%d)" % (fl, fr), "tasks": n,
+                         "kernel_ms": ms, "candidates_per_s": n / ms * 1e3, "accepted_fraction": acc}
+    reads.free()
+    del d_t, d_r
+
+    # S5: LevMyers256 distance, m = 250, k = 17, W = 284 (8 dwords per vector)
+    rd = synth.make_reads(codes, n, 250, 17, 78, chunk=1 << 16)
+    reads = ctx.upload_reads(*host(rd["codes"], 0), api.READS_NIBBLE, orientations=3)
+    t = synth.distance_tasks(rd, 250, 17)
+    d_t = torch.from_numpy(t.view(np.uint8)).to(device)
+    d_r = torch.zeros(n * 2, dtype=torch.int32, device=device)
+    ctx.set_max_text_len(16384)
+    ms = timed(lambda: ctx.dynamic_programming_dev(reads, d_t, n, d_r, last_symbol=-1))
+    out["S5_distance_250bp"] = {"shape": "LevMyers256 distance m=250 k=17 W=284", "tasks": n, "kernel_ms": ms,
+                                "candidates_per_s": n / ms * 1e3}
+    reads.free()
+    del d_t, d_r
+
+    # S4: fill_cigar_with_lev: distance + traceback + ext-CIGAR + refinement, m = 150, W = 177
+    na = n // 4
+    rd = synth.make_reads(codes, na, 150, 10, 79, true_frac=1.0, chunk=1 << 16)
+    reads = ctx.upload_reads(*host(rd["codes"], 1), api.READS_ASCII, orientations=3)
+    t = synth.distance_tasks(rd, 150, 13, W=177)
+    t["ref_pos"] = (rd["p"] - 13).cpu().numpy().astype(np.uint32)
+    d_t = torch.from_numpy(t.view(np.uint8)).to(device)
+    stride = 512
+    d_r = torch.zeros(na * api.ALIGN_RESULT.itemsize, dtype=torch.uint8, device=device)
+    d_c = torch.zeros(na * stride, dtype=torch.uint8, device=device)
+    wsb = ctx.align_workspace_bytes(reads, na)
+    d_w = torch.zeros(wsb, dtype=torch.uint8, device=device)
+    ms = timed(lambda: ctx.align_dev(reads, d_t, na, d_r, d_c, stride, d_w, wsb, last_symbol=0, refine=1))
+    res = d_r.cpu().numpy().view(api.ALIGN_RESULT)
+    out["S4_align"] = {"shape": "dynamicProgramming + getExtCigar + refine_ext_cigar m=150 k=13 W=177", "tasks": na,
+                       "total_ms": ms, "alignments_per_s": na / ms * 1e3, "ok_fraction": float(res["ok"].mean()),
+                       "workspace_bytes": wsb}
+    reads.free()
+    del d_t, d_r, d_c, d_w
+
+    # S8: CIndelMatching::Match, max_indel = 50
+    rc, fields = synth.indel_match_workload(codes, na, 150, 80)
+    reads = ctx.upload_reads(*host(rc, 0), api.READS_NIBBLE, orientations=1)
+    t = np.zeros(na, api.INDEL_TASK)
+    for k_, v in fields.items():
+        t[k_] = v
+    d_t = torch.from_numpy(t.view(np.uint8)).to(device)
+    d_r = torch.zeros(na * api.MAPPING.itemsize, dtype=torch.uint8, device=device)
+    ms = timed(lambda: ctx.indel_match_dev(reads, d_t, na, d_r))
+    res = d_r.cpu().numpy().view(api.MAPPING)
+    out["S8_indel_match"] = {"shape": "CIndelMatching::Match m=150 max_indel=50 k=12", "tasks": na, "kernel_ms": ms,
+                             "candidates_per_s": na / ms * 1e3, "found_fraction": float((res["found"] != 0).mean())}
+    reads.free()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,6 +196,8 @@ def main():
     ap.add_argument("--genome-symbols", type=int, default=1 << 28)
     ap.add_argument("--cpu-sample", type=int, default=1 << 24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary shapes (S2, S4, S5, S8)")
+    ap.add_argument("--extras-tasks", type=int, default=1 << 22)
     ap.add_argument("--true-frac", type=float, default=0.5,
                     help="fraction of candidates planted at their locus (S1 = 0.5; other values are experiments)")
     args = ap.parse_args()
@@ -256,11 +346,18 @@ def main():
             out["cpu_baseline"] = base
             if not same:
                 out["parity_error"] = "GPU and CPU results differ on the baseline sample"
+        if not args.no_extras and world == 1:
+            del d_tasks, d_results, d_records, d_scratch, d_rec_pos, d_dir
+            reads.free()
+            reads = None
+            torch.cuda.empty_cache()
+            out["extras"] = run_extras(ctx, device, args.genome_symbols, stream, args.extras_tasks)
         print(json.dumps(out))
     if dist:
         dist.barrier()
         dist.destroy_process_group()
-    reads.free()
+    if reads is not None:
+        reads.free()
     ctx.destroy()
 
 

@@ -35,10 +35,7 @@ def levdiag_workload(m, k, fl, fr, n, seed, cur_offset=0):
     return codes, packed, (blob, off, lens), tasks
 
 
-def stage_segments(min_len, stage_major):
-    """adjust_stage_segments, mapper.cpp:616: segment j of stage i."""
-    i = stage_major
-    return [((min_len * j + i) // (i + 1), (min_len * (j + 1) + i) // (i + 1)) for j in range(i + 1)]
+stage_segments = synth.stage_segments
 
 
 def mixed_reads(codes_list, encoding):

@@ -281,6 +281,11 @@ class Context:
                                                _ptr(d_record_pos), _ptr(d_direction), _ptr(d_records),
                                                _ptr(d_count), _ptr(d_scratch), C.c_void_p(stream or 0)))
 
+    def indel_match_dev(self, reads, d_tasks, n, d_results, params=None, stream=None):
+        prm = params or default_indel_params()
+        _check(lib().wamd_indel_match_dev(self.h, reads.h, _ptr(d_tasks), C.c_uint32(n), C.byref(prm),
+                                          _ptr(d_results), C.c_void_p(stream or 0)))
+
     def align_workspace_bytes(self, reads, n):
         return int(lib().wamd_align_workspace_bytes(reads.h, C.c_uint32(n)))
 

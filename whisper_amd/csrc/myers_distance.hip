@@ -36,7 +36,10 @@
 
 namespace wamd {
 
-constexpr int TEXT_CHUNK = 8;   // genome dwords (8 columns each) fetched per batch and lane
+#ifndef WAMD_TEXT_CHUNK
+#define WAMD_TEXT_CHUNK 8
+#endif
+constexpr int TEXT_CHUNK = WAMD_TEXT_CHUNK;   // genome dwords (8 columns each) fetched per batch and lane
 
 enum { RULE_M64 = 0, RULE_M128 = 1, RULE_M256 = 2 };
 
@@ -317,8 +320,11 @@ __device__ __forceinline__ uint32_t decode_task(const wamd_dist_task& task, cons
     return 0;
 }
 
+#ifndef WAMD_KATTR
+#define WAMD_KATTR
+#endif
 template <int NW, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void myers_distance_kernel(
+__global__ __launch_bounds__(BLOCK) WAMD_KATTR void myers_distance_kernel(
     GenomeView g, ReadsView rv, const wamd_dist_task* __restrict__ tasks, uint32_t n,
     int last_symbol, uint32_t max_text_len, wamd_dist_result* __restrict__ results,
     uint32_t* __restrict__ flags)

@@ -160,3 +160,54 @@ def levdiag_tasks(reads, k, fixed_left, fixed_right, cur_offset=0):
     t["max_mismatches"] = k
     t["dir_gen_flag"] = 1
     return t
+
+
+def stage_segments(min_len, stage_major):
+    """adjust_stage_segments, mapper.cpp:616: segment j of stage i."""
+    i = stage_major
+    return [((min_len * j + i) // (i + 1), (min_len * (j + 1) + i) // (i + 1)) for j in range(i + 1)]
+
+
+def indel_match_workload(genome, n, m, seed, max_indel=50, max_mm=12, stage_major=5):
+    """Shape S8 (SURVEY 8d), vectorised: candidates for CIndelMatching::Match.  A quarter each:
+    one long deletion (3..max_indel) left of the anchor segment, one right of it, a plain read
+    with a few substitutions, and a read that shares only the anchor.  Returns the read codes
+    [n, m] and the INDEL_TASK fields as a dict of numpy arrays."""
+    dev = genome.device
+    g = _gen(seed, dev)
+    G = genome.numel()
+    segs = torch.tensor(stage_segments(m, stage_major), device=dev)
+    sj = torch.randint(0, segs.shape[0], (n,), generator=g, device=dev)
+    fl, fr = segs[sj, 0], segs[sj, 1]
+    p = torch.randint(BOUNDARY_N_LEN + 200, G - BOUNDARY_N_LEN - m - 200, (n,), generator=g, device=dev)
+    kind = torch.arange(n, device=dev) & 3
+    L = torch.randint(3, max_indel + 1, (n,), generator=g, device=dev)
+    ar = torch.arange(m, device=dev)
+    out = torch.empty((n, m), dtype=torch.uint8, device=dev)
+    chunk = 1 << 16
+    for b in range(0, n, chunk):
+        e = min(n, b + chunk)
+        c = e - b
+        flc, frc, pc, kc, Lc = fl[b:e], fr[b:e], p[b:e], kind[b:e], L[b:e]
+        u = torch.rand(c, generator=g, device=dev)
+        xl = 8 + (u * (flc - 8).clamp(min=1)).long()            # split left of the anchor
+        xr = frc + (u * (m - 8 - frc).clamp(min=1)).long()      # split right of it
+        left_ok = (kc == 0) & (flc > 12)
+        right_ok = (kc == 1) & (m - frc > 12)
+        shift = torch.where(left_ok[:, None] & (ar[None, :] < xl[:, None]), -Lc[:, None], torch.zeros_like(ar)[None, :])
+        shift = torch.where(right_ok[:, None] & (ar[None, :] >= xr[:, None]), Lc[:, None], shift)
+        r = genome[pc[:, None] + ar[None, :] + shift]
+        inside = (ar[None, :] >= flc[:, None]) & (ar[None, :] < frc[:, None])
+        rnd = torch.randint(0, 4, (c, m), generator=g, device=dev, dtype=torch.uint8)
+        r = torch.where((kc == 3)[:, None] & ~inside, rnd, r)
+        sub = (torch.rand((c, m), generator=g, device=dev) < (2.0 / m)) & ~inside
+        delta = torch.randint(1, 4, (c, m), generator=g, device=dev, dtype=torch.uint8)
+        r = torch.where(sub & (r < 4), (r + delta) & 3, r)
+        r = torch.where(r > 3, torch.full_like(r, 4), r)
+        out[b:e] = r
+    fields = dict(read_idx=np.arange(n, dtype=np.uint32), ref_pos=p.cpu().numpy().astype(np.uint32),
+                  max_indel_size=np.full(n, max_indel, np.uint16),
+                  fixed_segment_pos=fl.cpu().numpy().astype(np.uint16),
+                  fixed_segment_size=(fr - fl).cpu().numpy().astype(np.uint16),
+                  max_no_mismatches=np.full(n, max_mm, np.uint8), flags=np.zeros(n, np.uint8))
+    return out, fields
