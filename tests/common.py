@@ -27,8 +27,30 @@ def distance_workload(m, k, n, seed, encoding=0, W=None, variant=0, **kw):
     return codes, packed, (blob, off, lens), tasks
 
 
-def levdiag_workload(m, k, fl, fr, n, seed, cur_offset=0):
-    codes, packed = genome()
+def low_complexity_genome(n_symbols=1 << 18, seed=5):
+    """Short tandem repeats (period 1..6) and homopolymers between random stretches: the
+    sequences on which alignments are ambiguous and band / tie rules show."""
+    import torch
+    key = ("lc", n_symbols, seed)
+    if key not in _GENOMES:
+        g = torch.Generator().manual_seed(seed)
+        codes = synth.make_genome(n_symbols, seed=seed)
+        lo, hi = synth.BOUNDARY_N_LEN, codes.numel() - synth.BOUNDARY_N_LEN
+        pos = lo
+        while pos < hi:
+            ln = int(torch.randint(10, 160, (1,), generator=g))
+            ln = min(ln, hi - pos)
+            if int(torch.randint(0, 3, (1,), generator=g)):      # two thirds repetitive
+                per = int(torch.randint(1, 7, (1,), generator=g))
+                unit = torch.randint(0, 4, (per,), generator=g, dtype=torch.uint8)
+                codes[pos:pos + ln] = unit.repeat(ln // per + 1)[:ln]
+            pos += ln
+        _GENOMES[key] = (codes, synth.pack_nibbles(codes).numpy())
+    return _GENOMES[key]
+
+
+def levdiag_workload(m, k, fl, fr, n, seed, cur_offset=0, gen=None):
+    codes, packed = gen if gen is not None else genome()
     rd = synth.make_reads(codes, n, m, k, seed, rc_frac=0.0, protect=(fl, fr))
     blob, off, lens = host_reads(rd, 0)
     tasks = synth.levdiag_tasks(rd, k, fl, fr, cur_offset)

@@ -118,6 +118,27 @@ def test_levdiag_stage_segments(ctx, oracle, k):
         np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("k", [2, 4, 6])
+def test_levdiag_low_complexity(oracle, k):
+    """Tandem repeats: many equally good alignments, anchors that extend far, runs that end
+    on the band's edge diagonals."""
+    gen = common.low_complexity_genome()
+    codes, packed = gen
+    c = api.Context(packed, ref_size=codes.numel(), cur_offset=0)
+    try:
+        for j, (fl, fr) in enumerate(common.stage_segments(120, k)):
+            _, _, (blob, off, lens), tasks = common.levdiag_workload(120, k, fl, fr, 4000, seed=900 + 10 * k + j,
+                                                                    gen=gen)
+            rc, want = oracle.levdiag(packed, codes.numel(), 0, blob, off, lens, tasks)
+            reads = c.upload_reads(blob, off, lens, 0, orientations=1)
+            got = c.lev_diag(reads, tasks)
+            reads.free()
+            assert (want <= k).sum() > 300
+            np.testing.assert_array_equal(got, want)
+    finally:
+        c.destroy()
+
+
 def test_levdiag_rc_and_offset(ctx, oracle):
     """dir_gen_flag = 0 window arithmetic (edit_dist.cpp:114-115) and a non-zero cur_offset."""
     codes, packed, (blob, off, lens), tasks = common.levdiag_workload(100, 4, 40, 60, 3000, seed=77,

@@ -40,6 +40,19 @@ def test_levdiag(oracle, reference, k):
         np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize("k", [2, 4, 6])
+def test_levdiag_low_complexity(oracle, reference, k):
+    """The same tandem-repeat workload the GPU test uses: pins the oracle where alignments are ambiguous."""
+    gen = common.low_complexity_genome()
+    codes, packed = gen
+    for j, (fl, fr) in enumerate(common.stage_segments(120, k)):
+        _, _, (blob, off, lens), tasks = common.levdiag_workload(120, k, fl, fr, 4000, seed=900 + 10 * k + j, gen=gen)
+        _, a = oracle.levdiag(packed, codes.numel(), 0, blob, off, lens, tasks)
+        _, b = reference.levdiag(packed, codes.numel(), 0, blob, off, lens, tasks)
+        assert (a <= k).sum() > 300
+        np.testing.assert_array_equal(a, b)
+
+
 @pytest.mark.parametrize("m,k,W,last,refine", [(150, 12, None, 0, 1), (150, 13, 177, 0, 1),
                                                (150, 26, 660, 0, 1), (250, 17, None, 0, 1),
                                                (100, 10, None, 0, 0), (300, 20, None, 0, 1),
