@@ -70,32 +70,45 @@ __global__ __launch_bounds__(256) void align_classify_kernel(
     uint32_t cigar_stride, uint32_t* __restrict__ lists, uint32_t* __restrict__ counters)
 {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= n)
-        return;
-    const wamd_dist_result d = dist[gid];
-    wamd_align_result r;
-    r.affine_score = 0;
-    r.ok = 0;
-    r.edit_distance = d.edit_distance;
-    r.end_pos = d.pos;
-    r.begin_pos = 0;
-    r.num_events = 0;
-    r.cigar_len = 0;
-    r.refined = 0;
-    r.reserved = 0;
-    cigars[(uint64_t)gid * cigar_stride] = 0;
-    const bool error = d.edit_distance == RESULT_ERROR;
-    const bool ok = !error && d.edit_distance <= tasks[gid].max_ed;
-    if (!ok) {
-        if (error)
-            r.end_pos = 0;
-        results[gid] = r;
-        return;
+    uint32_t cls = 3;   // 3: not accepted, no traceback
+    if (gid < n) {
+        const wamd_dist_result d = dist[gid];
+        wamd_align_result r;
+        r.affine_score = 0;
+        r.ok = 0;
+        r.edit_distance = d.edit_distance;
+        r.end_pos = d.pos;
+        r.begin_pos = 0;
+        r.num_events = 0;
+        r.cigar_len = 0;
+        r.refined = 0;
+        r.reserved = 0;
+        cigars[(uint64_t)gid * cigar_stride] = 0;
+        const bool error = d.edit_distance == RESULT_ERROR;
+        const bool ok = !error && d.edit_distance <= tasks[gid].max_ed;
+        if (!ok) {
+            if (error)
+                r.end_pos = 0;
+            results[gid] = r;
+        } else {
+            const uint32_t rows = 2 * d.edit_distance + 3;
+            cls = rows <= 64 ? 0u : (rows <= 128 ? 1u : 2u);
+        }
     }
-    const uint32_t rows = 2 * d.edit_distance + 3;
-    const uint32_t cls = rows <= 64 ? 0u : (rows <= 128 ? 1u : 2u);
-    const uint32_t slot = atomicAdd(counters + cls, 1u);
-    lists[(uint64_t)cls * n + slot] = gid;
+    // one atomic per wave and class, slots handed out by lane rank
+#pragma unroll
+    for (uint32_t c = 0; c < 3; ++c) {
+        const uint64_t mask = __ballot(cls == c);
+        if (!mask)
+            continue;
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+        uint32_t first = 0;
+        if (cls == c && rank == 0)
+            first = atomicAdd(counters + c, (uint32_t)__popcll(mask));
+        first = __shfl((int)first, __ffsll((long long)mask) - 1);
+        if (cls == c)
+            lists[(uint64_t)c * n + first + rank] = gid;
+    }
 }
 
 template <int NW, int WW>
