@@ -31,25 +31,31 @@ namespace wamd {
 enum { OP_NONE = 0, OP_M = 1, OP_X = 2, OP_D = 3, OP_I = 4 };
 enum { DIR_D = 0, DIR_H = 1, DIR_V = 2 };
 
-// buffered reader of 4-bit symbols from packed memory, either direction
+// reader of 4-bit symbols, either direction, over dwords staged in LDS as [dword][lane]
+// (already nibble-swapped: symbol s of a dword at bits 4s); dword 0 holds symbols
+// 8 * origin_dw .. 8 * origin_dw + 7 of the sequence the indices refer to
 struct NibStream {
     const uint32_t* base;
     int64_t idx;
-    uint32_t last_dword;
+    int64_t origin_dw;
+    int32_t n_dw;
+    uint32_t stride;
     uint32_t cur;
     int64_t cur_dw;
     __device__ __forceinline__ void load()
     {
-        int64_t d = idx >> 3;
-        d = d < 0 ? 0 : (d > (int64_t)last_dword ? (int64_t)last_dword : d);
+        int64_t d = (idx >> 3) - origin_dw;
+        d = d < 0 ? 0 : (d >= n_dw ? n_dw - 1 : d);
         cur_dw = idx >> 3;
-        cur = nibble_swap(base[d]);
+        cur = base[d * stride];
     }
-    __device__ __forceinline__ void init(const void* b, int64_t start, uint32_t last)
+    __device__ __forceinline__ void init(const uint32_t* b, uint32_t stride_, int64_t origin, int32_t n, int64_t start)
     {
-        base = (const uint32_t*)b;
+        base = b;
+        stride = stride_;
+        origin_dw = origin;
+        n_dw = n;
         idx = start;
-        last_dword = last;
         load();
     }
     __device__ __forceinline__ uint32_t get(int step)
@@ -156,8 +162,18 @@ struct AlignParams {
 template <int NW, int WW, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void align_traceback_kernel(GenomeView g, ReadsView rv, AlignParams ap)
 {
-    __shared__ uint64_t pm_lds[5 * NW * BLOCK];
     constexpr int WWE = WW >= NW ? NW : WW;   // words actually kept per vector and column
+    // One wave per block: its LDS holds the pattern-match vectors during the forward pass and,
+    // once that is over, the read and the genome window the two walks fetch symbols from
+    // (a fetch from HBM on every eighth step of every lane would stall the whole wave).
+    static_assert(BLOCK == 64, "phases reuse the LDS without a barrier: one wave per block");
+    constexpr int RD = 8 * NW + 1;                                               // read dwords
+    constexpr int GD = (WW == 1 && NW > 1 ? 64 * NW + 32 : (WW == 2 && NW > 2 ? 64 * NW + 64 : 128 * NW + 2)) / 8 + 4;
+    constexpr int CH = 8;                                      // columns per refill of the walk's LDS chunk
+    constexpr int CHB = WWE <= 2 ? (CH + 1) * 3 * WWE * 2 : 0;  // chunk dwords per lane
+    constexpr int LDS_DW = (10 * NW > RD + GD + CHB ? 10 * NW : RD + GD + CHB);
+    __shared__ uint64_t lds_all[LDS_DW * BLOCK / 2];
+    uint64_t* pm_lds = lds_all;
 
     const uint32_t tid = threadIdx.x;
     const uint32_t count = *ap.count;
@@ -298,36 +314,110 @@ __global__ __launch_bounds__(BLOCK) void align_traceback_kernel(GenomeView g, Re
         }
 
         // ---- backward walk (getExtCigar, LevMyers64.cpp:413-513) ----------------------
+        // The walk reads columns pos and pos - 1 and moves left one column at a time.  Fetching
+        // their words from HBM as it goes leaves every step waiting for memory, so the narrow
+        // classes keep CH + 1 columns per lane in LDS: when any lane of the wave runs out of
+        // its chunk, every lane reloads the CH + 1 columns ending at its own position, all
+        // requests in flight at once.  The widest class reads the words where they lie.
+        constexpr bool CACHED = WWE <= 2;
+        constexpr int CW = CACHED ? 3 * WWE : 1;
+        auto window_off = [&](uint32_t j) -> uint32_t {
+            if constexpr (WW < NW) {
+                const int32_t o = (int32_t)m - 2 - (int32_t)ed - (int32_t)(end_pos - j);
+                return o > 0 ? (uint32_t)o : 0u;
+            } else {
+                return 0u;
+            }
+        };
+        uint64_t* chunk = reinterpret_cast<uint64_t*>(reinterpret_cast<uint32_t*>(lds_all) + (RD + GD) * BLOCK) + tid;
+        uint32_t chunk_hi = 0;   // column held in slot 0; slot c holds column chunk_hi - c
+        auto refill = [&](uint32_t top, bool on) {
+            if constexpr (CACHED) {
+                chunk_hi = top;
+                uint64_t v[(CH + 1) * CW];
+#pragma unroll
+                for (int c = 0; c <= CH; ++c) {
+                    const uint32_t j = top - (uint32_t)c;
+                    const bool inside = on && top >= (uint32_t)c && j >= s_col && j <= end_pos;
+                    const uint64_t* src = mat + ((uint64_t)(inside ? j - s_col : 0) * 3 * WWE) * BLOCK + tid;
+#pragma unroll
+                    for (int q = 0; q < CW; ++q) {
+                        // the column before the window: VP all ones, VN and D0 zero
+                        v[c * CW + q] = q < WWE ? ~0ull : 0ull;
+                        if (inside)
+                            v[c * CW + q] = src[q * BLOCK];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < (CH + 1) * CW; ++i)
+                    chunk[i * BLOCK] = v[i];
+            }
+        };
+        auto col_bit = [&](uint32_t j, int vec, uint32_t beta) -> uint32_t {
+            const uint32_t b = beta - (j >= s_col ? window_off(j) : 0u);
+            const uint32_t slot = chunk_hi - j;
+            uint32_t w = vec * WWE;
+            if constexpr (WWE > 1)
+                w += (b >> 6) ? (WWE - 1) : 0;
+            const uint64_t word = chunk[(slot * CW + w) * BLOCK];
+            return (uint32_t)(word >> (b & 63u)) & 1u;
+        };
         // bit of vector `vec` in the window of column j (1-based) at row bit beta
         auto mat_bit = [&](uint32_t j, int vec, uint32_t beta) -> uint32_t {
             if (j < s_col)   // the column before the window: VP all ones, VN zero
                 return vec == 0 ? 1u : 0u;
             const uint32_t ci = j - s_col;
-            uint32_t b = beta;
-            if constexpr (WW < NW) {
-                const int32_t o = (int32_t)m - 2 - (int32_t)ed - (int32_t)(end_pos - j);
-                b = beta - (o > 0 ? (uint32_t)o : 0u);
-            }
+            const uint32_t b = beta - window_off(j);
             const uint64_t word = mat[(((uint64_t)ci * 3 + vec) * WWE + (b >> 6)) * BLOCK + tid];
             return (uint32_t)(word >> (b & 63u)) & 1u;
         };
 
+#ifdef WAMD_EXP_FWD_ONLY
+        valid = false;
+#endif
         uint32_t read_pos = valid ? m : 0, pos = valid ? end_pos : 0;
         uint32_t c_val = ed, events = 0, nsteps = 0, pacc = 0;
         int prev_dir = DIR_D;
         bool in_indel = false;
         double score = 0;
-        NibStream rs, gs;
-        // oriented read symbol q (0-based) = code[q], or rc(code[m-1-q]) when reversed
-        rs.init(my_codes, rev ? 0 : (int64_t)m - 1, (uint32_t)((m + 7) / 8 - 1));
-        gs.init(g.dwords, (int64_t)ref_pos + (int64_t)end_pos - 1, g.last_dword);
-        uint32_t rsym = 0, gsym = 0;       // symbols at read_pos and pos - 1
-        bool rsym_ok = false, gsym_ok = false;
-
+        // ---- stage the read and the genome symbols under the recomputed columns ------------
+        uint32_t* st_read = reinterpret_cast<uint32_t*>(lds_all) + tid;
+        uint32_t* st_gen = st_read + RD * BLOCK;
+        const int32_t rd_n = valid ? (int32_t)((m + 7) / 8) : 1;
+        // the walk reads genome symbols ref_pos + s_col - 2 .. ref_pos + end_pos - 1
+        const int64_t g_first = (int64_t)ref_pos + (int64_t)s_col - 2;
+        const int64_t g_origin = (g_first < 0 ? 0 : g_first) >> 3;
+        int32_t gd_n = valid ? (int32_t)((((int64_t)ref_pos + end_pos - 1) >> 3) - g_origin + 1) : 1;
+        gd_n = gd_n > GD ? GD : (gd_n < 1 ? 1 : gd_n);
+        {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(my_codes);
+#pragma unroll 4
+            for (int d = 0; d < RD; ++d)
+                if (d < rd_n)
+                    st_read[d * BLOCK] = nibble_swap(src[d]);
+#pragma unroll 4
+            for (int d = 0; d < GD; ++d)
+                if (d < gd_n)
+                    st_gen[d * BLOCK] = load_genome_dword(g, (uint32_t)(g_origin + d));
+        }
+        // symbol s of a staged sequence (branch-free: the walk fetches both symbols every step)
+        auto staged_sym = [&](const uint32_t* base, uint32_t origin_dw, int32_t n_dw, uint32_t idx) -> uint32_t {
+            int32_t d = (int32_t)((idx >> 3) - origin_dw);
+            d = d < 0 ? 0 : (d >= n_dw ? n_dw - 1 : d);
+            return (base[d * BLOCK] >> (4u * (idx & 7u))) & 15u;
+        };
         auto read_code = [&](uint32_t raw) -> uint32_t {
             uint32_t c = rev ? rc_code(raw) : raw;
             // copy_direct / convert_to_rev_comp: anything but ACGT is N_read (sam.cpp:2296-2347)
             return (ap.ascii && c > 3u) ? 4u : c;
+        };
+        // oriented read symbol q (0-based) = code[q], or rc(code[m-1-q]) when reversed
+        auto read_sym = [&](uint32_t q) -> uint32_t {
+            return read_code(staged_sym(st_read, 0u, rd_n, rev ? m - 1 - q : q));
+        };
+        auto genome_sym = [&](uint32_t col) -> uint32_t {   // 1-based column of the task's window
+            const uint32_t x = staged_sym(st_gen, (uint32_t)g_origin, gd_n, ref_pos + col - 1);
+            return x > 5u ? 5u : x;   // ref_copy_direct, sam.cpp:2372-2374
         };
         auto push_step = [&](int dir) {
             pacc |= (uint32_t)dir << (2 * (nsteps & 15u));
@@ -337,68 +427,58 @@ __global__ __launch_bounds__(BLOCK) void align_traceback_kernel(GenomeView g, Re
                 pacc = 0;
             }
         };
+        const double c_match = ap.sc.match, c_mism = ap.sc.mismatch, c_do = ap.sc.gap_del_open,
+                     c_de = ap.sc.gap_del_extend, c_io = ap.sc.gap_ins_open, c_ie = ap.sc.gap_ins_extend;
 
+        refill(end_pos, valid);
         while (__any(read_pos && pos)) {
-            if (read_pos && pos) {
-                if (!rsym_ok) {
-                    rsym = read_code(rs.get(rev ? 1 : -1));
-                    rsym_ok = true;
-                }
-                if (!gsym_ok) {
-                    const uint32_t x = gs.get(-1);
-                    gsym = x > 5u ? 5u : x;   // ref_copy_direct, sam.cpp:2372-2374
-                    gsym_ok = true;
-                }
-                const uint32_t beta = read_pos - 1;
-                const uint32_t vp = mat_bit(pos, 0, beta), vn = mat_bit(pos, 1, beta);
-                const uint32_t d0 = mat_bit(pos, 2, beta);
-                const uint32_t vp_l = mat_bit(pos - 1, 0, beta), vn_l = mat_bit(pos - 1, 1, beta);
-                const uint32_t d_val = c_val - (d0 ? 0u : 1u);
-                const uint32_t v_val = c_val - vp + vn;
-                const uint32_t h_val = d_val + vp_l - vn_l;   // C(i, j-1) = C(i-1, j-1) + V(i, j-1)
-                const uint32_t mism = rsym != gsym;
-                const bool from_h = h_val + 1 == c_val;
-                const bool from_v = v_val + 1 == c_val;
-                const bool from_d = d_val + mism == c_val;
-                int dir;
-                if (from_d && (prev_dir == DIR_D || (prev_dir == DIR_H && !from_h) ||
-                               (prev_dir == DIR_V && !from_v)))
-                    dir = DIR_D;
-                else if (from_h && (prev_dir == DIR_H || (prev_dir == DIR_D && !from_d) ||
-                                    (prev_dir == DIR_V && !from_v)))
-                    dir = DIR_H;
-                else
-                    dir = DIR_V;
-                if (dir == DIR_D) {
-                    score += mism ? ap.sc.mismatch : ap.sc.match;
-                    in_indel = false;
-                    --read_pos;
-                    --pos;
-                    rsym_ok = gsym_ok = false;
-                    c_val = d_val;
-                } else if (dir == DIR_H) {
-                    if (in_indel) {
-                        score += ap.sc.gap_del_extend;
-                    } else {
-                        score += ap.sc.gap_del_open;
-                        ++events;
-                        in_indel = true;
-                    }
-                    --pos;
-                    gsym_ok = false;
-                    c_val = h_val;
-                } else {
-                    if (in_indel) {
-                        score += ap.sc.gap_ins_extend;
-                    } else {
-                        score += ap.sc.gap_ins_open;
-                        ++events;
-                        in_indel = true;
-                    }
-                    --read_pos;
-                    rsym_ok = false;
-                    c_val = v_val;
-                }
+            const bool on = read_pos && pos;
+            const uint32_t rp = on ? read_pos : 1u, cp = on ? pos : chunk_hi;   // finished lanes idle on safe indices
+            if constexpr (CACHED) {
+                if (__any(on && cp < chunk_hi - (uint32_t)CH + 1u && chunk_hi >= (uint32_t)CH))
+                    refill(cp, on);
+            }
+            const uint32_t rsym = read_sym(rp - 1);
+            const uint32_t gsym = genome_sym(cp);
+            const uint32_t beta = rp - 1;
+            uint32_t vp, vn, d0, vp_l, vn_l;
+            if constexpr (CACHED) {
+                vp = col_bit(cp, 0, beta);
+                vn = col_bit(cp, 1, beta);
+                d0 = col_bit(cp, 2, beta);
+                vp_l = col_bit(cp - 1, 0, beta);
+                vn_l = col_bit(cp - 1, 1, beta);
+            } else {
+                vp = mat_bit(cp, 0, beta);
+                vn = mat_bit(cp, 1, beta);
+                d0 = mat_bit(cp, 2, beta);
+                vp_l = mat_bit(cp - 1, 0, beta);
+                vn_l = mat_bit(cp - 1, 1, beta);
+            }
+            const uint32_t d_val = c_val - (d0 ^ 1u);
+            const uint32_t v_val = c_val - vp + vn;
+            const uint32_t h_val = d_val + vp_l - vn_l;   // C(i, j-1) = C(i-1, j-1) + V(i, j-1)
+            const uint32_t mism = rsym != gsym;
+            const bool from_h = h_val + 1 == c_val;
+            const bool from_v = v_val + 1 == c_val;
+            const bool from_d = d_val + mism == c_val;
+            // D > H > V, but a move that continues the previous direction wins (LevMyers64.cpp:431-442)
+            const bool take_d = from_d && (prev_dir == DIR_D || (prev_dir == DIR_H && !from_h) ||
+                                           (prev_dir == DIR_V && !from_v));
+            const bool take_h = !take_d && from_h && (prev_dir == DIR_H || (prev_dir == DIR_D && !from_d) ||
+                                                      (prev_dir == DIR_V && !from_v));
+            const int dir = take_d ? DIR_D : (take_h ? DIR_H : DIR_V);
+            const double cost_d = mism ? c_mism : c_match;
+            const double cost_h = in_indel ? c_de : c_do;
+            const double cost_v = in_indel ? c_ie : c_io;
+            const double cost = take_d ? cost_d : (take_h ? cost_h : cost_v);
+            if (on) {
+                score += cost;
+                events += (!take_d && !in_indel) ? 1u : 0u;
+                in_indel = !take_d;
+                read_pos -= take_h ? 0u : 1u;
+                pos -= (take_d || take_h) ? 1u : 0u;
+                c_val = take_d ? d_val : (take_h ? h_val : v_val);
                 prev_dir = dir;
                 push_step(dir);
             }
@@ -436,10 +516,13 @@ __global__ __launch_bounds__(BLOCK) void align_traceback_kernel(GenomeView g, Re
             }
         };
         NibStream rf, gf;
-        rf.init(my_codes, rev ? (int64_t)m - 1 : 0, (uint32_t)((m + 7) / 8 - 1));
-        gf.init(g.dwords, (int64_t)ref_pos + begin_pos, g.last_dword);
+        rf.init(st_read, BLOCK, 0, rd_n, rev ? (int64_t)m - 1 : 0);
+        gf.init(st_gen, BLOCK, g_origin, gd_n, (int64_t)ref_pos + begin_pos);
         uint32_t hist = 0, ref_hist = 0;
         uint32_t pw = 0;
+#ifdef WAMD_EXP_NO_REPLAY
+        valid = false;
+#endif
         const uint32_t total = valid ? nsteps : 0;
         for (uint32_t k = 0; __any(k < total); ++k) {
             if (k < total) {
@@ -539,7 +622,7 @@ static AlignLayout align_layout(const wamd_reads* r, uint32_t n)
     AlignLayout L{};
     const uint32_t nw = r->words ? r->words : 1;
     const uint32_t m = r->max_len ? r->max_len : 1;
-    L.block = nw <= 4 ? 256 : 64;
+    L.block = 64;   // one wave per block, see align_traceback_kernel
     L.path_dwords = (2 * m + 15) / 16 + 1;
     // class 0: ed <= 30, class 1: ed <= 62, class 2: ed <= m
     L.cols[0] = m + 30 + 2;
@@ -556,7 +639,7 @@ static AlignLayout align_layout(const wamd_reads* r, uint32_t n)
         L.slot_bytes_max = per_block[c] > L.slot_bytes_max ? per_block[c] : L.slot_bytes_max;
     }
     const uint32_t need_blocks = (n + L.block - 1) / L.block;
-    const uint32_t cap_blocks = 256 * 2 * (256 / L.block);   // two 256-lane blocks per CU
+    const uint32_t cap_blocks = 256 * 16;   // sixteen waves per CU
     L.blocks = need_blocks < cap_blocks ? need_blocks : cap_blocks;
     if (L.blocks == 0)
         L.blocks = 1;
@@ -646,10 +729,10 @@ int launch_align(wamd_ctx* ctx, const wamd_reads* r, const wamd_dist_task* d_tas
         if (blocks == 0)
             blocks = 1;
         switch (rv.words) {
-        case 1: rc = launch_tb_class<1, 256>(cls, g, rv, ap, blocks, s); break;
-        case 2: rc = launch_tb_class<2, 256>(cls, g, rv, ap, blocks, s); break;
-        case 3: rc = launch_tb_class<3, 256>(cls, g, rv, ap, blocks, s); break;
-        case 4: rc = launch_tb_class<4, 256>(cls, g, rv, ap, blocks, s); break;
+        case 1: rc = launch_tb_class<1, 64>(cls, g, rv, ap, blocks, s); break;
+        case 2: rc = launch_tb_class<2, 64>(cls, g, rv, ap, blocks, s); break;
+        case 3: rc = launch_tb_class<3, 64>(cls, g, rv, ap, blocks, s); break;
+        case 4: rc = launch_tb_class<4, 64>(cls, g, rv, ap, blocks, s); break;
         default:
             if (rv.words <= 8)
                 rc = launch_tb_class<8, 64>(cls, g, rv, ap, blocks, s);
