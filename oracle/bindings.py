@@ -118,6 +118,17 @@ class Oracle(_Lib):
         return rc, res, cig
 
 
+    def check_ext_cigars(self, genome, reads, offsets, lens, tasks, results, cigars):
+        """Independent replay of ext-CIGARs (ASCII reads); returns a failure code per task, 0 = consistent."""
+        tasks = _c(tasks)
+        results = _c(results)
+        cigars = _c(cigars)
+        fail = np.zeros(len(tasks), np.uint8)
+        self.lib.wo_check_ext_cigar_batch(_p(genome), _p(reads), _p(offsets), _p(lens), _p(tasks),
+                                          C.c_uint32(len(tasks)), _p(results), _p(cigars),
+                                          C.c_uint32(cigars.shape[1]), _p(fail))
+        return fail
+
     def indel_match(self, genome, reads, offsets, lens, encoding, tasks, params=None):
         tasks = _c(tasks)
         prm = params or default_indel_params()

@@ -1420,3 +1420,61 @@ int wo_serialize_batch(uint32_t n, const wamd_mapping* m, const uint8_t* directi
         sizes[i] = (uint8_t)wo_serialize_mapping(&m[i], direction[i], out + (size_t)i * 12);
     return 0;
 }
+
+
+/* ------------------------------------------------ size-independent property check */
+
+/* Replays an ext-CIGAR (format of getExtCigar, LevMyers64.cpp:392-520) over the read and the
+ * genome window it claims to align: '.' read == ref, a letter = mismatch naming the ref base,
+ * "^x" deletion of ref base x, "#y" insertion of read base y.  Not a restatement of anything:
+ * an independent consistency check the tests run at sizes the oracle itself is too slow for.
+ * fail[i] = 0 when task i is consistent (or not ok), else a small code saying what broke. */
+int wo_check_ext_cigar_batch(const uint8_t* genome, const uint8_t* reads, const uint64_t* offsets,
+                             const uint32_t* lens, const wamd_dist_task* tasks, uint32_t n,
+                             const wamd_align_result* results, const uint8_t* cigars, uint32_t cigar_stride,
+                             uint8_t* fail)
+{
+    static const char decode[] = "ACGTNNXX";
+    uint8_t read_codes[64 * WO_MAX_WORDS + 2];
+    for (uint32_t i = 0; i < n; ++i) {
+        const wamd_dist_task* t = &tasks[i];
+        const wamd_align_result* r = &results[i];
+        fail[i] = 0;
+        if (!r->ok)
+            continue;
+        const uint32_t m = lens[t->read_idx];
+        wo_read_codes(read_codes, reads + offsets[t->read_idx], m, t->flags & WAMD_TASK_FLAG_REV_COMP);
+        const uint8_t* c = cigars + (uint64_t)i * cigar_stride;
+        uint32_t rp = 0, gp = r->begin_pos, edits = 0, opens = 0, k = 0;
+        int in_gap = 0;
+        if (r->cigar_len + 1 > cigar_stride || c[r->cigar_len] != 0) { fail[i] = 1; continue; }
+        while (k < r->cigar_len && !fail[i]) {
+            const uint8_t ch = c[k];
+            uint32_t g = nib(genome, (uint64_t)t->ref_pos + gp);
+            g = g > 5 ? 5 : g;
+            if (ch == '.') {
+                if (rp >= m || read_codes[rp] != g) fail[i] = 2;
+                ++rp; ++gp; ++k; in_gap = 0;
+            } else if (ch == '^') {
+                if (c[k + 1] != (uint8_t)decode[g & 7]) fail[i] = 3;
+                ++gp; k += 2; ++edits; opens += !in_gap; in_gap = 1;
+            } else if (ch == '#') {
+                if (rp >= m || c[k + 1] != (uint8_t)decode[read_codes[rp] & 7]) fail[i] = 4;
+                ++rp; k += 2; ++edits; opens += !in_gap; in_gap = 1;
+            } else {
+                /* mismatch: names the reference base; the read base differs (a refined triple may
+                 * hold an accidental match, so only the naming is checked when refined) */
+                if (rp >= m || ch != (uint8_t)decode[g & 7]) fail[i] = 5;
+                else if (!r->refined && read_codes[rp] == g) fail[i] = 6;
+                ++rp; ++gp; ++k; ++edits; in_gap = 0;
+            }
+        }
+        if (fail[i])
+            continue;
+        if (rp != m) fail[i] = 7;
+        else if (gp != r->end_pos) fail[i] = 8;
+        else if (edits != r->edit_distance + (r->refined ? 1u : 0u)) fail[i] = 9;
+        else if (!r->refined && opens != r->num_events) fail[i] = 10;
+    }
+    return 0;
+}

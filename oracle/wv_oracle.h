@@ -122,6 +122,12 @@ int wo_clip_boundary_batch(uint32_t n, wamd_clip_record* records, uint8_t* cigar
 int wo_serialize_batch(uint32_t n, const wamd_mapping* m, const uint8_t* direction, uint8_t* out,
                        uint8_t* sizes);
 
+/* independent consistency check of ext-CIGARs against read and genome (tests only) */
+int wo_check_ext_cigar_batch(const uint8_t* genome, const uint8_t* reads, const uint64_t* offsets,
+                             const uint32_t* lens, const wamd_dist_task* tasks, uint32_t n,
+                             const wamd_align_result* results, const uint8_t* cigars, uint32_t cigar_stride,
+                             uint8_t* fail);
+
 #ifdef __cplusplus
 }
 #endif

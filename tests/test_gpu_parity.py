@@ -178,6 +178,30 @@ ALIGN_CASES = [
 ]
 
 
+def test_align_round_trip_at_scale(ctx, oracle):
+    """Size-independent property at 2^17 tasks (the oracle does a 4096-task sample): every
+    ext-CIGAR, replayed over its read and genome window, consumes the whole read, ends at
+    end_pos, names the right bases and holds exactly edit_distance (+1 when refined) edits."""
+    n = 1 << 17
+    codes, packed, (blob, off, lens), tasks = common.distance_workload(150, 13, n, seed=4242, encoding=1,
+                                                                      W=177, true_frac=0.9)
+    reads = ctx.upload_reads(blob, off, lens, 1)
+    res, cig = ctx.align(reads, tasks, last_symbol=0, refine=1, cigar_stride=512)
+    reads.free()
+    assert res["ok"].sum() > n // 2
+    fail = oracle.check_ext_cigars(packed, blob, off, lens, tasks, res, cig)
+    bad = np.nonzero(fail)[0]
+    assert len(bad) == 0, "task %d fails the replay with code %d" % (bad[0], fail[bad[0]])
+    sel = np.arange(0, n, n // 4096)
+    rc, want, wcig = oracle.align(packed, blob, off, lens, 1, tasks[sel], last_symbol=0, refine=1, cigar_stride=512)
+    assert rc == 0
+    for f in ("ok", "edit_distance", "end_pos", "begin_pos", "num_events", "cigar_len", "refined", "affine_score"):
+        np.testing.assert_array_equal(res[f][sel], want[f], err_msg=f)
+    for i, j in enumerate(sel):
+        ln = int(want["cigar_len"][i]) + 1
+        assert bytes(cig[j, :ln]) == bytes(wcig[i, :ln])
+
+
 @pytest.mark.parametrize("m,k,W,last,refine,variant", ALIGN_CASES)
 def test_align(ctx, oracle, m, k, W, last, refine, variant):
     codes, packed, (blob, off, lens), tasks = common.distance_workload(m, k, 4000, seed=300 + m + k,

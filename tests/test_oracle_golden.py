@@ -68,3 +68,20 @@ def test_clip_boundary(oracle, name):
         if f != "no_clippings":      # not a field of the reference's mapping_desc_t
             np.testing.assert_array_equal(rec[f], want[f], err_msg=f)
     np.testing.assert_array_equal(cig, z["out_cigars"])
+
+
+def test_ext_cigar_checker_accepts_oracle_output(oracle):
+    """The replay checker the large GPU test relies on: consistent with the oracle's own
+    alignments, and it notices a corrupted CIGAR."""
+    import common
+    codes, packed, (blob, off, lens), tasks = common.distance_workload(150, 13, 3000, seed=99, encoding=1, W=177,
+                                                                      true_frac=0.9)
+    rc, res, cig = oracle.align(packed, blob, off, lens, 1, tasks, last_symbol=0, refine=1, cigar_stride=512)
+    assert rc == 0 and res["ok"].sum() > 1500
+    fail = oracle.check_ext_cigars(packed, blob, off, lens, tasks, res, cig)
+    assert not fail.any()
+    i = int(np.nonzero(res["ok"] & (res["cigar_len"] > 20))[0][0])
+    cig2 = cig.copy()
+    cig2[i, 10] = ord("#") if cig2[i, 10] == ord(".") else ord(".")
+    fail = oracle.check_ext_cigars(packed, blob, off, lens, tasks, res, cig2)
+    assert fail[i] != 0 and not np.delete(fail, i).any()
