@@ -138,6 +138,23 @@ def run_extras(ctx, device, genome_symbols, stream, n_small):
     reads.free()
     del d_t, d_r
 
+    # CF pre-filter in front of S2: same reads, anchor and loci (mapping_core_sa.cpp:228-230)
+    tc = np.zeros(n, api.CF_TASK)
+    tc["read_idx"] = np.arange(n, dtype=np.uint32)
+    tc["position"] = rd["p"].cpu().numpy().astype(np.uint32)
+    tc["pattern_len"] = 150
+    tc["fixed_left"], tc["fixed_right"] = fl, fr
+    tc["dir_gen_flag"] = 1
+    d_tc = torch.from_numpy(tc.view(np.uint8)).to(device)
+    d_rc = torch.zeros(n, dtype=torch.int32, device=device)
+    reads = ctx.upload_reads(*host(rd["codes"], 0), api.READS_NIBBLE, orientations=1)
+    ms = timed(lambda: ctx.cf_filter_dev(reads, d_tc, n, d_rc))
+    out["C_cf_filter"] = {"shape": "CF pre-filter m=150 anchor [%d,%d), pass iff L1 <= 20" % (fl, fr), "tasks": n,
+                          "kernel_ms": ms, "candidates_per_s": n / ms * 1e3,
+                          "pass_fraction": float((d_rc.cpu().numpy().view(np.uint32) <= 20).mean())}
+    reads.free()
+    del d_tc, d_rc
+
     # S5: LevMyers256 distance, m = 250, k = 17, W = 284 (8 dwords per vector)
     rd = synth.make_reads(codes, n, 250, 17, 78, chunk=1 << 16)
     reads = ctx.upload_reads(*host(rd["codes"], 0), api.READS_NIBBLE, orientations=3)

@@ -220,6 +220,30 @@ typedef struct wamd_clip_record {
     uint32_t reserved;
 } wamd_clip_record;
 
+/* One CF pre-filter decision of the mapping loops (mapping_core_sa.cpp:228-230, 283-285,
+ * 392, 444; mapping_core_dp.cpp:132, 161): dinucleotide histograms (16 saturating int8 bins,
+ * CF_SSE_lut, mapping_core.cpp:196-217) of the read and of the genome under it, both taken
+ * over pattern_len (= min_read_len) symbols outside the anchor [fixed_left, fixed_right);
+ * the candidate goes on to the verifier iff their L1 distance <= 4 * max_mismatches.
+ *   genome side  calculate_CF_128b_SEE_for_dir_and_rc_gen(fixed_left, fixed_right, pattern_len,
+ *                position, CF, dir_gen_flag)                       mapping_core_dp.cpp:349-428
+ *   read side    calculate_CF_128b_SSE_for_a_pattern(pattern + read_offset ..., pattern_len,
+ *                fixed_left, fixed_right, CF)                      mapping_core_dp.cpp:431-483
+ * read_offset: where the pattern_len window starts inside the read (0 on the direct strand,
+ * pattern length - min_read_len on the other, mapping_core_diff_len_reads.cpp:118-126).
+ * A region of exactly one symbol is rejected (the reference's byte walk underflows there). */
+typedef struct wamd_cf_task {
+    uint32_t read_idx;
+    uint32_t position;            /* position_read_from_SA_array                        */
+    uint16_t read_offset;
+    uint16_t pattern_len;
+    uint16_t fixed_left;
+    uint16_t fixed_right;
+    uint8_t dir_gen_flag;
+    uint8_t flags;                /* WAMD_TASK_FLAG_*: orientation of the read           */
+    uint16_t reserved;
+} wamd_cf_task;
+
 typedef struct wamd_ctx wamd_ctx;       /* one per (process, device)                  */
 typedef struct wamd_reads wamd_reads;   /* a device-resident batch of reads           */
 
@@ -290,6 +314,17 @@ WAMD_API int wamd_levdiag(wamd_ctx* ctx, const wamd_reads* reads,
 WAMD_API int wamd_levdiag_dev(wamd_ctx* ctx, const wamd_reads* reads,
                               const wamd_levdiag_task* d_tasks, uint32_t n,
                               uint32_t* d_results, void* stream);
+
+/* ---- CF pre-filter (decides which candidates reach the verifier) -------- *
+ * results[i] = horizontal_add(abs(CF_read - CF_genome)) of test_CF_128b_SSE_difference
+ * (mapping_core.h:260-263) exactly as the reference's unsigned comparison sees it - VCL
+ * truncates that sum to int8 and sign-extends it, so 128..255 arrive as huge values and
+ * 256+ wrap around; the candidate passes iff results[i] <= 4 * max_mismatches.
+ * Reads: nibble-packed, as in the mapping stage. */
+WAMD_API int wamd_cf_filter(wamd_ctx* ctx, const wamd_reads* reads, const wamd_cf_task* tasks,
+                            uint32_t n, uint32_t* results);
+WAMD_API int wamd_cf_filter_dev(wamd_ctx* ctx, const wamd_reads* reads, const wamd_cf_task* d_tasks,
+                                uint32_t n, uint32_t* d_results, void* stream);
 
 /* ---- verification with alignment (post-processing) --------------------- *
  * dynamicProgramming + getExtCigar (+ refine_ext_cigar when refine != 0) as in

@@ -47,6 +47,11 @@ assert INDEL_CIGAR_RESULT.itemsize == 32 and CLIP_RECORD.itemsize == 32
 
 
 
+CF_TASK = np.dtype([("read_idx", "<u4"), ("position", "<u4"), ("read_offset", "<u2"), ("pattern_len", "<u2"),
+                    ("fixed_left", "<u2"), ("fixed_right", "<u2"), ("dir_gen_flag", "u1"), ("flags", "u1"),
+                    ("reserved", "<u2")])
+
+
 class Scoring(C.Structure):  # noqa: E302
     _fields_ = [(n, C.c_double) for n in ("match", "mismatch", "gap_ins_open", "gap_ins_extend",
                                            "gap_del_open", "gap_del_extend", "clipping")]
@@ -117,6 +122,14 @@ class Oracle(_Lib):
                                      C.c_uint32(cigar_stride))
         return rc, res, cig
 
+
+    def cf_filter(self, genome, ref_size, cur_offset, reads, offsets, lens, tasks):
+        """CF pre-filter distances (mapping_core_dp.cpp:349-483); nibble-packed reads."""
+        tasks = np.ascontiguousarray(tasks, CF_TASK)
+        res = np.zeros(len(tasks), np.uint32)
+        rc = self.lib.wo_cf_batch(_p(genome), C.c_uint32(ref_size), C.c_uint32(cur_offset), _p(reads), _p(offsets),
+                                  _p(lens), _p(tasks), C.c_uint32(len(tasks)), _p(res))
+        return rc, res
 
     def check_ext_cigars(self, genome, reads, offsets, lens, tasks, results, cigars):
         """Independent replay of ext-CIGARs (ASCII reads); returns a failure code per task, 0 = consistent."""
@@ -263,3 +276,16 @@ Reference.indel_match = _ref_indel_match
 Reference.indel_ext_cigar = _ref_indel_ext_cigar
 Reference.clip_boundary = _ref_clip_boundary
 Reference.serialize = _ref_serialize
+
+
+def _ref_cf_filter(self, genome, ref_size, cur_offset, reads, offsets, lens, tasks, max_diff=20):
+    """The reference's own calculate_CF_128b_* and test_CF_128b_SSE_difference."""
+    tasks = np.ascontiguousarray(tasks, CF_TASK)
+    res = np.zeros(len(tasks), np.uint32)
+    ok = np.zeros(len(tasks), np.uint8)
+    rc = self.lib.ref_cf_batch(_p(genome), C.c_uint32(ref_size), C.c_uint32(cur_offset), _p(reads), _p(offsets),
+                               _p(lens), _p(tasks), C.c_uint32(len(tasks)), _p(res), _p(ok), C.c_uint32(max_diff))
+    return rc, res, ok
+
+
+Reference.cf_filter = _ref_cf_filter

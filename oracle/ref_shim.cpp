@@ -455,3 +455,70 @@ REF_API int ref_serialize_batch(uint32_t n, const wamd_mapping* m, const uint8_t
     }
     return 0;
 }
+
+
+/* ---- CF pre-filter: CMappingCore::calculate_CF_128b_* on storage that is never constructed.
+ * The two routines read ref_ptr, ref_size, CUR_OFFSET and CF_SSE_lut only; the lut is filled
+ * here exactly as the constructor does (mapping_core.cpp:196-217) from CMappingCore::list. */
+#include "mapper/mapping_core.h"
+
+namespace {
+struct MappingCoreBox {
+    alignas(CMappingCore) unsigned char raw[sizeof(CMappingCore)];
+    CMappingCore* get() { return reinterpret_cast<CMappingCore*>(raw); }
+    MappingCoreBox(const uint8_t* ref, uint32_t ref_size, uint32_t cur_offset)
+    {
+        memset(raw, 0, sizeof(raw));
+        CMappingCore* c = get();
+        c->ref_ptr = const_cast<uint8_t*>(ref);
+        c->ref_size = ref_size;
+        c->CUR_OFFSET = cur_offset;
+        for (int i = 0; i < 256; ++i)
+            c->CF_SSE_lut[i] = Vec16c(0);
+        for (int a = 0; a < 4; ++a)
+            for (int b = 0; b < 4; ++b)
+                c->CF_SSE_lut[16 * a + b].load(CMappingCore::list[4 * a + b]);
+    }
+};
+} // namespace
+
+static inline uint32_t shim_nib(const uint8_t* p, uint32_t i) { return (i & 1) ? (p[i >> 1] & 15u) : (p[i >> 1] >> 4); }
+static inline uint32_t shim_rc(uint32_t c) { return c < 4 ? 3 - c : (c < 8 ? c : 7); }
+
+REF_API int ref_cf_batch(const uint8_t* genome, uint32_t ref_size, uint32_t cur_offset, const uint8_t* reads,
+                         const uint64_t* offsets, const uint32_t* lens, const wamd_cf_task* tasks, uint32_t n,
+                         uint32_t* results, uint8_t* pass4k, uint32_t max_diff)
+{
+    MappingCoreBox box(genome, ref_size, cur_offset);
+    CMappingCore* mc = box.get();
+    std::vector<uint8_t> data, data_sft;
+    for (uint32_t i = 0; i < n; ++i) {
+        const wamd_cf_task& t = tasks[i];
+        const uint32_t m = lens[t.read_idx];
+        const uint8_t* src = reads + offsets[t.read_idx];
+        data.assign(m / 2 + 4, 0);
+        data_sft.assign(m / 2 + 4, 0);
+        for (uint32_t j = 0; j < m; ++j) {
+            const uint32_t c = (t.flags & WAMD_TASK_FLAG_REV_COMP) ? shim_rc(shim_nib(src, m - 1 - j)) : shim_nib(src, j);
+            data[j >> 1] |= (uint8_t)((j & 1) ? c : c << 4);
+        }
+        /* CReadsDeliverer::Pop, reads.cpp:381-391 */
+        data_sft[0] = data[0] >> 4;
+        for (uint32_t j = 1; j <= m / 2 + 1; ++j)
+            data_sft[j] = (uint8_t)(((data[j - 1] & 0xf) << 4) + (data[j] >> 4));
+        Vec16c cf_r, cf_g;
+        const uint32_t d = t.read_offset;
+        /* mapping_core_diff_len_reads.cpp:118-126 */
+        if (d & 1)
+            mc->calculate_CF_128b_SSE_for_a_pattern(data_sft.data() + (d >> 1) + 1, data.data() + (d >> 1), t.pattern_len,
+                                                    t.fixed_left, t.fixed_right, cf_r);
+        else
+            mc->calculate_CF_128b_SSE_for_a_pattern(data.data() + (d >> 1), data_sft.data() + (d >> 1), t.pattern_len,
+                                                    t.fixed_left, t.fixed_right, cf_r);
+        mc->calculate_CF_128b_SEE_for_dir_and_rc_gen(t.fixed_left, t.fixed_right, t.pattern_len, t.position, cf_g,
+                                                     t.dir_gen_flag != 0);
+        results[i] = (uint32_t)horizontal_add(abs(cf_r - cf_g));
+        pass4k[i] = mc->test_CF_128b_SSE_difference(cf_r, cf_g, max_diff) ? 1 : 0;
+    }
+    return 0;
+}

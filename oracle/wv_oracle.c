@@ -1478,3 +1478,153 @@ int wo_check_ext_cigar_batch(const uint8_t* genome, const uint8_t* reads, const 
     }
     return 0;
 }
+
+
+/* ------------------------------------------------------------- CF pre-filter (row C) */
+
+/* CF_SSE_lut (mapping_core.cpp:196-217): a byte holding two ACGT symbols selects the one-hot
+ * vector of its dinucleotide, every other byte the zero vector; add_saturated on int8 lanes. */
+static void cf_add(int8_t* cf, uint32_t byte)
+{
+    const uint32_t a = (byte >> 4) & 15u, b = byte & 15u;
+    if (a < 4 && b < 4 && cf[4 * a + b] < 127)
+        ++cf[4 * a + b];
+}
+
+/* one region of calculate_CF_128b_SEE_for_dir_and_rc_gen, mapping_core_dp.cpp:361-391 / 395-427 */
+static int cf_genome_region(int8_t* cf, const uint8_t* ref_ptr, uint32_t left_end, uint32_t len_in_chars)
+{
+    const uint8_t* T_ptr = ref_ptr + (left_end >> 1);
+    if (left_end & 1) {
+        uint32_t byte = (uint32_t)(*T_ptr & 15u) << 4;
+        T_ptr++;
+        byte += *T_ptr >> 4;
+        cf_add(cf, byte);
+        --len_in_chars;
+    }
+    if (len_in_chars == 0)
+        return 1;   /* (len_in_chars - 1) >> 1 underflows in the reference */
+    const uint32_t no_full_bytes = (len_in_chars - 1) >> 1;
+    for (uint32_t i = 0; i < no_full_bytes; ++i) {
+        cf_add(cf, *T_ptr);
+        uint32_t byte = (uint32_t)(*T_ptr & 15u) << 4;
+        T_ptr++;
+        byte += *T_ptr >> 4;
+        cf_add(cf, byte);
+    }
+    if ((len_in_chars & 1) == 0)
+        cf_add(cf, *T_ptr);
+    return 0;
+}
+
+int wo_cf_genome(const uint8_t* ref_ptr, uint32_t ref_size, uint32_t cur_offset, uint32_t fixed_left,
+                 uint32_t fixed_right, uint32_t pattern_len, uint32_t position, int dir_gen_flag, int8_t* cf)
+{
+    uint32_t left_end = dir_gen_flag ? position - cur_offset : ref_size - position - pattern_len + cur_offset;
+    int bad = 0;
+    memset(cf, 0, 16);
+    if (fixed_left)
+        bad |= cf_genome_region(cf, ref_ptr, left_end, fixed_left);
+    if (fixed_right != pattern_len)
+        bad |= cf_genome_region(cf, ref_ptr, left_end + fixed_right, pattern_len - fixed_right);
+    return bad;
+}
+
+/* calculate_CF_128b_SSE_for_a_pattern, mapping_core_dp.cpp:431-483 */
+int wo_cf_pattern(const uint8_t* pattern, const uint8_t* pattern_sft, uint32_t pattern_len, uint32_t fixed_left,
+                  uint32_t fixed_right, int8_t* cf)
+{
+    const uint8_t *p, *q;
+    memset(cf, 0, 16);
+    if (fixed_left) {
+        const uint32_t len_in_chars = fixed_left;
+        const uint32_t no_full_bytes = (len_in_chars - 1) / 2;
+        p = &pattern[0];
+        q = &pattern_sft[1];
+        for (uint32_t i = 0; i < no_full_bytes; ++i) {
+            cf_add(cf, *p++);
+            cf_add(cf, *q++);
+        }
+        if ((len_in_chars & 1) == 0)
+            cf_add(cf, *p++);
+    }
+    if (fixed_right != pattern_len) {
+        const uint32_t len_in_chars = pattern_len - fixed_right;
+        const uint32_t no_full_bytes = (len_in_chars - 1) / 2;
+        const uint32_t fixed_right_div2 = fixed_right / 2;
+        if (fixed_right & 1) {
+            p = &pattern_sft[fixed_right_div2 + 1];
+            q = &pattern[fixed_right_div2 + 1];
+        } else {
+            p = &pattern[fixed_right_div2];
+            q = &pattern_sft[fixed_right_div2 + 1];
+        }
+        for (uint32_t i = 0; i < no_full_bytes; ++i) {
+            cf_add(cf, *p++);
+            cf_add(cf, *q++);
+        }
+        if ((len_in_chars & 1) == 0)
+            cf_add(cf, *p++);
+    }
+    return 0;
+}
+
+/* test_CF_128b_SSE_difference's left-hand side, mapping_core.h:260-263.  VCL's
+ * horizontal_add(Vec16c) truncates the sum to 8 bits and sign-extends it (libs/vectori128.h),
+ * and the comparison with the unsigned max_diff is unsigned: sums of 128..255 never pass,
+ * sums of 256 and more wrap around to small values.  Returned as the caller compares it. */
+uint32_t wo_cf_difference(const int8_t* a, const int8_t* b)
+{
+    uint32_t s = 0;
+    for (int i = 0; i < 16; ++i) {
+        const int8_t d = (int8_t)(a[i] - b[i]);
+        s += (uint32_t)(d < 0 ? -d : d);
+    }
+    return (uint32_t)(int32_t)(int8_t)(s & 0xffu);
+}
+
+int wo_cf_batch(const uint8_t* genome, uint32_t ref_size, uint32_t cur_offset, const uint8_t* reads,
+                const uint64_t* offsets, const uint32_t* lens, const wamd_cf_task* tasks, uint32_t n,
+                uint32_t* results)
+{
+    uint8_t* data = (uint8_t*)malloc(64 * WO_MAX_WORDS / 2 + 4);
+    uint8_t* data_sft = (uint8_t*)malloc(64 * WO_MAX_WORDS / 2 + 4);
+    int rc = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const wamd_cf_task* t = &tasks[i];
+        const uint32_t m = lens[t->read_idx];
+        const uint8_t* src = reads + offsets[t->read_idx];
+        int8_t cf_r[16], cf_g[16];
+        results[i] = 0xffffffffu;
+        if ((uint32_t)t->read_offset + t->pattern_len > m || t->fixed_left > t->fixed_right ||
+            t->fixed_right > t->pattern_len || t->fixed_left == 1 || t->pattern_len - t->fixed_right == 1) {
+            rc = WAMD_ERR_INVALID_ARG;
+            continue;
+        }
+        /* the read in the orientation asked for, packed as the mapper holds it, and its copy
+         * shifted by one symbol (reads.cpp:381-391) */
+        memset(data, 0, (m + 1) / 2 + 2);
+        for (uint32_t j = 0; j < m; ++j) {
+            uint32_t c = (t->flags & WAMD_TASK_FLAG_REV_COMP) ? rc_code(nib(src, m - 1 - j)) : nib(src, j);
+            data[j >> 1] |= (uint8_t)((j & 1) ? c : c << 4);
+        }
+        data_sft[0] = data[0] >> 4;
+        for (uint32_t j = 1; j <= m / 2 + 1; ++j)
+            data_sft[j] = (uint8_t)(((data[j - 1] & 15u) << 4) + (data[j] >> 4));
+        /* window start as at the call sites (mapping_core_diff_len_reads.cpp:118-126) */
+        const uint32_t d = t->read_offset;
+        if (d & 1)
+            wo_cf_pattern(data_sft + (d >> 1) + 1, data + (d >> 1), t->pattern_len, t->fixed_left, t->fixed_right, cf_r);
+        else
+            wo_cf_pattern(data + (d >> 1), data_sft + (d >> 1), t->pattern_len, t->fixed_left, t->fixed_right, cf_r);
+        if (wo_cf_genome(genome, ref_size, cur_offset, t->fixed_left, t->fixed_right, t->pattern_len, t->position,
+                         t->dir_gen_flag, cf_g)) {
+            rc = WAMD_ERR_INVALID_ARG;
+            continue;
+        }
+        results[i] = wo_cf_difference(cf_r, cf_g);
+    }
+    free(data);
+    free(data_sft);
+    return rc;
+}

@@ -128,6 +128,16 @@ int wo_check_ext_cigar_batch(const uint8_t* genome, const uint8_t* reads, const 
                              const wamd_align_result* results, const uint8_t* cigars, uint32_t cigar_stride,
                              uint8_t* fail);
 
+/* CF pre-filter: mapping_core_dp.cpp:349-483, mapping_core.h:260-263 */
+int wo_cf_genome(const uint8_t* ref_ptr, uint32_t ref_size, uint32_t cur_offset, uint32_t fixed_left,
+                 uint32_t fixed_right, uint32_t pattern_len, uint32_t position, int dir_gen_flag, int8_t* cf);
+int wo_cf_pattern(const uint8_t* pattern, const uint8_t* pattern_sft, uint32_t pattern_len, uint32_t fixed_left,
+                  uint32_t fixed_right, int8_t* cf);
+uint32_t wo_cf_difference(const int8_t* a, const int8_t* b);
+int wo_cf_batch(const uint8_t* genome, uint32_t ref_size, uint32_t cur_offset, const uint8_t* reads,
+                const uint64_t* offsets, const uint32_t* lens, const wamd_cf_task* tasks, uint32_t n,
+                uint32_t* results);
+
 #ifdef __cplusplus
 }
 #endif

@@ -223,3 +223,55 @@ def clip_workload(n, m, seed, gen=None):
     rec["ref_length"] = (res["end_pos"][ok] - res["begin_pos"][ok]).astype(np.uint16)
     rec["err_edit_distance"] = res["edit_distance"][ok]
     return rec, np.ascontiguousarray(cig[ok])
+
+
+def cf_workload(n, seed, min_len=150, k=5, cur_offset=0, gen=None):
+    """CF pre-filter tasks (mapping_core_sa.cpp:228-230 / 283-285): reads of min_len .. min_len + 5
+    symbols, direct-strand and other-strand flavours, every segment of stage k as the anchor."""
+    import torch
+    from oracle import bindings as ob
+    codes, packed = gen if gen is not None else genome()
+    g = torch.Generator().manual_seed(seed)
+    ref_size = codes.numel()
+    segs = stage_segments(min_len, k)
+    reads_codes, tasks = [], np.zeros(n, ob.CF_TASK)
+    for i in range(n):
+        m = min_len + int(torch.randint(0, 6, (1,), generator=g))
+        p = int(torch.randint(synth.BOUNDARY_N_LEN - 40, ref_size - synth.BOUNDARY_N_LEN - 400, (1,), generator=g))
+        r = codes[p:p + m].clone()
+        kind = i % 4
+        if kind == 1:      # a few substitutions
+            for _ in range(int(torch.randint(1, 8, (1,), generator=g))):
+                z = int(torch.randint(0, m, (1,), generator=g))
+                r[z] = (int(r[z]) + 1 + int(torch.randint(0, 3, (1,), generator=g))) & 3
+        elif kind == 2:    # unrelated read
+            r = torch.randint(0, 4, (m,), generator=g, dtype=torch.uint8)
+        elif kind == 3:    # low complexity
+            r = torch.tensor([0, 1] * m, dtype=torch.uint8)[:m] if i % 8 == 3 else torch.zeros(m, dtype=torch.uint8)
+        r[r > 3] = 4
+        fl, fr = segs[int(torch.randint(0, len(segs), (1,), generator=g))]
+        other = bool(i & 16)
+        t = tasks[i]
+        t["read_idx"] = i
+        t["pattern_len"] = min_len
+        if not other:      # direct strand: window = first min_len symbols, left_end = position - cur_offset
+            t["position"] = p + cur_offset
+            t["read_offset"] = 0
+            t["fixed_left"], t["fixed_right"] = fl, fr
+            t["dir_gen_flag"] = 1
+            t["flags"] = 0
+            reads_codes.append(r)
+        else:              # other strand: the mapper holds the reverse complement, window = its last min_len symbols
+            t["position"] = (ref_size - p - min_len + cur_offset) & 0xFFFFFFFF
+            t["read_offset"] = m - min_len
+            t["fixed_left"], t["fixed_right"] = min_len - fr, min_len - fl
+            t["dir_gen_flag"] = 0
+            t["flags"] = 1   # stored direct, verified in rev_comp orientation
+            # oriented read = rev_comp(stored); make its window equal the genome at p
+            ext = codes[p - (m - min_len):p + min_len].clone() if kind != 2 else r
+            ext[ext > 3] = 4
+            if kind in (1, 3):
+                ext = r
+            reads_codes.append(synth.rev_comp(ext))
+    blob, off, lens = mixed_reads(reads_codes, 0)
+    return codes, packed, (blob, off, lens), tasks

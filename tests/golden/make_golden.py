@@ -54,11 +54,26 @@ ALIGN = [
 ]
 
 
+def make_cf(ref, codes, packed, ref_size):
+    """CF pre-filter fixtures: the reference's own calculate_CF_128b_* + horizontal_add(abs())."""
+    for name, k, cur_offset, n in (("cf_m150_k5", 5, 0, 1500), ("cf_m150_k2_off31", 2, 31, 800)):
+        _, _, (blob, off, lens), tasks = common.cf_workload(n, seed=700 + k, k=k, cur_offset=cur_offset,
+                                                            gen=(codes, packed))
+        rc, res, ok = ref.cf_filter(packed, ref_size, cur_offset, blob, off, lens, tasks, max_diff=4 * k)
+        assert rc == 0
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), kind="cf", blob=blob, off=off, lens=lens, tasks=tasks,
+                            results=res, passed=ok, cur_offset=cur_offset, max_diff=4 * k)
+        print(name, "passed", int(ok.sum()), "of", n)
+
+
 def main():
     ref = bindings.Reference()
     codes = synth.make_genome(GENOME_SYMBOLS, seed=GENOME_SEED)
     packed = synth.pack_nibbles(codes).numpy()
     ref_size = codes.numel()
+    if len(sys.argv) > 1 and sys.argv[1] == "cf":   # only the fixtures of this family
+        make_cf(ref, codes, packed, ref_size)
+        return
     np.savez_compressed(os.path.join(HERE, "genome.npz"), packed=packed,
                         ref_size=np.uint32(ref_size), reference_version=ref.version())
     seed = 1000
@@ -122,6 +137,7 @@ def main():
         print(name, "found", int(res["found"].sum()), "types", np.bincount(res["type"][res["found"] == 1], minlength=9))
     seed += 1
     rec, cig = common.clip_workload(1200, 150, seed, gen=(codes, packed))
+    make_cf(ref, codes, packed, ref_size)
     rc, rec2, cig2 = ref.clip_boundary(rec, cig)
     np.savez_compressed(os.path.join(HERE, "clip_m150.npz"), kind="clip", records=rec, cigars=cig,
                         out_records=rec2, out_cigars=cig2)

@@ -35,6 +35,21 @@ def test_levdiag(ctx, name):
     np.testing.assert_array_equal(got, z["results"])
 
 
+@pytest.mark.parametrize("name", gu.cases("cf"))
+def test_cf_filter(ctx, name):
+    z = gu.load(name)
+    _, ref_size = gu.load_genome()
+    ctx.set_reference_params(ref_size, int(z["cur_offset"]))
+    try:
+        reads = ctx.upload_reads(z["blob"], z["off"], z["lens"], 0, orientations=1)
+        got = ctx.cf_filter(reads, z["tasks"])
+        reads.free()
+    finally:
+        ctx.set_reference_params(ref_size, 0)
+    np.testing.assert_array_equal(got, z["results"])
+    np.testing.assert_array_equal((got <= int(z["max_diff"])).astype(np.uint8), z["passed"])
+
+
 @pytest.mark.parametrize("name", gu.cases("align"))
 def test_align(ctx, name):
     z = gu.load(name)

@@ -139,6 +139,27 @@ def test_levdiag_low_complexity(oracle, k):
         c.destroy()
 
 
+@pytest.mark.parametrize("k,cur_offset", [(5, 0), (1, 0), (6, 17)])
+def test_cf_filter(ctx, oracle, k, cur_offset):
+    """Row C: dinucleotide histograms, both strands, odd / even window starts, ragged read lengths."""
+    codes, packed, (blob, off, lens), tasks = common.cf_workload(6000, seed=60 + k, k=k, cur_offset=cur_offset)
+    rc, want = oracle.cf_filter(packed, codes.numel(), cur_offset, blob, off, lens, tasks)
+    assert rc == 0
+    ctx.set_reference_params(codes.numel(), cur_offset)
+    try:
+        reads = ctx.upload_reads(blob, off, lens, 0, orientations=1)
+        got = ctx.cf_filter(reads, tasks)
+        bad = tasks[:8].copy()
+        bad["fixed_left"] = 1                      # one-symbol region: the reference's walk underflows
+        with pytest.raises(api.WamdError):
+            ctx.cf_filter(reads, bad)
+        reads.free()
+    finally:
+        ctx.set_reference_params(codes.numel(), 0)
+    assert 500 < (want <= 4 * k).sum() < 5800
+    np.testing.assert_array_equal(got, want)
+
+
 def test_levdiag_rc_and_offset(ctx, oracle):
     """dir_gen_flag = 0 window arithmetic (edit_dist.cpp:114-115) and a non-zero cur_offset."""
     codes, packed, (blob, off, lens), tasks = common.levdiag_workload(100, 4, 40, 60, 3000, seed=77,

@@ -85,3 +85,13 @@ def test_ext_cigar_checker_accepts_oracle_output(oracle):
     cig2[i, 10] = ord("#") if cig2[i, 10] == ord(".") else ord(".")
     fail = oracle.check_ext_cigars(packed, blob, off, lens, tasks, res, cig2)
     assert fail[i] != 0 and not np.delete(fail, i).any()
+
+
+@pytest.mark.parametrize("name", gu.cases("cf"))
+def test_cf_filter(oracle, name):
+    z = gu.load(name)
+    packed, ref_size = gu.load_genome()
+    rc, res = oracle.cf_filter(packed, ref_size, int(z["cur_offset"]), z["blob"], z["off"], z["lens"], z["tasks"])
+    assert rc == 0
+    np.testing.assert_array_equal(res, z["results"])
+    np.testing.assert_array_equal((res <= int(z["max_diff"])).astype(np.uint8), z["passed"])

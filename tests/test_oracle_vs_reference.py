@@ -115,3 +115,14 @@ def test_clip_boundary(oracle, reference):
         if f != "no_clippings":
             np.testing.assert_array_equal(ra[f], rb[f], err_msg=f)
     np.testing.assert_array_equal(ca, cb)
+
+
+@pytest.mark.parametrize("k,cur_offset", [(5, 0), (2, 0), (5, 31)])
+def test_cf_filter(oracle, reference, k, cur_offset):
+    codes, packed, (blob, off, lens), tasks = common.cf_workload(3000, seed=40 + k, k=k, cur_offset=cur_offset)
+    rc1, a = oracle.cf_filter(packed, codes.numel(), cur_offset, blob, off, lens, tasks)
+    rc2, b, ok = reference.cf_filter(packed, codes.numel(), cur_offset, blob, off, lens, tasks, max_diff=4 * k)
+    assert rc1 == 0 and rc2 == 0
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(ok, (a <= 4 * k).astype(np.uint8))
+    assert 300 < ok.sum() < 2900     # the filter both passes and rejects

@@ -32,6 +32,9 @@ ALIGN_RESULT = np.dtype([("affine_score", "<f8"), ("ok", "<u4"), ("edit_distance
                          ("end_pos", "<u4"), ("begin_pos", "<u4"), ("num_events", "<u4"),
                          ("cigar_len", "<u4"), ("refined", "<u4"), ("reserved", "<u4")])
 
+CF_TASK = np.dtype([("read_idx", "<u4"), ("position", "<u4"), ("read_offset", "<u2"), ("pattern_len", "<u2"),
+                    ("fixed_left", "<u2"), ("fixed_right", "<u2"), ("dir_gen_flag", "u1"), ("flags", "u1"),
+                    ("reserved", "<u2")])
 INDEL_TASK = np.dtype([("read_idx", "<u4"), ("ref_pos", "<u4"), ("max_indel_size", "<u2"),
                        ("fixed_segment_pos", "<u2"), ("fixed_segment_size", "<u2"),
                        ("max_no_mismatches", "u1"), ("flags", "u1")])
@@ -61,7 +64,7 @@ EXPORTS = [
     "wamd_ctx_set_max_text_len", "wamd_ctx_set_reference_params", "wamd_ctx_stream",
     "wamd_ctx_synchronize", "wamd_ctx_take_flags", "wamd_reads_upload", "wamd_reads_free",
     "wamd_reads_count", "wamd_verify_distance", "wamd_verify_distance_dev", "wamd_levdiag",
-    "wamd_levdiag_dev", "wamd_align", "wamd_align_dev", "wamd_align_workspace_bytes",
+    "wamd_levdiag_dev", "wamd_cf_filter", "wamd_cf_filter_dev", "wamd_align", "wamd_align_dev", "wamd_align_workspace_bytes",
     "wamd_indel_match", "wamd_indel_match_dev", "wamd_indel_ext_cigar", "wamd_indel_ext_cigar_dev",
     "wamd_clip_boundary", "wamd_clip_boundary_dev", "wamd_serialize_mappings",
     "wamd_serialize_mappings_dev", "wamd_records_scratch_bytes", "wamd_emit_lev_records_dev",
@@ -216,6 +219,17 @@ class Context:
         res = np.zeros(len(tasks), np.uint32)
         _check(lib().wamd_levdiag(self.h, reads.h, _ptr(tasks), C.c_uint32(len(tasks)), _ptr(res)))
         return res
+
+    def cf_filter(self, reads, tasks):
+        """CF pre-filter distances for a batch (mapping_core_dp.cpp:349-483); pass iff <= 4k."""
+        tasks = np.ascontiguousarray(tasks, CF_TASK)
+        res = np.zeros(len(tasks), np.uint32)
+        _check(lib().wamd_cf_filter(self.h, reads.h, _ptr(tasks), C.c_uint32(len(tasks)), _ptr(res)))
+        return res
+
+    def cf_filter_dev(self, reads, d_tasks, n, d_results, stream=None):
+        _check(lib().wamd_cf_filter_dev(self.h, reads.h, _ptr(d_tasks), C.c_uint32(n), _ptr(d_results),
+                                        C.c_void_p(stream or 0)))
 
     def align(self, reads, tasks, last_symbol=0, refine=1, cigar_stride=1024):
         tasks = np.ascontiguousarray(tasks, DIST_TASK)

@@ -1,0 +1,178 @@
+// cf_filter.hip - the CF pre-filter of the mapping loops, one candidate per lane.
+//
+// Replaces calculate_CF_128b_SEE_for_dir_and_rc_gen + calculate_CF_128b_SSE_for_a_pattern +
+// test_CF_128b_SSE_difference (mapper/mapping_core_dp.cpp:349-483, mapping_core.h:260-263):
+// the candidate reaches the verifier iff the dinucleotide histograms of the read and of the
+// genome under it, both taken outside the anchor, differ by at most 4k in L1.
+//
+// What the reference's byte walks add up - whatever the parity of the start and of the
+// length - is every adjacent symbol pair that lies inside a region, one-hot per ACGT x ACGT
+// pair (CF_SSE_lut, mapping_core.cpp:196-217; a pair with any other symbol adds nothing),
+// with int8 saturation.  Here a dword of eight 4-bit symbols becomes four class masks (one
+// flag bit per nibble); a pair (X, Y) at position p is "class X at p" & "class Y at p + 1",
+// the latter a funnel shift by one nibble, and sixteen v_bcnt count them.  The other strand
+// is counted in the stored read's own coordinates and the bins are permuted at the end
+// ((a, b) seen from the other strand is (3 - b, 3 - a)).
+#include "wamd_internal.h"
+
+namespace wamd {
+
+struct Classes {
+    uint32_t c[4];   // bit 4p set when symbol p of the dword is A / C / G / T
+};
+
+__device__ __forceinline__ Classes classify(uint32_t s)
+{
+    const uint32_t m = 0x11111111u;
+    const uint32_t valid = ~((s >> 2) | (s >> 3)) & m;
+    const uint32_t b0 = s & m, b1 = (s >> 1) & m;
+    Classes k;
+    k.c[0] = valid & ~b0 & ~b1;
+    k.c[1] = valid & b0 & ~b1;
+    k.c[2] = valid & ~b0 & b1;
+    k.c[3] = valid & b0 & b1;
+    return k;
+}
+
+__device__ __forceinline__ uint32_t low_nibbles(int32_t n)   // flag bits of nibbles 0 .. n-1
+{
+    n = n < 0 ? 0 : (n > 8 ? 8 : n);
+    return n == 8 ? 0x11111111u : (0x11111111u & ((1u << (4 * n)) - 1u));
+}
+
+// flag bits of the positions of dword d that fall into [lo, hi)
+__device__ __forceinline__ uint32_t range_flags(int32_t lo, int32_t hi, int32_t d)
+{
+    return low_nibbles(hi - 8 * d) & ~low_nibbles(lo - 8 * d);
+}
+
+// Adds to cnt the pairs starting in [lo1, hi1) or [lo2, hi2) (symbol indices into `seq`,
+// a packed 4-bit sequence read as dwords 0 .. last_dw).
+template <class Load>
+__device__ __forceinline__ void count_pairs(Load load, int32_t lo1, int32_t hi1, int32_t lo2, int32_t hi2,
+                                            uint32_t (&cnt)[16])
+{
+    const bool r1 = lo1 < hi1, r2 = lo2 < hi2;   // the caller guarantees at least one
+    const int32_t lo = r1 && r2 ? min(lo1, lo2) : (r1 ? lo1 : lo2);
+    const int32_t hi = r1 && r2 ? max(hi1, hi2) : (r1 ? hi1 : hi2);
+    const int32_t first = lo >> 3, last = (hi - 1) >> 3;
+    Classes cur = classify(load(first));
+    // four dwords per round trip: the loads of a batch are independent of each other
+    for (int32_t d0 = first; d0 <= last; d0 += 4) {
+        uint32_t raw[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            raw[q] = load(d0 + 1 + q);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int32_t d = d0 + q;
+            const Classes nxt = classify(raw[q]);
+            if (d <= last) {
+                const uint32_t r = range_flags(lo1, hi1, d) | range_flags(lo2, hi2, d);
+                uint32_t second[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    second[b] = __builtin_amdgcn_alignbit(nxt.c[b], cur.c[b], 4);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const uint32_t fa = cur.c[a] & r;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        cnt[4 * a + b] += (uint32_t)__builtin_popcount(fa & second[b]);
+                }
+            }
+            cur = nxt;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void cf_filter_kernel(GenomeView g, ReadsView rv,
+                                                        const wamd_cf_task* __restrict__ tasks, uint32_t n,
+                                                        uint32_t ref_size, uint32_t cur_offset,
+                                                        uint32_t* __restrict__ results, uint32_t* __restrict__ flags)
+{
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n)
+        return;
+    const wamd_cf_task t = tasks[gid];
+    uint32_t err = 0, m = 0, left_end = 0;
+    const uint32_t plen = t.pattern_len, fl = t.fixed_left, fr = t.fixed_right;
+    if (t.read_idx >= rv.n) {
+        err = FLAG_READ_IDX;
+    } else {
+        m = rv.lens[t.read_idx];
+        // mapping_core_dp.cpp:353-356
+        left_end = t.dir_gen_flag ? t.position - cur_offset : ref_size - t.position - plen + cur_offset;
+        if ((uint32_t)t.read_offset + plen > m || fl > fr || fr > plen || fl == 1 || plen - fr == 1)
+            err = FLAG_ARG;   // a one-symbol region makes the reference's byte walk underflow
+        else if ((uint64_t)left_end + plen + 1 > g.n_symbols)
+            err = FLAG_RANGE;
+    }
+    if (err) {
+        raise_flag(flags, err);
+        results[gid] = RESULT_ERROR;
+        return;
+    }
+
+    // pair starts of the two regions, relative to the window's first symbol
+    const int32_t p_lo1 = 0, p_hi1 = fl ? (int32_t)fl - 1 : 0;
+    const int32_t p_lo2 = (int32_t)fr, p_hi2 = fr != plen ? (int32_t)plen - 1 : (int32_t)fr;
+
+    uint32_t cg[16], cr[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        cg[i] = cr[i] = 0;
+
+    if (p_hi1 > p_lo1 || p_hi2 > p_lo2) {
+        {
+            const int32_t w0 = (int32_t)(left_end & 7u);   // count from the dword the window starts in
+            const uint32_t d0 = left_end >> 3;
+            auto load = [&](int32_t d) -> uint32_t { return load_genome_dword(g, d0 + (uint32_t)d); };
+            count_pairs(load, w0 + p_lo1, w0 + p_hi1, w0 + p_lo2, w0 + p_hi2, cg);
+        }
+        const uint32_t* codes = reinterpret_cast<const uint32_t*>(rv.codes + rv.code_off[t.read_idx]);
+        const int32_t last_dw = (int32_t)((m + 7) / 8) - 1;
+        auto load = [&](int32_t d) -> uint32_t { return d <= last_dw ? nibble_swap(codes[d]) : 0xffffffffu; };
+        if (!(t.flags & WAMD_TASK_FLAG_REV_COMP)) {
+            const int32_t w0 = (int32_t)t.read_offset;
+            count_pairs(load, w0 + p_lo1, w0 + p_hi1, w0 + p_lo2, w0 + p_hi2, cr);
+        } else {
+            // oriented pair start i sits at stored pair start m - 2 - i
+            const int32_t e = (int32_t)m - 1 - (int32_t)t.read_offset;   // one past the stored start of oriented pair 0
+            uint32_t tmp[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                tmp[i] = 0;
+            count_pairs(load, e - p_hi1, e - p_lo1, e - p_hi2, e - p_lo2, tmp);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    cr[4 * (3 - b) + (3 - a)] = tmp[4 * a + b];
+        }
+    }
+
+    // add_saturated on int8 lanes, then horizontal_add(abs(.)) truncated to int8 and
+    // sign-extended (libs/vectori128.h:1496-1502) - compared as unsigned by the caller
+    uint32_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int32_t a = (int32_t)min(cr[i], 127u), b = (int32_t)min(cg[i], 127u);
+        sum += (uint32_t)(a > b ? a - b : b - a);
+    }
+    results[gid] = (uint32_t)(int32_t)(int8_t)(sum & 0xffu);
+}
+
+int launch_cf_filter(wamd_ctx* ctx, const wamd_reads* r, const wamd_cf_task* d_tasks, uint32_t n,
+                     uint32_t* d_results, hipStream_t s)
+{
+    WAMD_HIP(hipSetDevice(ctx->device));
+    if (n == 0)
+        return WAMD_OK;
+    hipLaunchKernelGGL(cf_filter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, genome_view(ctx), r->view(),
+                       d_tasks, n, ctx->ref_size, ctx->cur_offset, d_results, ctx->d_flags);
+    WAMD_HIP(hipGetLastError());
+    return WAMD_OK;
+}
+
+} // namespace wamd

@@ -476,6 +476,43 @@ int wamd_levdiag(wamd_ctx* ctx, const wamd_reads* reads, const wamd_levdiag_task
     return rc ? rc : flags_to_status(flags);
 }
 
+int wamd_cf_filter_dev(wamd_ctx* ctx, const wamd_reads* reads, const wamd_cf_task* d_tasks, uint32_t n,
+                       uint32_t* d_results, void* stream)
+{
+    if (n == 0)
+        return WAMD_OK;
+    int rc = check_batch(ctx, reads, d_tasks, d_results, "wamd_cf_filter_dev");
+    if (rc)
+        return rc;
+    return launch_cf_filter(ctx, reads, d_tasks, n, d_results, stream ? (hipStream_t)stream : ctx->stream);
+}
+
+int wamd_cf_filter(wamd_ctx* ctx, const wamd_reads* reads, const wamd_cf_task* tasks, uint32_t n,
+                   uint32_t* results)
+{
+    if (n == 0)
+        return WAMD_OK;
+    int rc = check_batch(ctx, reads, tasks, results, "wamd_cf_filter");
+    if (rc)
+        return rc;
+    WAMD_HIP(hipSetDevice(ctx->device));
+    const uint64_t tb = (uint64_t)n * sizeof(wamd_cf_task), rb = (uint64_t)n * sizeof(uint32_t);
+    rc = ensure_stage(ctx, tb + rb, 0);
+    if (rc)
+        return rc;
+    auto* d_tasks = (wamd_cf_task*)ctx->d_stage;
+    auto* d_res = (uint32_t*)((char*)ctx->d_stage + tb);
+    hipStream_t s = ctx->stream;
+    WAMD_HIP(hipMemcpyAsync(d_tasks, tasks, tb, hipMemcpyHostToDevice, s));
+    rc = wamd_cf_filter_dev(ctx, reads, d_tasks, n, d_res, s);
+    if (rc)
+        return rc;
+    WAMD_HIP(hipMemcpyAsync(results, d_res, rb, hipMemcpyDeviceToHost, s));
+    uint32_t flags = 0;
+    rc = fetch_flags(ctx, s, &flags);
+    return rc ? rc : flags_to_status(flags);
+}
+
 uint64_t wamd_align_workspace_bytes(const wamd_reads* reads, uint32_t n)
 {
     return reads ? align_workspace_bytes(reads, n) : 0;

@@ -132,6 +132,9 @@ int launch_clip_boundary(wamd_ctx* ctx, uint32_t n, wamd_clip_record* d_records,
 int launch_serialize(wamd_ctx* ctx, uint32_t n, const wamd_mapping* d_mappings, const uint8_t* d_direction,
                      uint8_t* d_out, uint8_t* d_sizes, hipStream_t s);
 
+int launch_cf_filter(wamd_ctx* ctx, const wamd_reads* r, const wamd_cf_task* d_tasks, uint32_t n,
+                     uint32_t* d_results, hipStream_t s);
+
 uint64_t records_scratch_bytes(uint32_t n);
 int launch_emit_lev_records(wamd_ctx* ctx, uint32_t n, const wamd_dist_task* d_tasks,
                             const wamd_dist_result* d_results, const uint32_t* d_record_pos,
