@@ -374,6 +374,28 @@ WAMD_API int wamd_clip_boundary(wamd_ctx* ctx, uint32_t n, wamd_clip_record* rec
 WAMD_API int wamd_clip_boundary_dev(wamd_ctx* ctx, uint32_t n, wamd_clip_record* d_records,
                                     uint8_t* d_cigars, uint32_t cigar_stride, void* stream);
 
+/* What CSamGenerator::extract_cigar_and_mdz / extract_cigarbin_and_mdz leave (sam.cpp:805-928,
+ * 932-1051): lengths of the three outputs of one ext-CIGAR. */
+typedef struct wamd_sam_cigar_len {
+    uint32_t cigar_len;            /* bytes of the text CIGAR, NUL not counted (the return value) */
+    uint32_t mdz_len;              /* bytes of MD:Z, NUL not counted                              */
+    uint32_t cigar_bin_len;        /* BAM operations (count << 4 | op), the other return value    */
+    uint32_t reserved;
+} wamd_sam_cigar_len;
+
+/* Replaces extract_cigar_and_mdz and extract_cigarbin_and_mdz (called at sam.cpp:1352-1357,
+ * 2002-2007, 2174-2179): ext-CIGAR i at ext_cigars + i * ext_stride (NUL-terminated) becomes
+ * the SAM CIGAR text at cigars + i * cigar_stride, MD:Z at mdz + i * mdz_stride (both
+ * NUL-terminated) and, when cigar_bin is not NULL, BAM operations at cigar_bin + i * bin_stride.
+ * A text output can be twice as long as its ext-CIGAR; outputs that do not fit are an error. */
+WAMD_API int wamd_sam_cigar(wamd_ctx* ctx, uint32_t n, const uint8_t* ext_cigars, uint32_t ext_stride,
+                            uint8_t* cigars, uint32_t cigar_stride, uint8_t* mdz, uint32_t mdz_stride,
+                            uint32_t* cigar_bin, uint32_t bin_stride, wamd_sam_cigar_len* lens);
+WAMD_API int wamd_sam_cigar_dev(wamd_ctx* ctx, uint32_t n, const uint8_t* d_ext_cigars, uint32_t ext_stride,
+                                uint8_t* d_cigars, uint32_t cigar_stride, uint8_t* d_mdz, uint32_t mdz_stride,
+                                uint32_t* d_cigar_bin, uint32_t bin_stride, wamd_sam_cigar_len* d_lens,
+                                void* stream);
+
 /* candidate_mapping_t::serialize (results.cpp:161-217): the 5..11-byte wire records
  * that are gathered across GPUs.  sizes[i] bytes are written at out + i * 12;
  * direction[i] != 0 means genome_t::direct. */

@@ -52,6 +52,22 @@ CF_TASK = np.dtype([("read_idx", "<u4"), ("position", "<u4"), ("read_offset", "<
                     ("reserved", "<u2")])
 
 
+SAM_CIGAR_LEN = np.dtype([("cigar_len", "<u4"), ("mdz_len", "<u4"), ("cigar_bin_len", "<u4"), ("reserved", "<u4")])
+
+
+def _sam_cigar(fn, ext_cigars, out_stride=None):
+    ext = np.ascontiguousarray(ext_cigars, np.uint8)
+    n, es = ext.shape
+    os_ = out_stride or 2 * es + 16
+    cig = np.zeros((n, os_), np.uint8)
+    mdz = np.zeros((n, os_), np.uint8)
+    cbin = np.zeros((n, es + 4), np.uint32)
+    lens = np.zeros(n, SAM_CIGAR_LEN)
+    rc = fn(C.c_uint32(n), _p(ext), C.c_uint32(es), _p(cig), C.c_uint32(os_), _p(mdz), C.c_uint32(os_), _p(cbin),
+            C.c_uint32(es + 4), _p(lens))
+    return rc, cig, mdz, cbin, lens
+
+
 class Scoring(C.Structure):  # noqa: E302
     _fields_ = [(n, C.c_double) for n in ("match", "mismatch", "gap_ins_open", "gap_ins_extend",
                                            "gap_del_open", "gap_del_extend", "clipping")]
@@ -130,6 +146,10 @@ class Oracle(_Lib):
         rc = self.lib.wo_cf_batch(_p(genome), C.c_uint32(ref_size), C.c_uint32(cur_offset), _p(reads), _p(offsets),
                                   _p(lens), _p(tasks), C.c_uint32(len(tasks)), _p(res))
         return rc, res
+
+    def sam_cigar(self, ext_cigars, out_stride=None):
+        """ext-CIGAR -> (rc, CIGAR text, MD:Z, BAM ops, lengths), sam.cpp:805-1051."""
+        return _sam_cigar(self.lib.wo_sam_cigar_batch, ext_cigars, out_stride)
 
     def check_ext_cigars(self, genome, reads, offsets, lens, tasks, results, cigars):
         """Independent replay of ext-CIGARs (ASCII reads); returns a failure code per task, 0 = consistent."""
@@ -289,3 +309,10 @@ def _ref_cf_filter(self, genome, ref_size, cur_offset, reads, offsets, lens, tas
 
 
 Reference.cf_filter = _ref_cf_filter
+
+
+def _ref_sam_cigar(self, ext_cigars, out_stride=None):
+    return _sam_cigar(self.lib.ref_sam_cigar_batch, ext_cigars, out_stride)
+
+
+Reference.sam_cigar = _ref_sam_cigar

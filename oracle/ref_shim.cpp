@@ -522,3 +522,26 @@ REF_API int ref_cf_batch(const uint8_t* genome, uint32_t ref_size, uint32_t cur_
     }
     return 0;
 }
+
+
+/* ---- ext-CIGAR -> SAM CIGAR / BAM operations / MD:Z: CSamGenerator members that touch no
+ * member data (sam.cpp:805-928, 932-1051), called on the unconstructed box. */
+REF_API int ref_sam_cigar_batch(uint32_t n, const uint8_t* ext_cigars, uint32_t ext_stride, uint8_t* cigars,
+                                uint32_t cigar_stride, uint8_t* mdz, uint32_t mdz_stride, uint32_t* cigar_bin,
+                                uint32_t bin_stride, wamd_sam_cigar_len* lens)
+{
+    SamGenBox box;
+    std::vector<uint8_t> mdz2(mdz_stride + 16);
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint8_t* ec = ext_cigars + (uint64_t)i * ext_stride;
+        uint8_t* m = mdz + (uint64_t)i * mdz_stride;
+        lens[i].cigar_len = (uint32_t)box.get()->extract_cigar_and_mdz(ec, cigars + (uint64_t)i * cigar_stride, m);
+        lens[i].mdz_len = (uint32_t)strlen((const char*)m);
+        lens[i].cigar_bin_len = (uint32_t)box.get()->extract_cigarbin_and_mdz(ec, cigar_bin + (uint64_t)i * bin_stride,
+                                                                              mdz2.data());
+        lens[i].reserved = 0;
+        if (strcmp((const char*)m, (const char*)mdz2.data()) != 0)
+            return 1;   /* the two routines disagree on MD:Z: would be news */
+    }
+    return 0;
+}

@@ -1628,3 +1628,104 @@ int wo_cf_batch(const uint8_t* genome, uint32_t ref_size, uint32_t cur_offset, c
     free(data_sft);
     return rc;
 }
+
+
+/* ---------------------------------------------- ext-CIGAR -> SAM CIGAR + MD:Z (row X) */
+
+/* CNumericConversions::Int2PChar (common/utils.h:219-): plain decimal, no terminator */
+static int int2pchar(uint32_t v, uint8_t* str)
+{
+    char tmp[12];
+    int n = 0;
+    do {
+        tmp[n++] = (char)('0' + v % 10);
+        v /= 10;
+    } while (v);
+    for (int i = 0; i < n; ++i)
+        str[i] = (uint8_t)tmp[n - 1 - i];
+    return n;
+}
+
+/* CSamGenerator::extract_cigar_and_mdz (sam.cpp:805-928) and extract_cigarbin_and_mdz
+ * (sam.cpp:932-1051) in one pass: the two differ only in how an operation is written. */
+void wo_sam_cigar(const uint8_t* ext_cigar, uint8_t* cigar, uint8_t* mdz, uint32_t* cigar_bin,
+                  wamd_sam_cigar_len* len)
+{
+    enum { Match, Mismatch, Insertion, Deletion, Begin, End, Clipping };
+    enum { M_op, I_op, D_op, N_op, S_op };
+    const uint8_t* ext_c = ext_cigar;
+    uint8_t *cigar_c = cigar, *mdz_c = mdz;
+    uint32_t* bin_c = cigar_bin;
+    int counters[7] = {0};
+    int cnt_match_mismatch = 0, cnt_match_ignoring_insert = 0;
+    int cur = Begin, prev = Begin;
+    while (cur != End) {
+        if (*ext_c == '$') {
+            cur = Clipping;
+            ++ext_c;
+        } else if (*ext_c == 0) {
+            cur = End;
+            if (cnt_match_ignoring_insert > 0)
+                mdz_c += int2pchar((uint32_t)cnt_match_ignoring_insert, mdz_c);
+        } else if (*ext_c == '.') {
+            ++ext_c;
+            cur = Match;
+        } else if (*ext_c == '#') {
+            ext_c += 2;
+            cur = Insertion;
+        } else {
+            mdz_c += int2pchar((uint32_t)cnt_match_ignoring_insert, mdz_c);
+            cnt_match_ignoring_insert = 0;
+            if (*ext_c == '^') {
+                *mdz_c++ = *ext_c++;
+                *mdz_c++ = *ext_c++;
+                cur = Deletion;
+            } else {
+                *mdz_c++ = *ext_c++;
+                cur = Mismatch;
+            }
+        }
+        ++counters[cur];
+        if (cur == Match) {
+            ++cnt_match_mismatch;
+            ++cnt_match_ignoring_insert;
+        } else if (cur == Mismatch) {
+            ++cnt_match_mismatch;
+        }
+        if (cur != prev && prev != Begin) {
+            int count = -1, op = 0;
+            if (prev == Clipping) { count = counters[Clipping]; op = S_op; }
+            else if (prev == Insertion) { count = counters[Insertion]; op = I_op; }
+            else if (prev == Deletion) { count = counters[Deletion]; op = D_op; }
+            else if (prev == Match) {
+                if (cur != Mismatch) { count = cnt_match_mismatch; op = M_op; cnt_match_mismatch = 0; }
+            } else if (prev == Mismatch) {
+                if (cur != Match) { count = cnt_match_mismatch; op = M_op; cnt_match_mismatch = 0; }
+            }
+            if (count >= 0) {
+                cigar_c += int2pchar((uint32_t)count, cigar_c);
+                *cigar_c++ = (uint8_t)"MIDNS"[op];
+                if (bin_c)
+                    *bin_c++ = (uint32_t)count << 4 | (uint32_t)op;
+            }
+            counters[prev] = 0;
+        }
+        prev = cur;
+    }
+    *cigar_c = 0;
+    *mdz_c = 0;
+    len->cigar_len = (uint32_t)(cigar_c - cigar);
+    len->mdz_len = (uint32_t)(mdz_c - mdz);
+    len->cigar_bin_len = cigar_bin ? (uint32_t)(bin_c - cigar_bin) : 0;
+    len->reserved = 0;
+}
+
+int wo_sam_cigar_batch(uint32_t n, const uint8_t* ext_cigars, uint32_t ext_stride, uint8_t* cigars,
+                       uint32_t cigar_stride, uint8_t* mdz, uint32_t mdz_stride, uint32_t* cigar_bin,
+                       uint32_t bin_stride, wamd_sam_cigar_len* lens)
+{
+    for (uint32_t i = 0; i < n; ++i)
+        wo_sam_cigar(ext_cigars + (uint64_t)i * ext_stride, cigars + (uint64_t)i * cigar_stride,
+                     mdz + (uint64_t)i * mdz_stride, cigar_bin ? cigar_bin + (uint64_t)i * bin_stride : NULL, &lens[i]);
+    return 0;
+}

@@ -138,6 +138,13 @@ int wo_cf_batch(const uint8_t* genome, uint32_t ref_size, uint32_t cur_offset, c
                 const uint64_t* offsets, const uint32_t* lens, const wamd_cf_task* tasks, uint32_t n,
                 uint32_t* results);
 
+/* ext-CIGAR -> SAM CIGAR / BAM operations / MD:Z: sam.cpp:805-928, 932-1051 */
+void wo_sam_cigar(const uint8_t* ext_cigar, uint8_t* cigar, uint8_t* mdz, uint32_t* cigar_bin,
+                  wamd_sam_cigar_len* len);
+int wo_sam_cigar_batch(uint32_t n, const uint8_t* ext_cigars, uint32_t ext_stride, uint8_t* cigars,
+                       uint32_t cigar_stride, uint8_t* mdz, uint32_t mdz_stride, uint32_t* cigar_bin,
+                       uint32_t bin_stride, wamd_sam_cigar_len* lens);
+
 #ifdef __cplusplus
 }
 #endif

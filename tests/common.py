@@ -275,3 +275,25 @@ def cf_workload(n, seed, min_len=150, k=5, cur_offset=0, gen=None):
             reads_codes.append(synth.rev_comp(ext))
     blob, off, lens = mixed_reads(reads_codes, 0)
     return codes, packed, (blob, off, lens), tasks
+
+
+def ext_cigar_pool(oracle, n=3000, seed=11, stride=512):
+    """ext-CIGARs of every flavour the post-processing produces: Myers alignments with
+    indels and refinement, the same after boundary clipping ('$'), and a few hand-made
+    corner cases (empty, all clipped, adjacent deletions, insertion at either end)."""
+    codes, packed, (blob, off, lens), tasks = distance_workload(150, 13, n, seed=seed, encoding=1, W=177,
+                                                               true_frac=0.9)
+    rc, res, cig = oracle.align(packed, blob, off, lens, 1, tasks, last_symbol=0, refine=1, cigar_stride=stride)
+    pool = [cig[res["ok"] != 0]]
+    rec, ccig = clip_workload(n // 3, 150, seed + 1)
+    _, rec2, ccig2 = oracle.clip_boundary(rec, ccig)
+    pad = np.zeros((ccig2.shape[0], stride), np.uint8)
+    pad[:, :min(stride, ccig2.shape[1])] = ccig2[:, :stride]
+    pool.append(pad)
+    hand = [b"", b".", b"$$$$", b"^A^C..", b"#A....#C", b"..A^G^T#C#C..", b"$$..T..$", b"AC", b"#A", b"^A",
+            b"....^A....", b".#T.", b"$.$"]
+    hm = np.zeros((len(hand), stride), np.uint8)
+    for i, h in enumerate(hand):
+        hm[i, :len(h)] = np.frombuffer(h, np.uint8)
+    pool.append(hm)
+    return np.ascontiguousarray(np.concatenate(pool))

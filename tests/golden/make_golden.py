@@ -66,6 +66,18 @@ def make_cf(ref, codes, packed, ref_size):
         print(name, "passed", int(ok.sum()), "of", n)
 
 
+def make_sam_cigar(ref):
+    """Row X fixtures: the reference's extract_cigar_and_mdz / extract_cigarbin_and_mdz."""
+    ext = common.ext_cigar_pool(bindings.Oracle(), n=1500, seed=31)
+    keep = np.ones(len(ext), bool)
+    rc, cig, mdz, cbin, lens = ref.sam_cigar(ext)
+    assert rc == 0
+    w = int(lens["cigar_len"].max()) + 1, int(lens["mdz_len"].max()) + 1, int(lens["cigar_bin_len"].max())
+    np.savez_compressed(os.path.join(HERE, "samcigar_pool.npz"), kind="samcigar", ext=ext[keep][:, :384],
+                        cigars=cig[:, :w[0]], mdz=mdz[:, :w[1]], cigar_bin=cbin[:, :w[2]], lens=lens)
+    print("samcigar_pool", len(ext), "ext-CIGARs, longest CIGAR", w[0] - 1, "MD:Z", w[1] - 1)
+
+
 def main():
     ref = bindings.Reference()
     codes = synth.make_genome(GENOME_SYMBOLS, seed=GENOME_SEED)
@@ -73,6 +85,9 @@ def main():
     ref_size = codes.numel()
     if len(sys.argv) > 1 and sys.argv[1] == "cf":   # only the fixtures of this family
         make_cf(ref, codes, packed, ref_size)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "samcigar":
+        make_sam_cigar(ref)
         return
     np.savez_compressed(os.path.join(HERE, "genome.npz"), packed=packed,
                         ref_size=np.uint32(ref_size), reference_version=ref.version())
@@ -138,6 +153,7 @@ def main():
     seed += 1
     rec, cig = common.clip_workload(1200, 150, seed, gen=(codes, packed))
     make_cf(ref, codes, packed, ref_size)
+    make_sam_cigar(ref)
     rc, rec2, cig2 = ref.clip_boundary(rec, cig)
     np.savez_compressed(os.path.join(HERE, "clip_m150.npz"), kind="clip", records=rec, cigars=cig,
                         out_records=rec2, out_cigars=cig2)

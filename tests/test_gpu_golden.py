@@ -94,3 +94,18 @@ def test_clip_boundary(ctx, name):
             np.testing.assert_array_equal(rec[f], want[f], err_msg=f)
     for i in range(len(rec)):
         assert gu.cigar_bytes(cig, i) == gu.cigar_bytes(z["out_cigars"], i), i
+
+def _check_sam_cigar(z, cig, mdz, cbin, lens):
+    np.testing.assert_array_equal(lens, z["lens"])
+    for i in range(len(lens)):
+        a, b, c = int(lens["cigar_len"][i]), int(lens["mdz_len"][i]), int(lens["cigar_bin_len"][i])
+        assert bytes(cig[i, :a]) == bytes(z["cigars"][i, :a])
+        assert bytes(mdz[i, :b]) == bytes(z["mdz"][i, :b])
+        np.testing.assert_array_equal(cbin[i, :c], z["cigar_bin"][i, :c])
+
+
+@pytest.mark.parametrize("name", gu.cases("samcigar"))
+def test_sam_cigar(ctx, name):
+    z = gu.load(name)
+    cig, mdz, cbin, lens = ctx.sam_cigar(z["ext"])
+    _check_sam_cigar(z, cig, mdz, cbin, lens)

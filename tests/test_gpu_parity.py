@@ -304,6 +304,21 @@ def test_clip_boundary(ctx, oracle):
         assert bytes(gcig[i, :n]) == bytes(wcig[i, :n]), i
 
 
+def test_sam_cigar(ctx, oracle):
+    """Row X: SAM CIGAR text, BAM operations and MD:Z from ext-CIGARs of every flavour."""
+    ext = common.ext_cigar_pool(oracle, n=6000, seed=21)
+    rc, wc, wm, wb, wl = oracle.sam_cigar(ext)
+    gc, gm, gb, gl = ctx.sam_cigar(ext)
+    np.testing.assert_array_equal(gl, wl)
+    for i in range(len(ext)):
+        assert bytes(gc[i, :wl["cigar_len"][i] + 1]) == bytes(wc[i, :wl["cigar_len"][i] + 1])
+        assert bytes(gm[i, :wl["mdz_len"][i] + 1]) == bytes(wm[i, :wl["mdz_len"][i] + 1])
+        nb = wl["cigar_bin_len"][i]
+        np.testing.assert_array_equal(gb[i, :nb], wb[i, :nb])
+    with pytest.raises(api.WamdError):             # outputs that cannot fit are an error, not a truncation
+        ctx.sam_cigar(ext[:64], out_stride=16)
+
+
 def test_emit_lev_records(ctx, oracle):
     """Accepted candidates -> 12-byte mapping records in task order (wamd_emit_lev_records_dev)."""
     import torch

@@ -95,3 +95,19 @@ def test_cf_filter(oracle, name):
     assert rc == 0
     np.testing.assert_array_equal(res, z["results"])
     np.testing.assert_array_equal((res <= int(z["max_diff"])).astype(np.uint8), z["passed"])
+
+def _check_sam_cigar(z, cig, mdz, cbin, lens):
+    np.testing.assert_array_equal(lens, z["lens"])
+    for i in range(len(lens)):
+        a, b, c = int(lens["cigar_len"][i]), int(lens["mdz_len"][i]), int(lens["cigar_bin_len"][i])
+        assert bytes(cig[i, :a]) == bytes(z["cigars"][i, :a])
+        assert bytes(mdz[i, :b]) == bytes(z["mdz"][i, :b])
+        np.testing.assert_array_equal(cbin[i, :c], z["cigar_bin"][i, :c])
+
+
+@pytest.mark.parametrize("name", gu.cases("samcigar"))
+def test_sam_cigar(oracle, name):
+    z = gu.load(name)
+    rc, cig, mdz, cbin, lens = oracle.sam_cigar(z["ext"])
+    assert rc == 0
+    _check_sam_cigar(z, cig, mdz, cbin, lens)

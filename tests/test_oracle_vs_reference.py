@@ -126,3 +126,18 @@ def test_cf_filter(oracle, reference, k, cur_offset):
     np.testing.assert_array_equal(a, b)
     np.testing.assert_array_equal(ok, (a <= 4 * k).astype(np.uint8))
     assert 300 < ok.sum() < 2900     # the filter both passes and rejects
+
+
+def test_sam_cigar(oracle, reference):
+    """Row X: extract_cigar_and_mdz / extract_cigarbin_and_mdz (sam.cpp:805-1051)."""
+    ext = common.ext_cigar_pool(oracle)
+    rc1, c1, m1, b1, l1 = oracle.sam_cigar(ext)
+    rc2, c2, m2, b2, l2 = reference.sam_cigar(ext)
+    assert rc1 == 0 and rc2 == 0
+    np.testing.assert_array_equal(l1, l2)
+    for i in range(len(ext)):
+        assert bytes(c1[i, :l1["cigar_len"][i] + 1]) == bytes(c2[i, :l2["cigar_len"][i] + 1])
+        assert bytes(m1[i, :l1["mdz_len"][i] + 1]) == bytes(m2[i, :l2["mdz_len"][i] + 1])
+        nb = l1["cigar_bin_len"][i]
+        np.testing.assert_array_equal(b1[i, :nb], b2[i, :nb])
+    assert (l1["cigar_bin_len"] > 3).sum() > 200       # plenty of multi-operation CIGARs

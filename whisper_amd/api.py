@@ -35,6 +35,7 @@ ALIGN_RESULT = np.dtype([("affine_score", "<f8"), ("ok", "<u4"), ("edit_distance
 CF_TASK = np.dtype([("read_idx", "<u4"), ("position", "<u4"), ("read_offset", "<u2"), ("pattern_len", "<u2"),
                     ("fixed_left", "<u2"), ("fixed_right", "<u2"), ("dir_gen_flag", "u1"), ("flags", "u1"),
                     ("reserved", "<u2")])
+SAM_CIGAR_LEN = np.dtype([("cigar_len", "<u4"), ("mdz_len", "<u4"), ("cigar_bin_len", "<u4"), ("reserved", "<u4")])
 INDEL_TASK = np.dtype([("read_idx", "<u4"), ("ref_pos", "<u4"), ("max_indel_size", "<u2"),
                        ("fixed_segment_pos", "<u2"), ("fixed_segment_size", "<u2"),
                        ("max_no_mismatches", "u1"), ("flags", "u1")])
@@ -67,7 +68,7 @@ EXPORTS = [
     "wamd_levdiag_dev", "wamd_cf_filter", "wamd_cf_filter_dev", "wamd_align", "wamd_align_dev", "wamd_align_workspace_bytes",
     "wamd_indel_match", "wamd_indel_match_dev", "wamd_indel_ext_cigar", "wamd_indel_ext_cigar_dev",
     "wamd_clip_boundary", "wamd_clip_boundary_dev", "wamd_serialize_mappings",
-    "wamd_serialize_mappings_dev", "wamd_records_scratch_bytes", "wamd_emit_lev_records_dev",
+    "wamd_serialize_mappings_dev", "wamd_sam_cigar", "wamd_sam_cigar_dev", "wamd_records_scratch_bytes", "wamd_emit_lev_records_dev",
 ]
 
 
@@ -265,6 +266,20 @@ class Context:
         _check(lib().wamd_clip_boundary(self.h, C.c_uint32(len(rec)), _ptr(rec), _ptr(cig),
                                         C.c_uint32(cig.shape[1])))
         return rec, cig
+
+    def sam_cigar(self, ext_cigars, out_stride=None):
+        """extract_cigar_and_mdz / extract_cigarbin_and_mdz for a batch (sam.cpp:805-1051):
+        returns CIGAR text, MD:Z, BAM operations and the lengths."""
+        ext = np.ascontiguousarray(ext_cigars, np.uint8)
+        n, es = ext.shape
+        os_ = out_stride or 2 * es + 16
+        cig = np.zeros((n, os_), np.uint8)
+        mdz = np.zeros((n, os_), np.uint8)
+        cbin = np.zeros((n, es + 4), np.uint32)
+        lens = np.zeros(n, SAM_CIGAR_LEN)
+        _check(lib().wamd_sam_cigar(self.h, C.c_uint32(n), _ptr(ext), C.c_uint32(es), _ptr(cig), C.c_uint32(os_),
+                                    _ptr(mdz), C.c_uint32(os_), _ptr(cbin), C.c_uint32(es + 4), _ptr(lens)))
+        return cig, mdz, cbin, lens
 
     def serialize_mappings(self, mappings, direction):
         """candidate_mapping_t::serialize for a batch (results.cpp:161-217)."""

@@ -557,6 +557,130 @@ int launch_clip_boundary(wamd_ctx* ctx, uint32_t n, wamd_clip_record* d_records,
     return WAMD_OK;
 }
 
+// ---- ext-CIGAR -> SAM CIGAR text, BAM operations, MD:Z (row X) ------------------------------
+// CSamGenerator::extract_cigar_and_mdz / extract_cigarbin_and_mdz (sam.cpp:805-928, 932-1051):
+// one state machine over the ext-CIGAR bytes; an operation is flushed when the state changes,
+// matches and mismatches share one 'M' run, MD:Z counts matches across insertions and writes
+// the count (also a 0) in front of every mismatch and of EVERY deleted base.
+__device__ __forceinline__ uint32_t put_decimal(uint8_t* dst, uint32_t v)
+{
+    uint32_t n = 1;
+    for (uint32_t t = v; t >= 10; t /= 10)
+        ++n;
+    for (uint32_t i = n; i-- > 0; v /= 10)
+        dst[i] = (uint8_t)('0' + v % 10);
+    return n;
+}
+
+__global__ __launch_bounds__(256) void sam_cigar_kernel(uint32_t n, const uint8_t* __restrict__ ext_cigars,
+                                                        uint32_t ext_stride, uint8_t* __restrict__ cigars,
+                                                        uint32_t cigar_stride, uint8_t* __restrict__ mdz,
+                                                        uint32_t mdz_stride, uint32_t* __restrict__ cigar_bin,
+                                                        uint32_t bin_stride, wamd_sam_cigar_len* __restrict__ lens,
+                                                        uint32_t* __restrict__ flags)
+{
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n)
+        return;
+    enum { Match, Mismatch, Insertion, Deletion, Begin, End, Clipping };
+    const uint8_t* ext = ext_cigars + (uint64_t)gid * ext_stride;
+    uint8_t* cg = cigars + (uint64_t)gid * cigar_stride;
+    uint8_t* md = mdz + (uint64_t)gid * mdz_stride;
+    uint32_t* cb = cigar_bin ? cigar_bin + (uint64_t)gid * bin_stride : nullptr;
+    uint32_t e = 0, c = 0, d = 0, b = 0;       // cursors: ext-CIGAR, CIGAR text, MD:Z, BAM operations
+    uint32_t counters[7] = {0, 0, 0, 0, 0, 0, 0};
+    uint32_t run_m = 0, run_md = 0;            // cnt_match_mismatch, cnt_match_ignoring_insert
+    int cur = Begin, prev = Begin;
+    bool overflow = false;
+    while (cur != End) {
+        const uint32_t ch = e < ext_stride ? ext[e] : 0u;   // a slot without a NUL ends at its stride
+        // 12 bytes of head room cover the longest single step (a count and two symbols)
+        if (c + 12 > cigar_stride || d + 14 > mdz_stride || (cb && b + 1 > bin_stride)) {
+            overflow = true;
+            break;
+        }
+        if (ch == '$') {
+            cur = Clipping;
+            ++e;
+        } else if (ch == 0) {
+            cur = End;
+            if (run_md > 0)
+                d += put_decimal(md + d, run_md);
+        } else if (ch == '.') {
+            ++e;
+            cur = Match;
+        } else if (ch == '#') {
+            e += 2;
+            cur = Insertion;
+        } else {
+            d += put_decimal(md + d, run_md);
+            run_md = 0;
+            if (ch == '^') {
+                md[d++] = (uint8_t)ch;
+                md[d++] = e + 1 < ext_stride ? ext[e + 1] : 0;
+                e += 2;
+                cur = Deletion;
+            } else {
+                md[d++] = (uint8_t)ch;
+                ++e;
+                cur = Mismatch;
+            }
+        }
+        ++counters[cur];
+        if (cur == Match) {
+            ++run_m;
+            ++run_md;
+        } else if (cur == Mismatch) {
+            ++run_m;
+        }
+        if (cur != prev && prev != Begin) {
+            uint32_t count = 0, op = 0;
+            bool flush = false;
+            if (prev == Clipping) {
+                count = counters[Clipping], op = 4, flush = true;    // S_op
+            } else if (prev == Insertion) {
+                count = counters[Insertion], op = 1, flush = true;   // I_op
+            } else if (prev == Deletion) {
+                count = counters[Deletion], op = 2, flush = true;    // D_op
+            } else if ((prev == Match && cur != Mismatch) || (prev == Mismatch && cur != Match)) {
+                count = run_m, op = 0, flush = true;                 // M_op
+                run_m = 0;
+            }
+            if (flush) {
+                c += put_decimal(cg + c, count);
+                cg[c++] = (uint8_t)(0x534e44494dull >> (8 * op));   // "MIDNS"[op]
+                if (cb)
+                    cb[b++] = count << 4 | op;
+            }
+            counters[prev] = 0;
+        }
+        prev = cur;
+    }
+    if (overflow) {
+        raise_flag(flags, FLAG_CIGAR);
+        c = d = b = 0;
+    }
+    cg[c] = 0;
+    md[d] = 0;
+    wamd_sam_cigar_len l;
+    l.cigar_len = c;
+    l.mdz_len = d;
+    l.cigar_bin_len = b;
+    l.reserved = overflow ? 1u : 0u;
+    lens[gid] = l;
+}
+
+int launch_sam_cigar(wamd_ctx* ctx, uint32_t n, const uint8_t* d_ext, uint32_t ext_stride, uint8_t* d_cigars,
+                     uint32_t cigar_stride, uint8_t* d_mdz, uint32_t mdz_stride, uint32_t* d_bin, uint32_t bin_stride,
+                     wamd_sam_cigar_len* d_lens, hipStream_t s)
+{
+    WAMD_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(sam_cigar_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_ext, ext_stride, d_cigars,
+                       cigar_stride, d_mdz, mdz_stride, d_bin, bin_stride, d_lens, ctx->d_flags);
+    WAMD_HIP(hipGetLastError());
+    return WAMD_OK;
+}
+
 int launch_serialize(wamd_ctx* ctx, uint32_t n, const wamd_mapping* d_mappings, const uint8_t* d_direction,
                      uint8_t* d_out, uint8_t* d_sizes, hipStream_t s)
 {

@@ -701,6 +701,63 @@ int wamd_clip_boundary(wamd_ctx* ctx, uint32_t n, wamd_clip_record* records, uin
     return WAMD_OK;
 }
 
+int wamd_sam_cigar_dev(wamd_ctx* ctx, uint32_t n, const uint8_t* d_ext_cigars, uint32_t ext_stride,
+                       uint8_t* d_cigars, uint32_t cigar_stride, uint8_t* d_mdz, uint32_t mdz_stride,
+                       uint32_t* d_cigar_bin, uint32_t bin_stride, wamd_sam_cigar_len* d_lens, void* stream)
+{
+    if (n == 0)
+        return WAMD_OK;
+    if (!ctx || !d_ext_cigars || !d_cigars || !d_mdz || !d_lens || ext_stride == 0 || cigar_stride < 16 ||
+        mdz_stride < 16 || (d_cigar_bin && bin_stride == 0)) {
+        set_error("wamd_sam_cigar_dev: missing buffer or stride too small (outputs need 16 bytes at least)");
+        return WAMD_ERR_INVALID_ARG;
+    }
+    return launch_sam_cigar(ctx, n, d_ext_cigars, ext_stride, d_cigars, cigar_stride, d_mdz, mdz_stride,
+                            d_cigar_bin, bin_stride, d_lens, pick(ctx, stream));
+}
+
+int wamd_sam_cigar(wamd_ctx* ctx, uint32_t n, const uint8_t* ext_cigars, uint32_t ext_stride, uint8_t* cigars,
+                   uint32_t cigar_stride, uint8_t* mdz, uint32_t mdz_stride, uint32_t* cigar_bin,
+                   uint32_t bin_stride, wamd_sam_cigar_len* lens)
+{
+    if (n == 0)
+        return WAMD_OK;
+    if (!ctx || !ext_cigars || !cigars || !mdz || !lens)
+        return WAMD_ERR_INVALID_ARG;
+    WAMD_HIP(hipSetDevice(ctx->device));
+    auto up = [](uint64_t x) { return (x + 255) / 256 * 256; };
+    const uint64_t eb = (uint64_t)n * ext_stride, cb = (uint64_t)n * cigar_stride, mb = (uint64_t)n * mdz_stride,
+                   bb = cigar_bin ? (uint64_t)n * bin_stride * sizeof(uint32_t) : 0,
+                   lb = (uint64_t)n * sizeof(wamd_sam_cigar_len);
+    int rc = ensure_stage(ctx, up(eb) + up(cb) + up(mb) + up(bb) + up(lb), 0);
+    if (rc)
+        return rc;
+    char* base = (char*)ctx->d_stage;
+    auto* d_ext = (uint8_t*)base;
+    auto* d_cig = (uint8_t*)(base + up(eb));
+    auto* d_mdz = (uint8_t*)(base + up(eb) + up(cb));
+    auto* d_bin = cigar_bin ? (uint32_t*)(base + up(eb) + up(cb) + up(mb)) : nullptr;
+    auto* d_len = (wamd_sam_cigar_len*)(base + up(eb) + up(cb) + up(mb) + up(bb));
+    hipStream_t s = ctx->stream;
+    WAMD_HIP(hipMemcpyAsync(d_ext, ext_cigars, eb, hipMemcpyHostToDevice, s));
+    rc = wamd_sam_cigar_dev(ctx, n, d_ext, ext_stride, d_cig, cigar_stride, d_mdz, mdz_stride, d_bin, bin_stride,
+                            d_len, s);
+    if (rc)
+        return rc;
+    WAMD_HIP(hipMemcpyAsync(cigars, d_cig, cb, hipMemcpyDeviceToHost, s));
+    WAMD_HIP(hipMemcpyAsync(mdz, d_mdz, mb, hipMemcpyDeviceToHost, s));
+    if (cigar_bin)
+        WAMD_HIP(hipMemcpyAsync(cigar_bin, d_bin, bb, hipMemcpyDeviceToHost, s));
+    WAMD_HIP(hipMemcpyAsync(lens, d_len, lb, hipMemcpyDeviceToHost, s));
+    uint32_t flags = 0;
+    rc = fetch_flags(ctx, s, &flags);
+    if (!rc && (flags & FLAG_CIGAR)) {
+        set_error("wamd_sam_cigar: an output does not fit its stride");
+        return WAMD_ERR_INVALID_ARG;
+    }
+    return rc ? rc : flags_to_status(flags);
+}
+
 int wamd_serialize_mappings_dev(wamd_ctx* ctx, uint32_t n, const wamd_mapping* d_mappings,
                                 const uint8_t* d_direction, uint8_t* d_out, uint8_t* d_sizes, void* stream)
 {

@@ -135,6 +135,10 @@ int launch_serialize(wamd_ctx* ctx, uint32_t n, const wamd_mapping* d_mappings, 
 int launch_cf_filter(wamd_ctx* ctx, const wamd_reads* r, const wamd_cf_task* d_tasks, uint32_t n,
                      uint32_t* d_results, hipStream_t s);
 
+int launch_sam_cigar(wamd_ctx* ctx, uint32_t n, const uint8_t* d_ext, uint32_t ext_stride, uint8_t* d_cigars,
+                     uint32_t cigar_stride, uint8_t* d_mdz, uint32_t mdz_stride, uint32_t* d_bin, uint32_t bin_stride,
+                     wamd_sam_cigar_len* d_lens, hipStream_t s);
+
 uint64_t records_scratch_bytes(uint32_t n);
 int launch_emit_lev_records(wamd_ctx* ctx, uint32_t n, const wamd_dist_task* d_tasks,
                             const wamd_dist_result* d_results, const uint32_t* d_record_pos,
