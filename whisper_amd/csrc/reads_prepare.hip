@@ -8,42 +8,73 @@
 
 namespace wamd {
 
-// one thread per output byte (two symbols) of the canonical code array
+// one thread per output dword (eight symbols) of the canonical code array
 __global__ __launch_bounds__(256) void canonical_codes_kernel(
     const uint8_t* __restrict__ raw, const uint64_t* __restrict__ raw_off,
     const uint32_t* __restrict__ lens, const uint64_t* __restrict__ code_off, uint32_t n,
-    uint32_t bytes_per_read, int ascii, uint8_t* __restrict__ codes)
+    uint32_t dwords_per_read, int ascii, uint8_t* __restrict__ codes)
 {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t read = (uint32_t)(t / bytes_per_read);
-    const uint32_t b = (uint32_t)(t % bytes_per_read);
+    const uint32_t read = (uint32_t)(t / dwords_per_read);
+    const uint32_t d = (uint32_t)(t % dwords_per_read);
     if (read >= n)
         return;
     const uint32_t len = lens[read];
-    const uint32_t padded = ((len + 1) / 2 + 3) / 4 * 4;
-    if (b >= padded)
+    const uint32_t padded_dw = ((len + 1) / 2 + 3) / 4;
+    if (d >= padded_dw)
         return;
-    uint32_t out = 0xff;   // padding: code 15
-    if (b < (len + 1) / 2) {
-        const uint8_t* src = raw + raw_off[read];
+    const uint8_t* src = raw + raw_off[read];
+    uint32_t out = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        const uint32_t b = 4 * d + k;   // output byte: symbols 2b (high nibble) and 2b + 1
+        uint32_t c0 = 15, c1 = 15;      // padding: code 15
         if (!ascii) {
-            out = src[b];
-            if ((len & 1) && b == len / 2)
-                out |= 0x0f;
-        } else {
-            uint32_t c[2] = {15, 15};
-            for (int h = 0; h < 2; ++h) {
-                const uint32_t i = 2 * b + h;
-                if (i < len) {
-                    const uint32_t ch = src[i];
-                    c[h] = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u
-                         : ch == 'N' ? 4u : 6u;
-                }
+            if (2 * b < len) {
+                const uint32_t x = src[b];
+                c0 = x >> 4;
+                if (2 * b + 1 < len)
+                    c1 = x & 15u;
             }
-            out = (c[0] << 4) | c[1];
+        } else {
+            // raw_code, LevMyers64.cpp:50-60: ACGT 0..3, N 4, anything else 6
+            auto code = [](uint32_t ch) -> uint32_t {
+                return ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : ch == 'N' ? 4u : 6u;
+            };
+            if (2 * b < len)
+                c0 = code(src[2 * b]);
+            if (2 * b + 1 < len)
+                c1 = code(src[2 * b + 1]);
         }
+        out |= ((c0 << 4) | c1) << (8 * k);
     }
-    codes[code_off[read] + b] = (uint8_t)out;
+    *reinterpret_cast<uint32_t*>(codes + code_off[read] + 4ull * d) = out;
+}
+
+// Eight symbols i0 .. i0+7 of a read in the orientation asked for, symbol k at bits 4k; symbols
+// outside the read come back as code 15.  codes: the read's canonical dwords (padded with 15).
+__device__ __forceinline__ uint32_t oriented_group8(const uint32_t* codes, uint32_t len, bool rc, int32_t i0)
+{
+    const int32_t last_dw = (int32_t)((len + 7) / 8) - 1;
+    auto dw = [&](int32_t q) -> uint32_t { return (q < 0 || q > last_dw) ? 0xffffffffu : nibble_swap(codes[q]); };
+    auto window = [&](int32_t a) -> uint32_t {   // stored symbols a .. a+7
+        const int32_t q = a >> 3;                // floor: a may be negative
+        const uint32_t sh = (uint32_t)(a & 7) * 4u;
+        return __builtin_amdgcn_alignbit(dw(q + 1), dw(q), sh);
+    };
+    if (!rc)
+        return window(i0);
+    // oriented symbol i = rc_code(stored[len-1-i]): take stored len-8-i0 .. len-1-i0 and reverse
+    uint32_t w = window((int32_t)len - 8 - i0);
+    w = __builtin_bswap32(w);
+    w = ((w & 0x0f0f0f0fu) << 4) | ((w >> 4) & 0x0f0f0f0fu);
+    // rc_code per nibble (LevMyers64.cpp:40-48): c < 4 -> 3 - c, c < 8 -> c, else 7
+    const uint32_t m = 0x11111111u;
+    const uint32_t ge8 = (w >> 3) & m, ge4 = ((w >> 2) | (w >> 3)) & m;
+    const uint32_t lt4 = ~ge4 & m;
+    w ^= lt4 * 3u;                       // 3 - c for A, C, G, T
+    w = (w & ~(ge8 * 15u)) | (ge8 * 7u);
+    return w;
 }
 
 // one thread per (read, slot, word)
@@ -60,18 +91,24 @@ __global__ __launch_bounds__(256) void pattern_vectors_kernel(ReadsView rv, uint
     const bool rc = ((int32_t)slot == rv.slot_rc);
     const uint32_t len = rv.lens[read];
     const uint8_t* codes = rv.codes + rv.code_off[read];
+    const uint32_t* code_dw = reinterpret_cast<const uint32_t*>(codes);
     uint64_t row[4] = {0, 0, 0, 0};
     uint32_t presence = 0;
     const uint32_t lo = w * 64, hi = min(len, lo + 64);
-    for (uint32_t i = lo; i < hi; ++i) {
-        // LevMyers64.cpp:176-190 / 206-217
-        const uint32_t c = rc ? rc_code(packed_symbol(codes, len - 1 - i)) : packed_symbol(codes, i);
-        const uint64_t bit = 1ull << (i - lo);
-        row[0] |= c == 0 ? bit : 0;
-        row[1] |= c == 1 ? bit : 0;
-        row[2] |= c == 2 ? bit : 0;
-        row[3] |= c == 3 ? bit : 0;
-        presence |= 1u << c;
+    for (uint32_t g0 = lo; g0 < hi; g0 += 8) {
+        const uint32_t syms = oriented_group8(code_dw, len, rc, (int32_t)g0);
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) {
+            // LevMyers64.cpp:176-190 / 206-217
+            const uint32_t i = g0 + k;
+            const uint32_t c = (syms >> (4 * k)) & 15u;
+            const uint64_t bit = i < hi ? 1ull << (i - lo) : 0ull;
+            row[0] |= c == 0 ? bit : 0;
+            row[1] |= c == 1 ? bit : 0;
+            row[2] |= c == 2 ? bit : 0;
+            row[3] |= c == 3 ? bit : 0;
+            presence |= i < hi ? 1u << c : 0u;
+        }
     }
     uint64_t* dst = pm + ((uint64_t)(read * (uint64_t)rv.n_orient + slot) * 4) * rv.words + w;
     for (int c = 0; c < 4; ++c)
@@ -99,21 +136,22 @@ __global__ __launch_bounds__(256) void pattern_vectors32_kernel(ReadsView rv, ui
     const uint32_t len = rv.lens[read];
     const uint8_t* codes = rv.codes + rv.code_off[read];
     const int32_t phantom = (int32_t)(32 * rv.words32 - len);   // rows below the read's first symbol
+    const uint32_t* code_dw = reinterpret_cast<const uint32_t*>(codes);
     uint32_t row[4] = {0, 0, 0, 0};
-    for (int32_t b = 0; b < 32; ++b) {
-        const int32_t i = (int32_t)(32 * j) + b - phantom;
-        const uint32_t bit = 1u << b;
-        if (i < 0) {
-            // a phantom row matches every text symbol: D stays 0 down to the read's row 0
-            row[0] |= bit;
-            row[1] |= bit;
-            row[2] |= bit;
-            row[3] |= bit;
-        } else {
-            const uint32_t c = rc ? rc_code(packed_symbol(codes, len - 1 - (uint32_t)i))
-                                  : packed_symbol(codes, (uint32_t)i);
-            if (c < 4)
-                row[c] |= bit;
+    const int32_t i0 = (int32_t)(32 * j) - phantom;
+#pragma unroll
+    for (int32_t g0 = 0; g0 < 32; g0 += 8) {
+        const uint32_t syms = i0 + g0 + 7 < 0 ? 0u : oriented_group8(code_dw, len, rc, i0 + g0);
+#pragma unroll
+        for (int32_t k = 0; k < 8; ++k) {
+            const int32_t i = i0 + g0 + k;
+            const uint32_t bit = 1u << (g0 + k);
+            // a phantom row (i < 0) matches every text symbol: D stays 0 down to the read's row 0
+            const uint32_t c = (syms >> (4 * k)) & 15u;
+            row[0] |= (i < 0 || c == 0) ? bit : 0;
+            row[1] |= (i < 0 || c == 1) ? bit : 0;
+            row[2] |= (i < 0 || c == 2) ? bit : 0;
+            row[3] |= (i < 0 || c == 3) ? bit : 0;
         }
     }
     uint32_t* dst = pm32 + ((uint64_t)(read * (uint64_t)rv.n_orient + slot) * 4) * rv.words32 + j;
@@ -125,12 +163,12 @@ int launch_reads_prepare(wamd_ctx* ctx, wamd_reads* r, const uint8_t* d_raw,
                          const uint64_t* d_raw_off, hipStream_t s)
 {
     (void)ctx;
-    const uint32_t bytes_per_read = ((r->max_len + 1) / 2 + 3) / 4 * 4;
+    const uint32_t dwords_per_read = ((r->max_len + 1) / 2 + 3) / 4;
     {
-        const uint64_t threads = (uint64_t)r->n * bytes_per_read;
+        const uint64_t threads = (uint64_t)r->n * dwords_per_read;
         const uint32_t blocks = (uint32_t)((threads + 255) / 256);
         hipLaunchKernelGGL(canonical_codes_kernel, dim3(blocks), dim3(256), 0, s, d_raw, d_raw_off,
-                           r->d_lens, r->d_code_off, r->n, bytes_per_read,
+                           r->d_lens, r->d_code_off, r->n, dwords_per_read,
                            r->encoding == WAMD_READS_ASCII ? 1 : 0, r->d_codes);
         WAMD_HIP(hipGetLastError());
     }
