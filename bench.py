@@ -229,7 +229,10 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    # WAMD_BENCH_FORCE_GATHER=1 rehearses the multi-rank code path (process group, record
+    # emission, gather) with whatever world size the launcher gives, also 1
+    multi = world > 1 or os.environ.get("WAMD_BENCH_FORCE_GATHER") == "1"
+    if multi:
         import torch.distributed as dist_mod
         dist = dist_mod
         dist.init_process_group("nccl", device_id=device)
@@ -266,7 +269,7 @@ def main():
 
     def step():
         verify()
-        if world > 1:
+        if multi:
             gather_records()
 
     for _ in range(args.warmup):
@@ -284,7 +287,7 @@ def main():
         a.record(stream)
         verify()
         b.record(stream)
-        if world > 1:
+        if multi:
             gather_records()
     ctx.synchronize()
     torch.cuda.synchronize()
