@@ -260,12 +260,24 @@ def main():
     d_count = torch.zeros(1, dtype=torch.int32, device=device)
     d_scratch = torch.zeros(ctx.records_scratch_bytes(n), dtype=torch.uint8, device=device)
 
+    # The gather of bin i stays in flight while bin i + 1 is verified (its block is a copy,
+    # so the next emission may overwrite d_records); the last one is waited for before the clock stops.
+    in_flight = [None]
+
     def gather_records():
         ctx.emit_lev_records_dev(n, d_tasks, d_results, d_rec_pos, d_dir, d_records, d_count, d_scratch)
         with torch.cuda.stream(stream):
             cnt = int(d_count.item())
-            out = gather.gather_records(d_records, cnt, dst=0)
-        return out
+            nxt = gather.gather_records(d_records, cnt, dst=0, async_op=True)
+            if in_flight[0] is not None:
+                in_flight[0].result()
+            in_flight[0] = nxt
+
+    def finish_gathers():
+        if in_flight[0] is not None:
+            with torch.cuda.stream(stream):
+                in_flight[0].result()
+            in_flight[0] = None
 
     def step():
         verify()
@@ -274,6 +286,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    finish_gathers()
     ctx.synchronize()
     torch.cuda.synchronize()
     if dist:
@@ -289,6 +302,7 @@ def main():
         b.record(stream)
         if multi:
             gather_records()
+    finish_gathers()
     ctx.synchronize()
     torch.cuda.synchronize()
     if dist:

@@ -34,6 +34,30 @@ def _worker(rank, world, port, counts, q):
         dist.destroy_process_group()
 
 
+def _worker_pipelined(rank, world, port, rounds, q):
+    """bench.py's pattern: the gather of bin i is in flight while bin i + 1 is produced."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pending, outs = None, []
+        for i, counts in enumerate(rounds):
+            rec = torch.from_numpy(_records(rank + 10 * i, counts[rank]))
+            nxt = gather.gather_records(rec, counts[rank], dst=0, async_op=True)
+            rec.zero_()                      # the caller may overwrite its buffer at once
+            if pending is not None:
+                outs.append(pending.result())
+            pending = nxt
+        outs.append(pending.result())
+        if rank == 0:
+            q.put([[o.numpy().copy() for o in out] for out in outs])
+        else:
+            assert all(o is None for o in outs)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -56,6 +80,23 @@ def test_gather_two_ranks():
             assert p.exitcode == 0
         for r in range(2):
             np.testing.assert_array_equal(got[r], _records(r, counts[r])[: counts[r]])
+
+
+def test_gather_pipelined_two_ranks():
+    rounds = [[7, 3], [0, 11], [5, 5], [4, 0]]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_pipelined, args=(r, 2, port, rounds, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for i, counts in enumerate(rounds):
+        for r in range(2):
+            np.testing.assert_array_equal(got[i][r], _records(r + 10 * i, counts[r])[: counts[r]])
 
 
 def test_shard_bins_partition():

@@ -7,11 +7,28 @@ import torch.distributed as dist
 RECORD_BYTES = 12   # include/whisper_amd.h: wamd_emit_lev_records_dev
 
 
-def gather_records(records, count, dst=0, group=None):
+class PendingGather:
+    """A gather in flight (gather_records(..., async_op=True)): result() waits for it and
+    returns what gather_records would have; the buffers live as long as this object."""
+
+    def __init__(self, work, out, counts, rank, dst, block):
+        self.work, self.out, self.counts, self.rank, self.dst, self.block = work, out, counts, rank, dst, block
+
+    def result(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        if self.rank != self.dst:
+            return None
+        return [self.out[r][: self.counts[r]] for r in range(len(self.counts))]
+
+
+def gather_records(records, count, dst=0, group=None, async_op=False):
     """records: uint8 tensor [capacity, RECORD_BYTES] on this rank's device, the first
     `count` rows valid.  Returns on rank dst the list of every rank's valid rows (in rank
     order), on the other ranks None.  Two collectives: an all_gather of the counts, then a
-    gather of blocks padded to the largest count."""
+    gather of blocks padded to the largest count.  With async_op the gather itself is left
+    in flight (a PendingGather): the caller verifies its next bin meanwhile."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = records.device
@@ -23,10 +40,9 @@ def gather_records(records, count, dst=0, group=None):
     block = torch.zeros((mx, RECORD_BYTES), dtype=torch.uint8, device=dev)
     block[: counts[rank]] = records[: counts[rank]]
     out = [torch.zeros_like(block) for _ in range(world)] if rank == dst else None
-    dist.gather(block, out, dst=dst, group=group)
-    if rank != dst:
-        return None
-    return [out[r][: counts[r]] for r in range(world)]
+    work = dist.gather(block, out, dst=dst, group=group, async_op=async_op)
+    pending = PendingGather(work if async_op else None, out, counts, rank, dst, block)
+    return pending if async_op else pending.result()
 
 
 def shard_bins(n_bins, world, rank):
