@@ -374,6 +374,52 @@ WAMD_API int wamd_clip_boundary(wamd_ctx* ctx, uint32_t n, wamd_clip_record* rec
 WAMD_API int wamd_clip_boundary_dev(wamd_ctx* ctx, uint32_t n, wamd_clip_record* d_records,
                                     uint8_t* d_cigars, uint32_t cigar_stride, void* stream);
 
+/* What CSoftClipping::clipIllegalPositions (soft_clipping.cpp:592-729) reads besides the
+ * record: the length of the record's chromosome with its N borders
+ * (seq_desc: size + no_initial_Ns + no_final_Ns, soft_clipping.cpp:594-595), the read length,
+ * and whether the mapping came from a perfect match (method Perfect / PerfectDistant), in
+ * which case it has no ext-CIGAR yet and one of read_length '.' is made first (614-618). */
+typedef struct wamd_clip_illegal_task {
+    int32_t ref_size;
+    uint16_t read_length;
+    uint16_t perfect;
+} wamd_clip_illegal_task;
+
+/* Replaces softClipping->clipIllegalPositions(hit, scoring, seq_desc, pool) (sam.cpp:1339, 1889;
+ * sam_matching.cpp:451-452, 599-600, 655): the part of a mapping that hangs over either end of
+ * its chromosome becomes '$'; score and err_edit_distance are recomputed from what is left.
+ * Records and ext-CIGARs are rewritten in place; no_clippings = sides that hung over (0 = the
+ * record was left alone).  The routine's own habits are kept: the tail loop does not advance
+ * its input on an ordinary symbol (it pads with '$' up to read_length), and a '$' already in
+ * the kept part is scored as a mismatch. */
+WAMD_API int wamd_clip_illegal(wamd_ctx* ctx, uint32_t n, const wamd_clip_illegal_task* tasks,
+                               wamd_clip_record* records, uint8_t* cigars, uint32_t cigar_stride);
+WAMD_API int wamd_clip_illegal_dev(wamd_ctx* ctx, uint32_t n, const wamd_clip_illegal_task* d_tasks,
+                                   wamd_clip_record* d_records, uint8_t* d_cigars, uint32_t cigar_stride,
+                                   void* stream);
+
+/* What CSoftClipping::clipOverlappingPairs (soft_clipping.cpp:997-1044) reads of the two
+ * mappings of a pair besides their records; index 0 = p.first, 1 = p.second. */
+typedef struct wamd_clip_pair_task {
+    int32_t ref_seq_id[2];
+    uint16_t read_length[2];
+    uint8_t direct[2];             /* mapping.direction == genome_t::direct                 */
+    uint8_t perfect[2];            /* method Perfect / PerfectDistant                       */
+} wamd_clip_pair_task;
+
+/* Replaces softClipping->clipOverlappingPairs(mp, scoring, pool) (sam.cpp:1898-1900) with its
+ * clipLeft / clipRight (soft_clipping.cpp:1047-1151): when the reverse read lies left of the
+ * forward read and overlaps it, the left read loses what precedes the right read's start and
+ * the right read what follows the left read's end.  Pair i owns records 2i (p.first) and
+ * 2i + 1 (p.second) and the ext-CIGAR slots of the same indices; no_clippings of both records
+ * is 1 when the pair was clipped.  A record whose ref_length disagrees with its ext-CIGAR
+ * (the reference would run off the string) raises the malformed-task flag. */
+WAMD_API int wamd_clip_overlapping_pairs(wamd_ctx* ctx, uint32_t n_pairs, const wamd_clip_pair_task* tasks,
+                                         wamd_clip_record* records, uint8_t* cigars, uint32_t cigar_stride);
+WAMD_API int wamd_clip_overlapping_pairs_dev(wamd_ctx* ctx, uint32_t n_pairs, const wamd_clip_pair_task* d_tasks,
+                                             wamd_clip_record* d_records, uint8_t* d_cigars,
+                                             uint32_t cigar_stride, void* stream);
+
 /* What CSamGenerator::extract_cigar_and_mdz / extract_cigarbin_and_mdz leave (sam.cpp:805-928,
  * 932-1051): lengths of the three outputs of one ext-CIGAR. */
 typedef struct wamd_sam_cigar_len {

@@ -316,3 +316,51 @@ def _ref_sam_cigar(self, ext_cigars, out_stride=None):
 
 
 Reference.sam_cigar = _ref_sam_cigar
+
+
+# ---- row L: clipIllegalPositions / clipOverlappingPairs (soft_clipping.cpp:592-729, 997-1151)
+CLIP_ILLEGAL_TASK = np.dtype([("ref_size", "<i4"), ("read_length", "<u2"), ("perfect", "<u2")])
+CLIP_PAIR_TASK = np.dtype([("ref_seq_id", "<i4", (2,)), ("read_length", "<u2", (2,)), ("direct", "u1", (2,)),
+                           ("perfect", "u1", (2,))])
+assert CLIP_ILLEGAL_TASK.itemsize == 8 and CLIP_PAIR_TASK.itemsize == 16
+
+
+def _clip_illegal(fn, tasks, records, cigars, scoring=None):
+    sc = scoring or default_scoring()
+    t = np.ascontiguousarray(tasks, CLIP_ILLEGAL_TASK)
+    rec = np.array(records, CLIP_RECORD, copy=True)
+    cig = np.array(cigars, np.uint8, copy=True)
+    rc = fn(C.c_uint32(len(rec)), _p(t), _p(rec), _p(cig), C.c_uint32(cig.shape[1]), C.byref(sc))
+    return rc, rec, cig
+
+
+def _clip_pairs(fn, tasks, records, cigars, *extra):
+    t = np.ascontiguousarray(tasks, CLIP_PAIR_TASK)
+    rec = np.array(records, CLIP_RECORD, copy=True)
+    cig = np.array(cigars, np.uint8, copy=True)
+    assert len(rec) == 2 * len(t) and len(cig) == len(rec)
+    rc = fn(C.c_uint32(len(t)), _p(t), _p(rec), _p(cig), C.c_uint32(cig.shape[1]), *extra)
+    return rc, rec, cig
+
+
+def _o_clip_illegal(self, tasks, records, cigars, scoring=None):
+    return _clip_illegal(self.lib.wo_clip_illegal_batch, tasks, records, cigars, scoring)
+
+
+def _o_clip_pairs(self, tasks, records, cigars):
+    return _clip_pairs(self.lib.wo_clip_pairs_batch, tasks, records, cigars)
+
+
+def _r_clip_illegal(self, tasks, records, cigars, scoring=None):
+    return _clip_illegal(self.lib.ref_clip_illegal_batch, tasks, records, cigars, scoring)
+
+
+def _r_clip_pairs(self, tasks, records, cigars, scoring=None):
+    sc = scoring or default_scoring()
+    return _clip_pairs(self.lib.ref_clip_pairs_batch, tasks, records, cigars, C.byref(sc))
+
+
+Oracle.clip_illegal = _o_clip_illegal
+Oracle.clip_overlapping_pairs = _o_clip_pairs
+Reference.clip_illegal = _r_clip_illegal
+Reference.clip_overlapping_pairs = _r_clip_pairs

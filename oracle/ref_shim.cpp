@@ -545,3 +545,93 @@ REF_API int ref_sam_cigar_batch(uint32_t n, const uint8_t* ext_cigars, uint32_t 
     }
     return 0;
 }
+
+
+/* ---- clipIllegalPositions / clipOverlappingPairs (soft_clipping.cpp:592-729, 997-1151).
+ * Perfect mappings get their ext-CIGAR from the pool inside the call, as in the reference;
+ * the string is copied to the caller's slot afterwards. */
+namespace {
+void load_desc(mapping_desc_t& md, const wamd_clip_record& r, uint8_t* ec)
+{
+    md.ext_cigar = ec;
+    md.score = r.score;
+    md.ref_seq_pos = r.ref_seq_pos;
+    md.ref_length = r.ref_length;
+    md.err_edit_distance = r.err_edit_distance;
+    md.left_clipping = r.left_clipping;
+    md.right_clipping = r.right_clipping;
+}
+
+void store_desc(const mapping_desc_t& md, wamd_clip_record& r, uint8_t* ec, uint32_t stride,
+                CMemoryPool<uchar_t>& pool)
+{
+    r.score = md.score;
+    r.ref_seq_pos = md.ref_seq_pos;
+    r.ref_length = md.ref_length;
+    r.err_edit_distance = md.err_edit_distance;
+    r.left_clipping = md.left_clipping;
+    r.right_clipping = md.right_clipping;
+    if (md.ext_cigar != ec) {
+        strncpy((char*)ec, (const char*)md.ext_cigar, stride - 1);
+        ec[stride - 1] = 0;
+        pool.Free(md.ext_cigar);
+    }
+    r.cigar_len = (uint32_t)strlen((const char*)ec);
+}
+} // namespace
+
+REF_API int ref_clip_illegal_batch(uint32_t n, const wamd_clip_illegal_task* tasks, wamd_clip_record* records,
+                                   uint8_t* cigars, uint32_t cigar_stride, const wamd_scoring* sc)
+{
+    CSoftClipping clip(512, 16384, 3, 50, 0);
+    scoring_t scoring = make_scoring(sc);
+    CMemoryPool<uchar_t> pool(8 * (int64_t)cigar_stride, cigar_stride, "shim");
+    std::vector<seq_desc_t> desc(1);
+    for (uint32_t i = 0; i < n; ++i) {
+        wamd_clip_record& r = records[i];
+        uint8_t* ec = cigars + (size_t)i * cigar_stride;
+        mapping_desc_t md;
+        load_desc(md, r, ec);
+        md.ref_seq_id = 0;
+        md.read_length = tasks[i].read_length;
+        md.method = tasks[i].perfect ? MatchingMethod::Enumeration::Perfect : MatchingMethod::Enumeration::LevMyers;
+        desc[0].size = (uint64_t)tasks[i].ref_size;
+        desc[0].no_initial_Ns = desc[0].no_final_Ns = 0;
+        const int32_t pos0 = md.ref_seq_pos;
+        const uint16_t l0 = md.left_clipping, r0 = md.right_clipping;
+        clip.clipIllegalPositions(md, scoring, desc, pool);
+        r.no_clippings = (uint32_t)((md.left_clipping != l0) + (md.right_clipping != r0));
+        (void)pos0;
+        store_desc(md, r, ec, cigar_stride, pool);
+    }
+    return 0;
+}
+
+REF_API int ref_clip_pairs_batch(uint32_t n_pairs, const wamd_clip_pair_task* tasks, wamd_clip_record* records,
+                                 uint8_t* cigars, uint32_t cigar_stride, const wamd_scoring* sc)
+{
+    CSoftClipping clip(512, 16384, 3, 50, 0);
+    scoring_t scoring = make_scoring(sc);
+    CMemoryPool<uchar_t> pool(8 * (int64_t)cigar_stride, cigar_stride, "shim");
+    for (uint32_t i = 0; i < n_pairs; ++i) {
+        mapping_desc_t md[2];
+        uint8_t* ec[2];
+        for (int q = 0; q < 2; ++q) {
+            ec[q] = cigars + (size_t)(2 * i + q) * cigar_stride;
+            load_desc(md[q], records[2 * i + q], ec[q]);
+            md[q].ref_seq_id = tasks[i].ref_seq_id[q];
+            md[q].read_length = tasks[i].read_length[q];
+            md[q].mapping.direction = tasks[i].direct[q] ? genome_t::direct : genome_t::rev_comp;
+            md[q].method = tasks[i].perfect[q] ? MatchingMethod::Enumeration::Perfect : MatchingMethod::Enumeration::LevMyers;
+        }
+        const int32_t len0[2] = {md[0].ref_length, md[1].ref_length};
+        const uint16_t clip0 = md[0].left_clipping + md[0].right_clipping + md[1].left_clipping + md[1].right_clipping;
+        mapping_pair_t p(&md[0], &md[1]);
+        clip.clipOverlappingPairs(p, scoring, pool);
+        (void)len0;
+        (void)clip0;
+        for (int q = 0; q < 2; ++q)
+            store_desc(md[q], records[2 * i + q], ec[q], cigar_stride, pool);
+    }
+    return 0;
+}

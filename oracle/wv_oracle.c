@@ -1316,6 +1316,283 @@ void wo_clip_boundary(wamd_clip_record* d, uint8_t* ext_cigar, const wamd_scorin
     d->cigar_len = (uint32_t)strlen((const char*)ext_cigar);
 }
 
+/* ---- clipIllegalPositions ----------------------------------------------------- */
+
+static uint32_t bounded_len(const uint8_t* ec, uint32_t stride)
+{
+    uint32_t l = 0;
+    while (l < stride && ec[l])
+        ++l;
+    return l;
+}
+
+int wo_clip_illegal(wamd_clip_record* d, const wamd_clip_illegal_task* t, uint8_t* ec, uint32_t stride,
+                    const wamd_scoring* sc)
+{
+    const int32_t ref_size = t->ref_size;                                   /* 594-595 */
+    const int32_t mapping_last = d->ref_seq_pos + (int32_t)d->ref_length - 1; /* 596 */
+    int to_left = 0, to_right = 0;
+    int i_read = 0, i_ref = d->ref_seq_pos;
+    const int read_length = t->read_length;
+    int bad = 0;
+    d->no_clippings = 0;
+    if (d->ref_seq_pos <= 0) /* 604-606 */
+        to_left = -d->ref_seq_pos + 1;
+    if (mapping_last > ref_size) /* 608-610 */
+        to_right = mapping_last - ref_size;
+    if (!to_left && !to_right) {
+        d->cigar_len = bounded_len(ec, stride);
+        return 0;
+    }
+    if ((uint32_t)read_length + 1 > stride)
+        return 1;
+    if (t->perfect) { /* 614-618 */
+        memset(ec, '.', (size_t)read_length);
+        ec[read_length] = 0;
+    }
+    d->left_clipping = (uint16_t)(d->left_clipping + to_left); /* 620-625 */
+    d->right_clipping = (uint16_t)(d->right_clipping + to_right);
+    d->ref_length = (uint16_t)(d->ref_length - (to_left + to_right));
+    d->ref_seq_pos += to_left;
+    d->err_edit_distance = 0;
+    d->score = 0;
+    d->no_clippings = (uint32_t)((to_left != 0) + (to_right != 0));
+
+    uint32_t in = 0, out = 0;
+    const uint32_t lim = stride - 1; /* last byte that may hold the NUL */
+#define AT(i) ((i) < stride ? ec[i] : 0)
+    while (i_ref < 1 && AT(in)) { /* 632-652 */
+        if (ec[in] == '^') {
+            in += 2;
+            ++i_ref;
+        } else if (ec[in] == '#') {
+            in += 2;
+            ec[out++] = '$';
+            ++i_read;
+        } else {
+            ++in;
+            ec[out++] = '$';
+            ++i_read;
+            ++i_ref;
+        }
+    }
+    int gap_opened = 0;
+    while (i_read < read_length && i_ref <= ref_size && AT(in)) { /* 655-703 */
+        const uint8_t c = ec[in];
+        if (c == '^' || c == '#') {
+            if (in + 1 >= lim) {
+                bad = 1;
+                break;
+            }
+            ec[out++] = ec[in++];
+            ec[out++] = ec[in++];
+            d->err_edit_distance++;
+            if (c == '^') {
+                ++i_ref;
+                d->score += gap_opened ? sc->gap_del_extend : sc->gap_del_open;
+            } else {
+                ++i_read;
+                d->score += gap_opened ? sc->gap_ins_extend : sc->gap_ins_open;
+            }
+            gap_opened = 1;
+        } else {
+            if (c == '.')
+                d->score += sc->match;
+            else {
+                d->score += sc->mismatch;
+                d->err_edit_distance++;
+            }
+            ec[out++] = ec[in++];
+            ++i_read;
+            ++i_ref;
+            gap_opened = 0;
+        }
+    }
+    while (!bad && i_read < read_length && AT(in)) { /* 706-725 */
+        if (ec[in] == '^') {
+            in += 2;
+            ++i_ref;
+        } else if (ec[in] == '#') {
+            in += 2;
+            ec[out++] = '$';
+            ++i_read;
+        } else { /* 719-724: `in` stays where it is - the rest of the read is padded with '$' */
+            if (out >= lim) {
+                bad = 1;
+                break;
+            }
+            ec[out++] = '$';
+            ++i_read;
+            ++i_ref;
+        }
+    }
+#undef AT
+    if (out > lim)
+        out = lim;
+    ec[out] = 0; /* 727 */
+    d->cigar_len = out;
+    return bad;
+}
+
+/* ---- clipOverlappingPairs, clipLeft, clipRight --------------------------------- */
+
+static int wo_isalpha(uint8_t c) { return (uint8_t)((c | 32) - 'a') < 26; }
+
+static int clip_left(wamd_clip_record* d, uint8_t* ec, uint32_t stride, int count) /* 1047-1098 */
+{
+    uint32_t in = d->left_clipping, out = in;
+    int clipped = 0;
+#define AT(i) ((i) < stride ? ec[i] : 0)
+    while (clipped < count || (clipped == count && AT(in) == '#')) {
+        const uint8_t c = AT(in);
+        if (c == '.') {
+            ec[out++] = '$';
+            ++in;
+            ++d->left_clipping;
+            ++d->ref_seq_pos;
+            --d->ref_length;
+            ++clipped;
+        } else if (c == '#') {
+            ec[out++] = '$';
+            in += 2;
+            ++d->left_clipping;
+            --d->err_edit_distance;
+        } else if (c == '^') {
+            in += 2;
+            ++d->ref_seq_pos;
+            --d->ref_length;
+            --d->err_edit_distance;
+            ++clipped;
+        } else if (wo_isalpha(c)) {
+            ec[out++] = '$';
+            ++in;
+            ++d->left_clipping;
+            ++d->ref_seq_pos;
+            --d->ref_length;
+            --d->err_edit_distance;
+            ++clipped;
+        } else {
+            return 1; /* NUL or a foreign byte: the reference spins here */
+        }
+    }
+    if (out != in) { /* 1092-1097 */
+        while (AT(in))
+            ec[out++] = ec[in++];
+        ec[out] = 0;
+    }
+#undef AT
+    return 0;
+}
+
+static int clip_right(wamd_clip_record* d, uint8_t* ec, uint32_t stride, int count) /* 1101-1151 */
+{
+    const int len = (int)bounded_len(ec, stride);
+    int in = len - (int)d->right_clipping - 1, out = in + 1;
+    int clipped = 0;
+#define PREV() (in >= 1 ? ec[in - 1] : 0)
+    while (clipped < count || (clipped == count && PREV() == '#')) {
+        if (in < 0)
+            return 1;
+        const uint8_t c = ec[in];
+        if (c == '.') {
+            ec[--out] = '$';
+            --in;
+            ++d->right_clipping;
+            --d->ref_length;
+            ++clipped;
+        } else if (wo_isalpha(c)) {
+            if (PREV() == '#') {
+                ec[--out] = '$';
+                in -= 2;
+                ++d->right_clipping;
+                --d->err_edit_distance;
+            } else if (PREV() == '^') {
+                in -= 2;
+                --d->ref_length;
+                --d->err_edit_distance;
+                ++clipped;
+            } else {
+                ec[--out] = '$';
+                --in;
+                ++d->right_clipping;
+                --d->ref_length;
+                --d->err_edit_distance;
+                ++clipped;
+            }
+        } else {
+            return 1;
+        }
+    }
+#undef PREV
+    ++in; /* 1144-1150: the string becomes [0, in) + [out, len); what the reference leaves behind
+           * the new NUL is whatever followed the old one and is not reproduced */
+    if (in != out) {
+        while (out < len)
+            ec[in++] = ec[out++];
+        ec[in] = 0;
+    }
+    return 0;
+}
+
+int wo_clip_overlapping_pair(wamd_clip_record* rec, const wamd_clip_pair_task* t, uint8_t* ec_first,
+                             uint8_t* ec_second, uint32_t stride)
+{
+    wamd_clip_record *first = &rec[0], *second = &rec[1];
+    uint8_t* ec[2] = {ec_first, ec_second};
+    int rc = 0;
+    first->no_clippings = second->no_clippings = 0;
+    first->cigar_len = bounded_len(ec_first, stride);
+    second->cigar_len = bounded_len(ec_second, stride);
+    if (t->ref_seq_id[0] != t->ref_seq_id[1] || first->left_clipping || first->right_clipping ||
+        second->left_clipping || second->right_clipping) /* 999-1003 */
+        return 0;
+    int left; /* index of the left mapping, 1005-1025 */
+    if (first->ref_seq_pos < second->ref_seq_pos)
+        left = 0;
+    else if (first->ref_seq_pos == second->ref_seq_pos)
+        left = t->direct[0] ? 0 : 1;
+    else
+        left = 1;
+    const int right = 1 - left;
+    wamd_clip_record *l = &rec[left], *r = &rec[right];
+    if (!t->direct[left] && l->ref_seq_pos + (int32_t)l->ref_length > r->ref_seq_pos) { /* 1028 */
+        for (int q = 0; q < 2; ++q)
+            if (t->perfect[q]) { /* 1029-1036 */
+                if ((uint32_t)t->read_length[q] + 1 > stride)
+                    return 1;
+                memset(ec[q], '.', t->read_length[q]);
+                ec[q][t->read_length[q]] = 0;
+            }
+        const int to_left = r->ref_seq_pos - l->ref_seq_pos; /* 1038-1039 */
+        const int to_right = (r->ref_seq_pos + (int32_t)r->ref_length) - (l->ref_seq_pos + (int32_t)l->ref_length);
+        rc |= clip_left(l, ec[left], stride, to_left);
+        rc |= clip_right(r, ec[right], stride, to_right);
+        first->no_clippings = second->no_clippings = 1;
+        first->cigar_len = bounded_len(ec_first, stride);
+        second->cigar_len = bounded_len(ec_second, stride);
+    }
+    return rc;
+}
+
+int wo_clip_illegal_batch(uint32_t n, const wamd_clip_illegal_task* tasks, wamd_clip_record* records,
+                          uint8_t* cigars, uint32_t cigar_stride, const wamd_scoring* sc)
+{
+    int rc = 0;
+    for (uint32_t i = 0; i < n; ++i)
+        rc |= wo_clip_illegal(&records[i], &tasks[i], cigars + (size_t)i * cigar_stride, cigar_stride, sc);
+    return rc;
+}
+
+int wo_clip_pairs_batch(uint32_t n_pairs, const wamd_clip_pair_task* tasks, wamd_clip_record* records,
+                        uint8_t* cigars, uint32_t cigar_stride)
+{
+    int rc = 0;
+    for (uint32_t i = 0; i < n_pairs; ++i)
+        rc |= wo_clip_overlapping_pair(&records[2 * (size_t)i], &tasks[i], cigars + (size_t)(2 * i) * cigar_stride,
+                                       cigars + (size_t)(2 * i + 1) * cigar_stride, cigar_stride);
+    return rc;
+}
+
 /* ---- wire records ------------------------------------------------------------- */
 
 static uint8_t indel_size_encode(int32_t x) /* types.h:296-302 */

@@ -145,6 +145,18 @@ int wo_sam_cigar_batch(uint32_t n, const uint8_t* ext_cigars, uint32_t ext_strid
                        uint32_t cigar_stride, uint8_t* mdz, uint32_t mdz_stride, uint32_t* cigar_bin,
                        uint32_t bin_stride, wamd_sam_cigar_len* lens);
 
+/* clipIllegalPositions (soft_clipping.cpp:592-729) and clipOverlappingPairs with clipLeft /
+ * clipRight (997-1151).  Both return 0, or 1 when the record does not describe its ext-CIGAR
+ * (where the reference would run off the string); stride bounds every access. */
+int wo_clip_illegal(wamd_clip_record* rec, const wamd_clip_illegal_task* t, uint8_t* ext_cigar, uint32_t stride,
+                    const wamd_scoring* sc);
+int wo_clip_overlapping_pair(wamd_clip_record* rec2, const wamd_clip_pair_task* t, uint8_t* ext_cigar_first,
+                             uint8_t* ext_cigar_second, uint32_t stride);
+int wo_clip_illegal_batch(uint32_t n, const wamd_clip_illegal_task* tasks, wamd_clip_record* records,
+                          uint8_t* cigars, uint32_t cigar_stride, const wamd_scoring* sc);
+int wo_clip_pairs_batch(uint32_t n_pairs, const wamd_clip_pair_task* tasks, wamd_clip_record* records,
+                        uint8_t* cigars, uint32_t cigar_stride);
+
 #ifdef __cplusplus
 }
 #endif

@@ -297,3 +297,86 @@ def ext_cigar_pool(oracle, n=3000, seed=11, stride=512):
         hm[i, :len(h)] = np.frombuffer(h, np.uint8)
     pool.append(hm)
     return np.ascontiguousarray(np.concatenate(pool))
+
+
+def clip_illegal_workload(oracle, n, seed, m=150):
+    """Inputs of clipIllegalPositions (soft_clipping.cpp:592-729): aligned records (some already
+    boundary-clipped, some perfect matches without an ext-CIGAR) placed so that they hang over the
+    start of their chromosome, over its end, over both, or not at all."""
+    from oracle import bindings as ob
+    rec, cig = clip_workload(n, m, seed)
+    _, rec_b, cig_b = oracle.clip_boundary(rec, cig)
+    rng = np.random.default_rng(seed)
+    n = len(rec)
+    use_b = rng.random(n) < 0.3
+    rec = np.where(use_b, rec_b, rec)
+    cig = np.where(use_b[:, None], cig_b, cig)
+    rec["no_clippings"] = 0
+    tasks = np.zeros(n, ob.CLIP_ILLEGAL_TASK)
+    tasks["read_length"] = m
+    perfect = rng.random(n) < 0.15
+    tasks["perfect"] = perfect
+    cig[perfect] = 0
+    rec["ref_length"][perfect] = m
+    rec["err_edit_distance"][perfect] = 0
+    rec["left_clipping"][perfect] = 0
+    rec["right_clipping"][perfect] = 0
+    rec["score"][perfect] = float(m)
+    rec["cigar_len"] = [len(bytes(c).split(b"\0")[0]) for c in cig]
+    kind = rng.integers(0, 4, n)
+    over_l = rng.integers(0, 40, n)
+    over_r = rng.integers(1, 40, n)
+    pos = rec["ref_seq_pos"].astype(np.int64)
+    pos = np.where((kind == 0) | (kind == 2), -over_l, pos)
+    rec["ref_seq_pos"] = pos
+    last = pos + rec["ref_length"].astype(np.int64) - 1
+    tasks["ref_size"] = np.where((kind == 1) | (kind == 2), last - over_r, last + rng.integers(0, 1000, n))
+    return tasks, rec, np.ascontiguousarray(cig)
+
+
+def clip_pairs_workload(oracle, n_pairs, seed, m=150):
+    """Inputs of clipOverlappingPairs (soft_clipping.cpp:997-1044): pairs of aligned records, most of
+    them with the reverse read left of and overlapping the forward read, plus the cases the routine
+    leaves alone (other chromosome, a clipped mate, proper order, no overlap) and perfect matches."""
+    from oracle import bindings as ob
+    rec, cig = clip_workload(2 * n_pairs + 64, m, seed)
+    n_pairs = min(n_pairs, len(rec) // 2)
+    rec, cig = rec[:2 * n_pairs].copy(), np.ascontiguousarray(cig[:2 * n_pairs])
+    rng = np.random.default_rng(seed + 1)
+    rec["no_clippings"] = 0
+    tasks = np.zeros(n_pairs, ob.CLIP_PAIR_TASK)
+    tasks["read_length"] = m
+    for i in range(n_pairs):
+        a, b = 2 * i, 2 * i + 1
+        kind = i % 8
+        for q in (a, b):
+            if rng.random() < 0.15:
+                tasks["perfect"][i][q - a] = 1
+                cig[q] = 0
+                rec["ref_length"][q] = m
+                rec["err_edit_distance"][q] = 0
+                rec["score"][q] = float(m)
+        la = int(rec["ref_length"][a])
+        swap = bool(rng.integers(0, 2))            # which of first / second is the left one
+        l, r = (b, a) if swap else (a, b)
+        ll = int(rec["ref_length"][l])
+        base = int(rng.integers(100, 100000))
+        rec["ref_seq_pos"][l] = base
+        rec["ref_seq_pos"][r] = base + int(rng.integers(0, ll))     # overlap: left end > right start
+        tasks["direct"][i][l - a] = 0
+        tasks["direct"][i][r - a] = 1
+        tasks["ref_seq_id"][i] = (3, 3)
+        if kind == 1:
+            tasks["ref_seq_id"][i] = (3, 4)
+        elif kind == 2:
+            rec["left_clipping" if i & 8 else "right_clipping"][a if i & 16 else b] = 5
+        elif kind == 3:                                              # proper orientation: forward read on the left
+            tasks["direct"][i][l - a] = 1
+            tasks["direct"][i][r - a] = 0
+        elif kind == 4:                                              # same start: `direct` decides who is left
+            rec["ref_seq_pos"][r] = base
+        elif kind == 5:                                              # no overlap
+            rec["ref_seq_pos"][r] = base + ll + int(rng.integers(0, 50))
+        del la
+    rec["cigar_len"] = [len(bytes(c).split(b"\0")[0]) for c in cig]
+    return tasks, rec, cig

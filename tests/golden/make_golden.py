@@ -78,6 +78,24 @@ def make_sam_cigar(ref):
     print("samcigar_pool", len(ext), "ext-CIGARs, longest CIGAR", w[0] - 1, "MD:Z", w[1] - 1)
 
 
+def make_clip_l(ref):
+    """Row L fixtures: the reference's clipIllegalPositions and clipOverlappingPairs."""
+    orc = bindings.Oracle()
+    t, rec, cig = common.clip_illegal_workload(orc, 900, seed=61)
+    rc, rec2, cig2 = ref.clip_illegal(t, rec, cig)
+    assert rc == 0
+    np.savez_compressed(os.path.join(HERE, "clipillegal_m150.npz"), kind="clipillegal", tasks=t, records=rec,
+                        cigars=cig, out_records=rec2, out_cigars=cig2)
+    print("clipillegal_m150 clipped", int((rec2["no_clippings"] > 0).sum()), "of", len(rec))
+    t, rec, cig = common.clip_pairs_workload(orc, 600, seed=62)
+    rc, rec2, cig2 = ref.clip_overlapping_pairs(t, rec, cig)
+    assert rc == 0
+    np.savez_compressed(os.path.join(HERE, "clippairs_m150.npz"), kind="clippairs", tasks=t, records=rec,
+                        cigars=cig, out_records=rec2, out_cigars=cig2)
+    print("clippairs_m150 changed", int(((rec2["left_clipping"] != rec["left_clipping"]) |
+                                         (rec2["right_clipping"] != rec["right_clipping"])).sum()), "of", len(rec))
+
+
 def main():
     ref = bindings.Reference()
     codes = synth.make_genome(GENOME_SYMBOLS, seed=GENOME_SEED)
@@ -88,6 +106,9 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "samcigar":
         make_sam_cigar(ref)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "clipl":
+        make_clip_l(ref)
         return
     np.savez_compressed(os.path.join(HERE, "genome.npz"), packed=packed,
                         ref_size=np.uint32(ref_size), reference_version=ref.version())
@@ -154,6 +175,7 @@ def main():
     rec, cig = common.clip_workload(1200, 150, seed, gen=(codes, packed))
     make_cf(ref, codes, packed, ref_size)
     make_sam_cigar(ref)
+    make_clip_l(ref)
     rc, rec2, cig2 = ref.clip_boundary(rec, cig)
     np.savez_compressed(os.path.join(HERE, "clip_m150.npz"), kind="clip", records=rec, cigars=cig,
                         out_records=rec2, out_cigars=cig2)

@@ -18,7 +18,8 @@ def cases(kind):
         if name == "genome":
             continue
         prefix = {"distance": "dist_", "levdiag": "lev_", "align": "align_", "indel": "indel_",
-                  "clip": "clip_", "cf": "cf_", "samcigar": "samcigar_"}[kind]
+                  "clip": "clip_", "cf": "cf_", "samcigar": "samcigar_", "clipillegal": "clipillegal_",
+                  "clippairs": "clippairs_"}[kind]
         if name.startswith(prefix):
             out.append(name)
     return out

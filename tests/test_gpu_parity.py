@@ -304,6 +304,54 @@ def test_clip_boundary(ctx, oracle):
         assert bytes(gcig[i, :n]) == bytes(wcig[i, :n]), i
 
 
+def _same_clip_output(grec, gcig, wrec, wcig):
+    for f in wrec.dtype.names:
+        if f != "reserved":
+            np.testing.assert_array_equal(grec[f], wrec[f], err_msg=f)
+    for i in range(len(wrec)):
+        n = wrec["cigar_len"][i] + 1
+        assert bytes(gcig[i, :n]) == bytes(wcig[i, :n]), i
+
+
+def test_clip_illegal(ctx, oracle):
+    """Row L: clipIllegalPositions - mappings hanging over either end of their chromosome."""
+    t, rec, cig = common.clip_illegal_workload(oracle, 4000, seed=33)
+    rc, wrec, wcig = oracle.clip_illegal(t, rec, cig)
+    assert rc == 0
+    grec, gcig = ctx.clip_illegal(t, rec, cig)
+    assert (wrec["no_clippings"] > 0).sum() > 2000
+    _same_clip_output(grec, gcig, wrec, wcig)
+    # a record that claims more read than its ext-CIGAR holds is an error, not a wild write
+    t2, rec2, cig2 = t[:64].copy(), rec[:64].copy(), cig[:64, :160].copy()
+    t2["read_length"] = 400
+    rec2["ref_seq_pos"] = -3
+    with pytest.raises(api.WamdError):
+        ctx.clip_illegal(t2, rec2, cig2)
+
+
+def test_clip_overlapping_pairs(ctx, oracle):
+    """Row L: clipOverlappingPairs with clipLeft / clipRight."""
+    t, rec, cig = common.clip_pairs_workload(oracle, 4000, seed=34)
+    rc, wrec, wcig = oracle.clip_overlapping_pairs(t, rec, cig)
+    assert rc == 0
+    grec, gcig = ctx.clip_overlapping_pairs(t, rec, cig)
+    assert (wrec["no_clippings"] > 0).sum() > 2000
+    _same_clip_output(grec, gcig, wrec, wcig)
+    # ref_length larger than the ext-CIGAR spans: the reference would run off the string
+    t2, rec2, cig2 = t[:32].copy(), rec[:64].copy(), cig[:64].copy()
+    t2["ref_seq_id"] = 1
+    t2["direct"][:, 0] = 0
+    t2["direct"][:, 1] = 1
+    t2["perfect"] = 0
+    rec2["left_clipping"] = 0
+    rec2["right_clipping"] = 0
+    rec2["ref_seq_pos"][0::2] = 100
+    rec2["ref_seq_pos"][1::2] = 900
+    rec2["ref_length"][0::2] = 1000
+    with pytest.raises(api.WamdError):
+        ctx.clip_overlapping_pairs(t2, rec2, cig2)
+
+
 def test_sam_cigar(ctx, oracle):
     """Row X: SAM CIGAR text, BAM operations and MD:Z from ext-CIGARs of every flavour."""
     ext = common.ext_cigar_pool(oracle, n=6000, seed=21)

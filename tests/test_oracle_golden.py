@@ -111,3 +111,28 @@ def test_sam_cigar(oracle, name):
     rc, cig, mdz, cbin, lens = oracle.sam_cigar(z["ext"])
     assert rc == 0
     _check_sam_cigar(z, cig, mdz, cbin, lens)
+
+
+def _check_clip_l(z, rec, cig, skip):
+    want = z["out_records"]
+    for f in want.dtype.names:
+        if f not in ("reserved",) + skip:
+            np.testing.assert_array_equal(rec[f], want[f], err_msg=f)
+    for i in range(len(rec)):
+        assert gu.cigar_bytes(cig, i) == gu.cigar_bytes(z["out_cigars"], i), i
+
+
+@pytest.mark.parametrize("name", gu.cases("clipillegal"))
+def test_clip_illegal(oracle, name):
+    z = gu.load(name)
+    rc, rec, cig = oracle.clip_illegal(z["tasks"], z["records"], z["cigars"])
+    assert rc == 0
+    _check_clip_l(z, rec, cig, ())
+
+
+@pytest.mark.parametrize("name", gu.cases("clippairs"))
+def test_clip_overlapping_pairs(oracle, name):
+    z = gu.load(name)
+    rc, rec, cig = oracle.clip_overlapping_pairs(z["tasks"], z["records"], z["cigars"])
+    assert rc == 0
+    _check_clip_l(z, rec, cig, ("no_clippings",))

@@ -141,3 +141,35 @@ def test_sam_cigar(oracle, reference):
         nb = l1["cigar_bin_len"][i]
         np.testing.assert_array_equal(b1[i, :nb], b2[i, :nb])
     assert (l1["cigar_bin_len"] > 3).sum() > 200       # plenty of multi-operation CIGARs
+
+
+def _same_clip_output(ra, ca, rb, cb, skip=()):
+    for f in ra.dtype.names:
+        if f not in ("reserved",) + tuple(skip):
+            np.testing.assert_array_equal(ra[f], rb[f], err_msg=f)
+    for i in range(len(ra)):          # as C strings: the reference leaves stale bytes behind the NUL
+        n = ra["cigar_len"][i] + 1
+        assert bytes(ca[i, :n]) == bytes(cb[i, :n]), i
+
+
+def test_clip_illegal(oracle, reference):
+    """Row L: clipIllegalPositions (soft_clipping.cpp:592-729)."""
+    t, rec, cig = common.clip_illegal_workload(oracle, 3000, seed=5)
+    rc1, ra, ca = oracle.clip_illegal(t, rec, cig)
+    rc2, rb, cb = reference.clip_illegal(t, rec, cig)
+    assert rc1 == 0 and rc2 == 0
+    assert (ra["no_clippings"] == 1).sum() > 800 and (ra["no_clippings"] == 2).sum() > 400
+    assert (ra["no_clippings"] == 0).sum() > 400
+    _same_clip_output(ra, ca, rb, cb)
+
+
+def test_clip_overlapping_pairs(oracle, reference):
+    """Row L: clipOverlappingPairs, clipLeft, clipRight (soft_clipping.cpp:997-1151)."""
+    t, rec, cig = common.clip_pairs_workload(oracle, 3000, seed=7)
+    rc1, ra, ca = oracle.clip_overlapping_pairs(t, rec, cig)
+    rc2, rb, cb = reference.clip_overlapping_pairs(t, rec, cig)
+    assert rc1 == 0 and rc2 == 0
+    assert (ra["no_clippings"] > 0).sum() > 1500
+    changed = (ra["left_clipping"] != rec["left_clipping"]) | (ra["right_clipping"] != rec["right_clipping"])
+    assert changed.sum() > 1000
+    _same_clip_output(ra, ca, rb, cb, skip=("no_clippings",))   # the reference does not say whether it clipped

@@ -35,6 +35,9 @@ ALIGN_RESULT = np.dtype([("affine_score", "<f8"), ("ok", "<u4"), ("edit_distance
 CF_TASK = np.dtype([("read_idx", "<u4"), ("position", "<u4"), ("read_offset", "<u2"), ("pattern_len", "<u2"),
                     ("fixed_left", "<u2"), ("fixed_right", "<u2"), ("dir_gen_flag", "u1"), ("flags", "u1"),
                     ("reserved", "<u2")])
+CLIP_ILLEGAL_TASK = np.dtype([("ref_size", "<i4"), ("read_length", "<u2"), ("perfect", "<u2")])
+CLIP_PAIR_TASK = np.dtype([("ref_seq_id", "<i4", (2,)), ("read_length", "<u2", (2,)), ("direct", "u1", (2,)),
+                           ("perfect", "u1", (2,))])
 SAM_CIGAR_LEN = np.dtype([("cigar_len", "<u4"), ("mdz_len", "<u4"), ("cigar_bin_len", "<u4"), ("reserved", "<u4")])
 INDEL_TASK = np.dtype([("read_idx", "<u4"), ("ref_pos", "<u4"), ("max_indel_size", "<u2"),
                        ("fixed_segment_pos", "<u2"), ("fixed_segment_size", "<u2"),
@@ -67,7 +70,8 @@ EXPORTS = [
     "wamd_reads_count", "wamd_verify_distance", "wamd_verify_distance_dev", "wamd_levdiag",
     "wamd_levdiag_dev", "wamd_cf_filter", "wamd_cf_filter_dev", "wamd_align", "wamd_align_dev", "wamd_align_workspace_bytes",
     "wamd_indel_match", "wamd_indel_match_dev", "wamd_indel_ext_cigar", "wamd_indel_ext_cigar_dev",
-    "wamd_clip_boundary", "wamd_clip_boundary_dev", "wamd_serialize_mappings",
+    "wamd_clip_boundary", "wamd_clip_boundary_dev", "wamd_clip_illegal", "wamd_clip_illegal_dev",
+    "wamd_clip_overlapping_pairs", "wamd_clip_overlapping_pairs_dev", "wamd_serialize_mappings",
     "wamd_serialize_mappings_dev", "wamd_sam_cigar", "wamd_sam_cigar_dev", "wamd_records_scratch_bytes", "wamd_emit_lev_records_dev",
 ]
 
@@ -265,6 +269,29 @@ class Context:
         cig = np.array(cigars, np.uint8, copy=True)
         _check(lib().wamd_clip_boundary(self.h, C.c_uint32(len(rec)), _ptr(rec), _ptr(cig),
                                         C.c_uint32(cig.shape[1])))
+        return rec, cig
+
+    def clip_illegal(self, tasks, records, cigars):
+        """CSoftClipping::clipIllegalPositions for a batch (soft_clipping.cpp:592-729)."""
+        t = np.ascontiguousarray(tasks, CLIP_ILLEGAL_TASK)
+        rec = np.array(records, CLIP_RECORD, copy=True)
+        cig = np.array(cigars, np.uint8, copy=True)
+        if len(t) != len(rec) or len(cig) != len(rec):
+            raise ValueError("one task and one ext-CIGAR slot per record")
+        _check(lib().wamd_clip_illegal(self.h, C.c_uint32(len(rec)), _ptr(t), _ptr(rec), _ptr(cig),
+                                       C.c_uint32(cig.shape[1])))
+        return rec, cig
+
+    def clip_overlapping_pairs(self, tasks, records, cigars):
+        """CSoftClipping::clipOverlappingPairs for a batch of pairs (soft_clipping.cpp:997-1151);
+        pair i owns records and ext-CIGAR slots 2i (p.first) and 2i + 1 (p.second)."""
+        t = np.ascontiguousarray(tasks, CLIP_PAIR_TASK)
+        rec = np.array(records, CLIP_RECORD, copy=True)
+        cig = np.array(cigars, np.uint8, copy=True)
+        if len(rec) != 2 * len(t) or len(cig) != len(rec):
+            raise ValueError("two records and two ext-CIGAR slots per pair")
+        _check(lib().wamd_clip_overlapping_pairs(self.h, C.c_uint32(len(t)), _ptr(t), _ptr(rec), _ptr(cig),
+                                                 C.c_uint32(cig.shape[1])))
         return rec, cig
 
     def sam_cigar(self, ext_cigars, out_stride=None):

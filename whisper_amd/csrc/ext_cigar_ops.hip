@@ -373,6 +373,304 @@ __global__ __launch_bounds__(256) void clip_boundary_kernel(uint32_t n, wamd_cli
     records[gid] = d;
 }
 
+// ---- row L: clipIllegalPositions (soft_clipping.cpp:592-729) ---------------------------------
+// One record per lane.  The three loops of the reference, byte for byte - including the tail
+// loop that does not advance its input on an ordinary symbol and so pads with '$' up to
+// read_length, and the '$' of an earlier clipping being scored as a mismatch.
+__device__ __forceinline__ uint32_t bounded_len(const uint8_t* ec, uint32_t stride)
+{
+    uint32_t l = 0;
+    while (l < stride && ec[l])
+        ++l;
+    return l;
+}
+
+__global__ __launch_bounds__(256) void clip_illegal_kernel(uint32_t n, const wamd_clip_illegal_task* __restrict__ tasks,
+                                                           wamd_clip_record* __restrict__ records,
+                                                           uint8_t* __restrict__ cigars, uint32_t stride,
+                                                           wamd_scoring sc, uint32_t* __restrict__ flags)
+{
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n)
+        return;
+    wamd_clip_record d = records[gid];
+    const wamd_clip_illegal_task t = tasks[gid];
+    uint8_t* ec = cigars + (uint64_t)gid * stride;
+    const int32_t ref_size = t.ref_size;
+    const int32_t mapping_last = d.ref_seq_pos + (int32_t)d.ref_length - 1;   // 596
+    const int read_length = t.read_length;
+    int to_left = 0, to_right = 0;
+    int i_read = 0, i_ref = d.ref_seq_pos;
+    d.no_clippings = 0;
+    if (d.ref_seq_pos <= 0)   // 604-610
+        to_left = -d.ref_seq_pos + 1;
+    if (mapping_last > ref_size)
+        to_right = mapping_last - ref_size;
+    if (!to_left && !to_right) {
+        d.cigar_len = bounded_len(ec, stride);
+        records[gid] = d;
+        return;
+    }
+    if ((uint32_t)read_length + 1 > stride) {
+        raise_flag(flags, FLAG_CIGAR);
+        return;
+    }
+    if (t.perfect) {   // 614-618
+        for (int i = 0; i < read_length; ++i)
+            ec[i] = '.';
+        ec[read_length] = 0;
+    }
+    d.left_clipping = (uint16_t)(d.left_clipping + to_left);   // 620-625
+    d.right_clipping = (uint16_t)(d.right_clipping + to_right);
+    d.ref_length = (uint16_t)(d.ref_length - (to_left + to_right));
+    d.ref_seq_pos += to_left;
+    d.err_edit_distance = 0;
+    double score = 0;
+    d.no_clippings = (uint32_t)((to_left != 0) + (to_right != 0));
+
+    uint32_t in = 0, out = 0;
+    const uint32_t lim = stride - 1;
+    bool bad = false;
+    auto at = [&](uint32_t i) -> uint32_t { return i < stride ? ec[i] : 0u; };
+    uint32_t c;
+    while (i_ref < 1 && (c = at(in)) != 0) {   // 632-652
+        if (c == '^') {
+            in += 2;
+            ++i_ref;
+        } else if (c == '#') {
+            in += 2;
+            ec[out++] = '$';
+            ++i_read;
+        } else {
+            ++in;
+            ec[out++] = '$';
+            ++i_read;
+            ++i_ref;
+        }
+    }
+    bool gap_opened = false;
+    while (i_read < read_length && i_ref <= ref_size && (c = at(in)) != 0) {   // 655-703
+        if (c == '^' || c == '#') {
+            if (in + 1 >= lim) {
+                bad = true;
+                break;
+            }
+            ec[out++] = (uint8_t)c;
+            ec[out++] = ec[in + 1];
+            in += 2;
+            d.err_edit_distance++;
+            if (c == '^') {
+                ++i_ref;
+                score += gap_opened ? sc.gap_del_extend : sc.gap_del_open;
+            } else {
+                ++i_read;
+                score += gap_opened ? sc.gap_ins_extend : sc.gap_ins_open;
+            }
+            gap_opened = true;
+        } else {
+            if (c == '.')
+                score += sc.match;
+            else {
+                score += sc.mismatch;
+                d.err_edit_distance++;
+            }
+            ec[out++] = (uint8_t)c;
+            ++in;
+            ++i_read;
+            ++i_ref;
+            gap_opened = false;
+        }
+    }
+    while (!bad && i_read < read_length && (c = at(in)) != 0) {   // 706-725
+        if (c == '^') {
+            in += 2;
+            ++i_ref;
+        } else if (c == '#') {
+            in += 2;
+            ec[out++] = '$';
+            ++i_read;
+        } else {   // 719-724: the input does not move
+            if (out >= lim) {
+                bad = true;
+                break;
+            }
+            ec[out++] = '$';
+            ++i_read;
+            ++i_ref;
+        }
+    }
+    if (out > lim)
+        out = lim;
+    ec[out] = 0;   // 727
+    if (bad)
+        raise_flag(flags, FLAG_ARG);
+    d.score = score;
+    d.cigar_len = out;
+    records[gid] = d;
+}
+
+// ---- row L: clipOverlappingPairs with clipLeft / clipRight (soft_clipping.cpp:997-1151) -------
+// One pair per lane.  Returns false where the reference would run off the string.
+__device__ bool clip_left(wamd_clip_record& d, uint8_t* ec, uint32_t stride, int count)
+{
+    uint32_t in = d.left_clipping, out = in;
+    int clipped = 0;
+    auto at = [&](uint32_t i) -> uint32_t { return i < stride ? ec[i] : 0u; };
+    uint32_t c;
+    while (clipped < count || (clipped == count && at(in) == '#')) {
+        c = at(in);
+        if (c == '.') {
+            ec[out++] = '$';
+            ++in;
+            ++d.left_clipping;
+            ++d.ref_seq_pos;
+            --d.ref_length;
+            ++clipped;
+        } else if (c == '#') {
+            ec[out++] = '$';
+            in += 2;
+            ++d.left_clipping;
+            --d.err_edit_distance;
+        } else if (c == '^') {
+            in += 2;
+            ++d.ref_seq_pos;
+            --d.ref_length;
+            --d.err_edit_distance;
+            ++clipped;
+        } else if (is_alpha(c)) {
+            ec[out++] = '$';
+            ++in;
+            ++d.left_clipping;
+            ++d.ref_seq_pos;
+            --d.ref_length;
+            --d.err_edit_distance;
+            ++clipped;
+        } else {
+            return false;
+        }
+    }
+    if (out != in) {   // 1092-1097
+        while ((c = at(in)) != 0) {
+            ec[out++] = (uint8_t)c;
+            ++in;
+        }
+        ec[out] = 0;
+    }
+    return true;
+}
+
+__device__ bool clip_right(wamd_clip_record& d, uint8_t* ec, uint32_t stride, int count)
+{
+    const int len = (int)bounded_len(ec, stride);
+    int in = len - (int)d.right_clipping - 1, out = in + 1;
+    int clipped = 0;
+    auto prev = [&]() -> uint32_t { return in >= 1 ? ec[in - 1] : 0u; };
+    while (clipped < count || (clipped == count && prev() == '#')) {
+        if (in < 0)
+            return false;
+        const uint32_t c = ec[in];
+        if (c == '.') {
+            ec[--out] = '$';
+            --in;
+            ++d.right_clipping;
+            --d.ref_length;
+            ++clipped;
+        } else if (is_alpha(c)) {
+            const uint32_t p = prev();
+            if (p == '#') {
+                ec[--out] = '$';
+                in -= 2;
+                ++d.right_clipping;
+                --d.err_edit_distance;
+            } else if (p == '^') {
+                in -= 2;
+                --d.ref_length;
+                --d.err_edit_distance;
+                ++clipped;
+            } else {
+                ec[--out] = '$';
+                --in;
+                ++d.right_clipping;
+                --d.ref_length;
+                --d.err_edit_distance;
+                ++clipped;
+            }
+        } else {
+            return false;
+        }
+    }
+    ++in;   // 1144-1150: the string becomes [0, in) + [out, len)
+    if (in != out) {
+        while (out < len)
+            ec[in++] = ec[out++];
+        ec[in] = 0;
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(256) void clip_pairs_kernel(uint32_t n_pairs, const wamd_clip_pair_task* __restrict__ tasks,
+                                                         wamd_clip_record* __restrict__ records,
+                                                         uint8_t* __restrict__ cigars, uint32_t stride,
+                                                         uint32_t* __restrict__ flags)
+{
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n_pairs)
+        return;
+    const wamd_clip_pair_task t = tasks[gid];
+    wamd_clip_record rec[2] = {records[2 * (uint64_t)gid], records[2 * (uint64_t)gid + 1]};
+    uint8_t* ec[2] = {cigars + 2 * (uint64_t)gid * stride, cigars + (2 * (uint64_t)gid + 1) * stride};
+    rec[0].no_clippings = rec[1].no_clippings = 0;
+    bool touched = false;
+    if (t.ref_seq_id[0] == t.ref_seq_id[1] && !rec[0].left_clipping && !rec[0].right_clipping &&
+        !rec[1].left_clipping && !rec[1].right_clipping) {   // 999-1003
+        int left;   // 1005-1025
+        if (rec[0].ref_seq_pos < rec[1].ref_seq_pos)
+            left = 0;
+        else if (rec[0].ref_seq_pos == rec[1].ref_seq_pos)
+            left = t.direct[0] ? 0 : 1;
+        else
+            left = 1;
+        const int right = 1 - left;
+        // dynamic indexing of the two records would put them in scratch memory: select instead
+        wamd_clip_record l = left ? rec[1] : rec[0], r = left ? rec[0] : rec[1];
+        uint8_t *ecl = left ? ec[1] : ec[0], *ecr = left ? ec[0] : ec[1];
+        const bool left_direct = left ? t.direct[1] : t.direct[0];
+        if (!left_direct && l.ref_seq_pos + (int32_t)l.ref_length > r.ref_seq_pos) {   // 1028
+            bool ok = true;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if (t.perfect[q]) {   // 1029-1036
+                    const uint32_t rl = t.read_length[q];
+                    if (rl + 1 > stride) {
+                        ok = false;
+                    } else {
+                        for (uint32_t i = 0; i < rl; ++i)
+                            ec[q][i] = '.';
+                        ec[q][rl] = 0;
+                    }
+                }
+            if (ok) {
+                const int to_left = r.ref_seq_pos - l.ref_seq_pos;   // 1038-1039
+                const int to_right = (r.ref_seq_pos + (int32_t)r.ref_length) - (l.ref_seq_pos + (int32_t)l.ref_length);
+                ok = clip_left(l, ecl, stride, to_left);
+                ok = clip_right(r, ecr, stride, to_right) && ok;
+            }
+            if (!ok)
+                raise_flag(flags, FLAG_ARG);
+            l.no_clippings = r.no_clippings = 1;
+            rec[0] = left ? r : l;
+            rec[1] = left ? l : r;
+            touched = true;
+        }
+        (void)right;
+    }
+    (void)touched;
+    rec[0].cigar_len = bounded_len(ec[0], stride);
+    rec[1].cigar_len = bounded_len(ec[1], stride);
+    records[2 * (uint64_t)gid] = rec[0];
+    records[2 * (uint64_t)gid + 1] = rec[1];
+}
+
 __device__ __forceinline__ uint8_t indel_size_encode(int32_t x)   // types.h:296-302
 {
     return x > 0 ? (uint8_t)x : (uint8_t)(-x + 128);
@@ -553,6 +851,26 @@ int launch_clip_boundary(wamd_ctx* ctx, uint32_t n, wamd_clip_record* d_records,
     WAMD_HIP(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(clip_boundary_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_records, d_cigars,
                        cigar_stride, ctx->scoring);
+    WAMD_HIP(hipGetLastError());
+    return WAMD_OK;
+}
+
+int launch_clip_illegal(wamd_ctx* ctx, uint32_t n, const wamd_clip_illegal_task* d_tasks, wamd_clip_record* d_records,
+                        uint8_t* d_cigars, uint32_t cigar_stride, hipStream_t s)
+{
+    WAMD_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(clip_illegal_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_tasks, d_records, d_cigars,
+                       cigar_stride, ctx->scoring, ctx->d_flags);
+    WAMD_HIP(hipGetLastError());
+    return WAMD_OK;
+}
+
+int launch_clip_pairs(wamd_ctx* ctx, uint32_t n_pairs, const wamd_clip_pair_task* d_tasks, wamd_clip_record* d_records,
+                      uint8_t* d_cigars, uint32_t cigar_stride, hipStream_t s)
+{
+    WAMD_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(clip_pairs_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, s, n_pairs, d_tasks, d_records,
+                       d_cigars, cigar_stride, ctx->d_flags);
     WAMD_HIP(hipGetLastError());
     return WAMD_OK;
 }

@@ -91,6 +91,44 @@ static int fetch_flags(wamd_ctx* ctx, hipStream_t s, uint32_t* out)
     return WAMD_OK;
 }
 
+// host-pointer form of the two clipping post-passes: tasks up, records and ext-CIGARs up and back
+template <class Task, class Call>
+static int clip_pass_host(wamd_ctx* ctx, uint32_t n_tasks, uint32_t n_records, const Task* tasks,
+                          wamd_clip_record* records, uint8_t* cigars, uint32_t cigar_stride, const char* who, Call call)
+{
+    if (n_tasks == 0)
+        return WAMD_OK;
+    if (!ctx || !tasks || !records || !cigars || cigar_stride < 2)
+        return WAMD_ERR_INVALID_ARG;
+    WAMD_HIP(hipSetDevice(ctx->device));
+    auto up = [](uint64_t x) { return (x + 255) / 256 * 256; };
+    const uint64_t tb = (uint64_t)n_tasks * sizeof(Task), rb = (uint64_t)n_records * sizeof(wamd_clip_record),
+                   cb = (uint64_t)n_records * cigar_stride;
+    int rc = ensure_stage(ctx, up(tb) + up(rb) + up(cb), 0);
+    if (rc)
+        return rc;
+    char* base = (char*)ctx->d_stage;
+    auto* d_tasks = (Task*)base;
+    auto* d_rec = (wamd_clip_record*)(base + up(tb));
+    auto* d_cig = (uint8_t*)(base + up(tb) + up(rb));
+    hipStream_t s = ctx->stream;
+    WAMD_HIP(hipMemcpyAsync(d_tasks, tasks, tb, hipMemcpyHostToDevice, s));
+    WAMD_HIP(hipMemcpyAsync(d_rec, records, rb, hipMemcpyHostToDevice, s));
+    WAMD_HIP(hipMemcpyAsync(d_cig, cigars, cb, hipMemcpyHostToDevice, s));
+    rc = call(d_tasks, d_rec, d_cig, s);
+    if (rc)
+        return rc;
+    WAMD_HIP(hipMemcpyAsync(records, d_rec, rb, hipMemcpyDeviceToHost, s));
+    WAMD_HIP(hipMemcpyAsync(cigars, d_cig, cb, hipMemcpyDeviceToHost, s));
+    uint32_t flags = 0;
+    rc = fetch_flags(ctx, s, &flags);
+    if (!rc && flags) {
+        set_error("%s: a record does not describe its ext-CIGAR, or the ext-CIGAR does not fit its stride", who);
+        return WAMD_ERR_INVALID_ARG;
+    }
+    return rc;
+}
+
 } // namespace wamd
 
 using namespace wamd;
@@ -699,6 +737,47 @@ int wamd_clip_boundary(wamd_ctx* ctx, uint32_t n, wamd_clip_record* records, uin
     WAMD_HIP(hipMemcpyAsync(cigars, d_cig, cb, hipMemcpyDeviceToHost, s));
     WAMD_HIP(hipStreamSynchronize(s));
     return WAMD_OK;
+}
+
+int wamd_clip_illegal_dev(wamd_ctx* ctx, uint32_t n, const wamd_clip_illegal_task* d_tasks, wamd_clip_record* d_records,
+                          uint8_t* d_cigars, uint32_t cigar_stride, void* stream)
+{
+    if (n == 0)
+        return WAMD_OK;
+    if (!ctx || !d_tasks || !d_records || !d_cigars || cigar_stride < 2)
+        return WAMD_ERR_INVALID_ARG;
+    return launch_clip_illegal(ctx, n, d_tasks, d_records, d_cigars, cigar_stride, pick(ctx, stream));
+}
+
+int wamd_clip_overlapping_pairs_dev(wamd_ctx* ctx, uint32_t n_pairs, const wamd_clip_pair_task* d_tasks,
+                                    wamd_clip_record* d_records, uint8_t* d_cigars, uint32_t cigar_stride,
+                                    void* stream)
+{
+    if (n_pairs == 0)
+        return WAMD_OK;
+    if (!ctx || !d_tasks || !d_records || !d_cigars || cigar_stride < 2 || n_pairs > 0x7fffffffu)
+        return WAMD_ERR_INVALID_ARG;
+    return launch_clip_pairs(ctx, n_pairs, d_tasks, d_records, d_cigars, cigar_stride, pick(ctx, stream));
+}
+
+int wamd_clip_illegal(wamd_ctx* ctx, uint32_t n, const wamd_clip_illegal_task* tasks, wamd_clip_record* records,
+                      uint8_t* cigars, uint32_t cigar_stride)
+{
+    return clip_pass_host(ctx, n, n, tasks, records, cigars, cigar_stride, "wamd_clip_illegal",
+                          [&](const wamd_clip_illegal_task* dt, wamd_clip_record* dr, uint8_t* dc, hipStream_t s) {
+                              return wamd_clip_illegal_dev(ctx, n, dt, dr, dc, cigar_stride, s);
+                          });
+}
+
+int wamd_clip_overlapping_pairs(wamd_ctx* ctx, uint32_t n_pairs, const wamd_clip_pair_task* tasks,
+                                wamd_clip_record* records, uint8_t* cigars, uint32_t cigar_stride)
+{
+    if (n_pairs > 0x7fffffffu)
+        return WAMD_ERR_INVALID_ARG;
+    return clip_pass_host(ctx, n_pairs, 2 * n_pairs, tasks, records, cigars, cigar_stride, "wamd_clip_overlapping_pairs",
+                          [&](const wamd_clip_pair_task* dt, wamd_clip_record* dr, uint8_t* dc, hipStream_t s) {
+                              return wamd_clip_overlapping_pairs_dev(ctx, n_pairs, dt, dr, dc, cigar_stride, s);
+                          });
 }
 
 int wamd_sam_cigar_dev(wamd_ctx* ctx, uint32_t n, const uint8_t* d_ext_cigars, uint32_t ext_stride,

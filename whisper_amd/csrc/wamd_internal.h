@@ -129,6 +129,10 @@ int launch_indel_ext_cigar(wamd_ctx* ctx, const wamd_reads* r, const wamd_indel_
                            uint32_t cigar_stride, hipStream_t s);
 int launch_clip_boundary(wamd_ctx* ctx, uint32_t n, wamd_clip_record* d_records, uint8_t* d_cigars,
                          uint32_t cigar_stride, hipStream_t s);
+int launch_clip_illegal(wamd_ctx* ctx, uint32_t n, const wamd_clip_illegal_task* d_tasks, wamd_clip_record* d_records,
+                        uint8_t* d_cigars, uint32_t cigar_stride, hipStream_t s);
+int launch_clip_pairs(wamd_ctx* ctx, uint32_t n_pairs, const wamd_clip_pair_task* d_tasks, wamd_clip_record* d_records,
+                      uint8_t* d_cigars, uint32_t cigar_stride, hipStream_t s);
 int launch_serialize(wamd_ctx* ctx, uint32_t n, const wamd_mapping* d_mappings, const uint8_t* d_direction,
                      uint8_t* d_out, uint8_t* d_sizes, hipStream_t s);
 
