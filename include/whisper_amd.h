@@ -420,6 +420,67 @@ WAMD_API int wamd_clip_overlapping_pairs_dev(wamd_ctx* ctx, uint32_t n_pairs, co
                                              wamd_clip_record* d_records, uint8_t* d_cigars,
                                              uint32_t cigar_stride, void* stream);
 
+/* ---- hashing rescue: CSoftClipping::match + getExtCigar ------------------- *
+ * One softClipping->preprocessRawSeq(seq, len, dir) + match(ref_pos, max_distance_in_ref,
+ * min_exact_len, ...) (+ getExtCigar) as in find_pairs<Clipping> (sam_matching.cpp:556-575) and
+ * fill_cigar_with_clipping (sam_matching.cpp:771-797). */
+typedef struct wamd_softclip_task {
+    uint32_t read_idx;
+    uint32_t ref_pos;              /* raw genome position of the window start (start_pos)   */
+    uint32_t max_distance_in_ref;  /* window length searched for 20-mer hits                */
+    uint16_t min_exact_len;        /* HashTable::hash_len = 20 at both call sites           */
+    uint8_t flags;                 /* WAMD_TASK_FLAG_*                                      */
+    uint8_t reserved;
+} wamd_softclip_task;
+
+/* Constructor arguments of CSoftClipping (soft_clipping.cpp:28-48, built at sam.cpp:220 from
+ * params->max_read_len, min/max_approx_indel_len, max_approx_indel_mismatches).  max_query_len
+ * fixes the size of the open-addressing table (smallest power of two >= 256 with
+ * size / max_query_len >= 50), hence which 20-mers share a probe chain: results depend on it.
+ * fresh_object: the reference's checked_pos_left starts zero-filled and only cells it has touched
+ * are reset to "empty" (1 << 30) afterwards, so a hit at query position 1 on a text position no
+ * earlier call of the same object has marked is skipped.  1 reproduces a newly built object,
+ * 0 one whose cells have all been touched (the long-run state). */
+typedef struct wamd_softclip_params {
+    uint32_t max_query_len;
+    uint32_t min_approx_indel_len;         /* mapper/params.h:134: 3                        */
+    uint32_t max_approx_indel_len;         /* mapper/params.h:135: 50                       */
+    uint32_t max_approx_indel_mismatches;  /* mapper/params.h:136                           */
+    uint32_t fresh_object;
+    uint32_t reserved;
+} wamd_softclip_params;
+
+/* What match() hands back, and getExtCigar's score.  found = match's bool; when it is 0 every
+ * other field is 0 and the ext-CIGAR is empty.  pos is relative to ref_pos and can be
+ * 0xffffffff (= -1: the reference subtracts the dummy symbol in front of its window). */
+typedef struct wamd_softclip_result {
+    double affine_score;
+    uint32_t found;
+    uint32_t pos;
+    uint32_t left_clipping;
+    uint32_t right_clipping;
+    uint32_t left_match;
+    uint32_t right_match;
+    int32_t del_size;
+    uint32_t no_mismatches;
+    uint32_t cigar_len;
+    uint32_t reserved;
+} wamd_softclip_result;
+
+/* Replaces softClipping->{preprocessRawSeq | preprocess, match, getExtCigar}
+ * (soft_clipping.cpp:139-231, 234-495, 498-589).  Window lengths above max_text_len
+ * (wamd_ctx_set_max_text_len, 16384 as in sam.cpp:190) and reads shorter than 20 symbols are
+ * errors.  ext-CIGARs are written NUL-terminated at cigars + i * cigar_stride
+ * (cigar_stride >= read length + 2 * max_approx_indel_len * 2 + 1). */
+WAMD_API int wamd_softclip_match(wamd_ctx* ctx, const wamd_reads* reads, const wamd_softclip_task* tasks,
+                                 uint32_t n, const wamd_softclip_params* params, wamd_softclip_result* results,
+                                 uint8_t* cigars, uint32_t cigar_stride);
+/* max_window: an upper bound of max_distance_in_ref over the batch (sizes the kernel's LDS). */
+WAMD_API int wamd_softclip_match_dev(wamd_ctx* ctx, const wamd_reads* reads, const wamd_softclip_task* d_tasks,
+                                     uint32_t n, const wamd_softclip_params* params, uint32_t max_window,
+                                     wamd_softclip_result* d_results, uint8_t* d_cigars, uint32_t cigar_stride,
+                                     void* stream);
+
 /* What CSamGenerator::extract_cigar_and_mdz / extract_cigarbin_and_mdz leave (sam.cpp:805-928,
  * 932-1051): lengths of the three outputs of one ext-CIGAR. */
 typedef struct wamd_sam_cigar_len {

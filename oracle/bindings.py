@@ -364,3 +364,51 @@ Oracle.clip_illegal = _o_clip_illegal
 Oracle.clip_overlapping_pairs = _o_clip_pairs
 Reference.clip_illegal = _r_clip_illegal
 Reference.clip_overlapping_pairs = _r_clip_pairs
+
+
+# ---- row S: CSoftClipping::match + getExtCigar (soft_clipping.cpp:139-589)
+SOFTCLIP_TASK = np.dtype([("read_idx", "<u4"), ("ref_pos", "<u4"), ("max_distance_in_ref", "<u4"),
+                          ("min_exact_len", "<u2"), ("flags", "u1"), ("reserved", "u1")])
+SOFTCLIP_RESULT = np.dtype([("affine_score", "<f8"), ("found", "<u4"), ("pos", "<u4"), ("left_clipping", "<u4"),
+                            ("right_clipping", "<u4"), ("left_match", "<u4"), ("right_match", "<u4"),
+                            ("del_size", "<i4"), ("no_mismatches", "<u4"), ("cigar_len", "<u4"), ("reserved", "<u4")])
+assert SOFTCLIP_TASK.itemsize == 16 and SOFTCLIP_RESULT.itemsize == 48
+
+
+class SoftclipParams(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("max_query_len", "min_approx_indel_len", "max_approx_indel_len",
+                                          "max_approx_indel_mismatches", "fresh_object", "reserved")]
+
+
+def default_softclip_params(max_query_len=151, max_mismatches=12, fresh_object=0):
+    # mapper/params.h:134-136, 174: 3, 50, max_no_errors * sensitivity_factor
+    return SoftclipParams(max_query_len, 3, 50, max_mismatches, fresh_object, 0)
+
+
+def _o_softclip(self, genome, reads, offsets, lens, encoding, tasks, params=None, scoring=None, cigar_stride=512):
+    tasks = np.ascontiguousarray(tasks, SOFTCLIP_TASK)
+    prm = params or default_softclip_params()
+    sc = scoring or default_scoring()
+    res = np.zeros(len(tasks), SOFTCLIP_RESULT)
+    cig = np.zeros((len(tasks), cigar_stride), np.uint8)
+    rc = self.lib.wo_softclip_batch(_p(genome), _p(reads), _p(offsets), _p(lens), C.c_int(encoding), _p(tasks),
+                                    C.c_uint32(len(tasks)), C.byref(prm), C.byref(sc), _p(res), _p(cig),
+                                    C.c_uint32(cigar_stride))
+    return rc, res, cig
+
+
+def _r_softclip(self, genome, reads, offsets, lens, encoding, tasks, params=None, scoring=None, cigar_stride=512,
+                max_text_len=16384):
+    tasks = np.ascontiguousarray(tasks, SOFTCLIP_TASK)
+    prm = params or default_softclip_params()
+    sc = scoring or default_scoring()
+    res = np.zeros(len(tasks), SOFTCLIP_RESULT)
+    cig = np.zeros((len(tasks), cigar_stride), np.uint8)
+    rc = self.lib.ref_softclip_batch(_p(genome), _p(reads), _p(offsets), _p(lens), C.c_int(encoding), _p(tasks),
+                                     C.c_uint32(len(tasks)), C.byref(prm), C.byref(sc), C.c_uint32(max_text_len),
+                                     _p(res), _p(cig), C.c_uint32(cigar_stride))
+    return rc, res, cig
+
+
+Oracle.softclip_match = _o_softclip
+Reference.softclip_match = _r_softclip

@@ -635,3 +635,83 @@ REF_API int ref_clip_pairs_batch(uint32_t n_pairs, const wamd_clip_pair_task* ta
     }
     return 0;
 }
+
+
+/* ---- CSoftClipping::{preprocess | preprocessRawSeq, match, getExtCigar} around the calls of
+ * find_pairs<Clipping> (sam_matching.cpp:556-575) and fill_cigar_with_clipping (771-797).
+ * fresh_object: a new object per task (checked_pos_* zero-filled, soft_clipping.cpp:91-92);
+ * otherwise one object whose cells are all set to empty_pos_in_query first - the state
+ * clear_ckecked_pos() leaves in every cell it has ever touched (soft_clipping.h:107-115). */
+REF_API int ref_softclip_batch(const uint8_t* genome, const uint8_t* reads, const uint64_t* offsets,
+                               const uint32_t* lens, int encoding, const wamd_softclip_task* tasks, uint32_t n,
+                               const wamd_softclip_params* prm, const wamd_scoring* sc, uint32_t max_text_len,
+                               wamd_softclip_result* results, uint8_t* cigars, uint32_t cigar_stride)
+{
+    SamGenBox box;
+    scoring_t scoring = make_scoring(sc);
+    auto make = [&]() {
+        auto* c = new CSoftClipping(prm->max_query_len, max_text_len, prm->min_approx_indel_len,
+                                    prm->max_approx_indel_len, prm->max_approx_indel_mismatches);
+        c->setReference(const_cast<uint8_t*>(genome), 0, 0);   // sam.cpp:221
+        return c;
+    };
+    std::unique_ptr<CSoftClipping> shared;
+    if (!prm->fresh_object) {
+        shared.reset(make());
+        std::fill(shared->checked_pos_left.begin(), shared->checked_pos_left.end(), shared->empty_pos_in_query);
+        std::fill(shared->checked_pos_right.begin(), shared->checked_pos_right.end(), shared->empty_pos_in_query);
+    }
+    std::vector<uint8_t> read_codes(prm->max_query_len + 8), ref_codes((size_t)max_text_len + prm->max_query_len + 16);
+    for (uint32_t i = 0; i < n; ++i) {
+        const wamd_softclip_task& t = tasks[i];
+        wamd_softclip_result& r = results[i];
+        memset(&r, 0, sizeof(r));
+        uint8_t* ec = cigars + (size_t)i * cigar_stride;
+        ec[0] = 0;
+        const uint32_t m = lens[t.read_idx];
+        uint8_t* seq = const_cast<uint8_t*>(reads + offsets[t.read_idx]);
+        const bool rev = t.flags & WAMD_TASK_FLAG_REV_COMP;
+        const genome_t dir = rev ? genome_t::rev_comp : genome_t::direct;
+        std::unique_ptr<CSoftClipping> own;
+        CSoftClipping* c = shared.get();
+        if (!c) {
+            own.reset(make());
+            c = own.get();
+        }
+        if (encoding == WAMD_READS_NIBBLE)
+            c->preprocess(seq, m, dir);
+        else
+            c->preprocessRawSeq(seq, m, dir);
+        ref_pos_t pos = 0;
+        uint32_t lc = 0, rcl = 0, lm = 0, rm = 0, mm = 0;
+        int32_t del = 0;
+        if (!c->match(t.ref_pos, t.max_distance_in_ref, t.min_exact_len, pos, lc, rcl, lm, rm, del, mm))
+            continue;
+        r.found = 1;
+        r.pos = pos;
+        r.left_clipping = lc;
+        r.right_clipping = rcl;
+        r.left_match = lm;
+        r.right_match = rm;
+        r.del_size = del;
+        r.no_mismatches = mm;
+        if (encoding == WAMD_READS_ASCII) {
+            if (!rev)
+                box.get()->copy_direct(read_codes.data() + 1, seq, m);
+            else
+                box.get()->convert_to_rev_comp(read_codes.data() + 1, seq, m);
+        } else {
+            for (uint32_t z = 0; z < m; ++z) {
+                uint32_t code = rev ? shim_rc(shim_nib(seq, m - 1 - z)) : shim_nib(seq, z);
+                read_codes[z + 1] = (uint8_t)(code > 4 ? 4 : code);
+            }
+        }
+        box.get()->ref_copy_direct(ref_codes.data(), const_cast<uint8_t*>(genome), t.ref_pos,
+                                   t.max_distance_in_ref + m);   // sam_matching.cpp:568
+        double score = 0;
+        c->getExtCigar(ec, ref_codes.data(), read_codes.data(), pos, m, lc, rcl, lm, rm, del, mm, scoring, score);
+        r.affine_score = score;
+        r.cigar_len = (uint32_t)strlen((const char*)ec);
+    }
+    return 0;
+}

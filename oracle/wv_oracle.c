@@ -1593,6 +1593,329 @@ int wo_clip_pairs_batch(uint32_t n_pairs, const wamd_clip_pair_task* tasks, wamd
     return rc;
 }
 
+/* ---- CSoftClipping::match + getExtCigar (soft_clipping.cpp:28-48, 139-231, 234-589) ------- */
+
+#define SC_HASH_LEN 20u                      /* HashTable::hash_len, soft_clipping.cpp:25 */
+#define SC_EMPTY 0xffffffffu                 /* HashTable::EMPTY_CELL, soft_clipping.cpp:24 */
+#define SC_EMPTY_POS (1u << 30)              /* empty_pos_in_query, soft_clipping.h:102 */
+
+static uint64_t sc_increment(uint64_t key, uint8_t symbol) /* soft_clipping.h:69-71 */
+{
+    return ((key << 2) + symbol) & ((1ull << 2 * SC_HASH_LEN) - 1);
+}
+
+uint32_t wo_softclip_table_size(uint32_t max_query_len) /* soft_clipping.cpp:45-48 */
+{
+    uint32_t ht_size;
+    for (ht_size = 256; ht_size / max_query_len < 50; ht_size *= 2)
+        ;
+    return ht_size;
+}
+
+/* query: oriented read codes as preprocess / preprocessRawSeq leave them; tref / tread: what
+ * ref_copy_direct and copy_direct / convert_to_rev_comp hand to getExtCigar. */
+int wo_softclip(const uint8_t* genome, const uint8_t* query, uint32_t query_len, uint32_t ref_pos,
+                uint32_t max_distance_in_ref, uint32_t min_exact_len, const wamd_softclip_params* prm,
+                const wamd_scoring* sc, wamd_softclip_result* res, uint8_t* ext_cigar)
+{
+    const uint32_t W = max_distance_in_ref;
+    const uint32_t ht_size = wo_softclip_table_size(prm->max_query_len), ht_mask = ht_size - 1;
+    const uint64_t ht_mult = 0x5555555555555555ull;
+    memset(res, 0, sizeof(*res));
+    ext_cigar[0] = 0;
+    if (query_len < SC_HASH_LEN || query_len > prm->max_query_len)
+        return -1;
+    uint32_t* ht = (uint32_t*)malloc(sizeof(uint32_t) * ht_size);
+    uint8_t* gp = (uint8_t*)malloc((size_t)W + query_len + 16);
+    uint32_t* checked_left = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)W + 16));
+    uint32_t* checked_right = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)W + 16));
+    uint32_t* left_mm = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)query_len + 1));
+    uint32_t* right_mm = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)query_len + 1));
+    memset(ht, 0xff, sizeof(uint32_t) * ht_size);
+    for (uint32_t i = 0; i < W + 16; ++i) /* zero in a new object, empty_pos_in_query once touched and cleared */
+        checked_left[i] = checked_right[i] = prm->fresh_object ? 0u : SC_EMPTY_POS;
+
+    /* preprocess*, 139-231: every 20-mer of the read, in order, linear probing */
+    uint64_t ht_val = 0;
+    for (uint32_t i = 0; i < query_len; ++i) {
+        ht_val = sc_increment(ht_val, query[i]);
+        if (i >= SC_HASH_LEN - 1) {
+            uint32_t p = (uint32_t)(ht_val * ht_mult) & ht_mask;
+            while (ht[p] != SC_EMPTY)
+                p = (p + 1) & ht_mask;
+            ht[p] = i - (SC_HASH_LEN - 1);
+        }
+    }
+
+    /* 242-243: dummy symbol, then the window and what an extension can run into */
+    gp[0] = 7;
+    for (uint32_t i = 0; i < W + query_len + 8; ++i)
+        gp[1 + i] = (uint8_t)nib(genome, (uint64_t)ref_pos + i);
+
+    uint32_t no_mismatches = 0;
+    uint64_t key = 0;
+    uint32_t best_text_pos = 0, best_query_pos = 0, best_exact_len = 0;
+    int32_t best_score = 0, left_exact_len = 0, left_text_pos = 0;
+    uint32_t best_left_len = 0, best_right_len = 0;
+    uint32_t j;
+    for (j = 1; j < SC_HASH_LEN; ++j) /* 259-260 */
+        key = sc_increment(key, gp[j]);
+    for (; j <= W; ++j) { /* 265-461 */
+        key = sc_increment(key, gp[j]);
+        uint32_t pos_in_query;
+        uint32_t ht_pos = (uint32_t)(key * ht_mult) & ht_mask;
+        while ((pos_in_query = ht[ht_pos]) != SC_EMPTY) {
+            const uint32_t pos_in_text = j - (SC_HASH_LEN - 1);
+            const uint32_t front = pos_in_text - pos_in_query;
+            if (front <= W) {
+                int32_t len = 0;
+                if (checked_left[front] + 1 != pos_in_query) {
+                    const uint8_t* qq = query + pos_in_query;
+                    const uint8_t* gg = gp + pos_in_text;
+                    const int len_range = (int)(query_len - pos_in_query);
+                    for (; len < len_range && *qq == *gg; ++len, ++qq, ++gg)
+                        ;
+                    if (len >= (int)min_exact_len) {
+                        if (len > best_score) { /* 295-303 */
+                            best_score = len;
+                            best_query_pos = pos_in_query;
+                            best_text_pos = front;
+                            best_left_len = 0;
+                            best_right_len = 0;
+                            best_exact_len = (uint32_t)len;
+                        }
+                        if (pos_in_query == 0) { /* 305-309 */
+                            left_exact_len = len;
+                            left_text_pos = (int32_t)front;
+                        } else if (pos_in_query + (uint32_t)len == query_len && left_exact_len > 0) { /* 310-447 */
+                            const int32_t text_dist = (int32_t)(pos_in_text + (uint32_t)len) - left_text_pos;
+                            int exact_found = 0;
+                            if (left_exact_len + len >= (int32_t)query_len) { /* deletion, 317-338 */
+                                left_exact_len -= left_exact_len + len - (int32_t)query_len;
+                                if (text_dist > (int32_t)query_len) {
+                                    const int32_t score = (int32_t)query_len - (text_dist - (int32_t)query_len);
+                                    exact_found = 1;
+                                    if (score > best_score) {
+                                        best_score = score;
+                                        best_left_len = (uint32_t)left_exact_len;
+                                        best_right_len = (uint32_t)len;
+                                        best_query_pos = 0;
+                                        best_text_pos = (uint32_t)left_text_pos;
+                                        left_exact_len = 0;
+                                        best_exact_len = 0;
+                                        no_mismatches = 0;
+                                    }
+                                }
+                            } else if (left_exact_len + len == text_dist) { /* insertion, 339-355 */
+                                const int32_t score = text_dist;
+                                exact_found = 1;
+                                if (score > best_score) {
+                                    best_score = score;
+                                    best_left_len = (uint32_t)left_exact_len;
+                                    best_right_len = (uint32_t)len;
+                                    best_query_pos = 0;
+                                    best_text_pos = (uint32_t)left_text_pos;
+                                    left_exact_len = 0;
+                                    best_exact_len = 0;
+                                    no_mismatches = 0;
+                                }
+                            }
+                            const int potential_indel_len = abs(text_dist - (int)query_len); /* 358-360 */
+                            if (!exact_found && potential_indel_len >= (int)prm->min_approx_indel_len &&
+                                potential_indel_len <= (int)prm->max_approx_indel_len &&
+                                checked_right[front] != query_len) {
+                                const uint32_t max_cmp_dist = (uint32_t)text_dist < query_len ? (uint32_t)text_dist : query_len;
+                                const uint8_t* q0 = query;
+                                const uint8_t* g0 = gp + left_text_pos;
+                                left_mm[0] = 0;
+                                for (uint32_t i = 0; i < max_cmp_dist; ++i)
+                                    left_mm[i + 1] = left_mm[i] + (q0[i] != g0[i]);
+                                q0 = query + query_len - 1;
+                                g0 = gp + left_text_pos + text_dist - 1;
+                                right_mm[0] = 0;
+                                for (uint32_t i = 0; i < max_cmp_dist; ++i)
+                                    right_mm[i + 1] = right_mm[i] + (*(q0 - i) != *(g0 - i));
+                                if (text_dist > (int)query_len) { /* deletion, 383-412 */
+                                    int mid_point = 0, best_val_mid = (int)query_len + 1;
+                                    for (int i = 0; i <= (int)query_len; ++i)
+                                        if (left_mm[i] + right_mm[query_len - i] < (uint32_t)best_val_mid) {
+                                            best_val_mid = (int)(left_mm[i] + right_mm[query_len - i]);
+                                            mid_point = i;
+                                        }
+                                    if (best_val_mid <= (int)prm->max_approx_indel_mismatches) {
+                                        const int32_t score = (int32_t)query_len - (text_dist - (int32_t)query_len) - best_val_mid;
+                                        if (score > best_score) {
+                                            best_score = score;
+                                            best_left_len = (uint32_t)mid_point;
+                                            best_right_len = query_len - (uint32_t)mid_point;
+                                            best_query_pos = 0;
+                                            best_text_pos = (uint32_t)left_text_pos;
+                                            left_exact_len = 0;
+                                            best_exact_len = 0;
+                                            no_mismatches = (uint32_t)best_val_mid;
+                                        }
+                                    }
+                                } else { /* insertion, 413-442 */
+                                    int mid_point = 0, best_val_mid = (int)query_len + 1;
+                                    const int del_len = (int)query_len - text_dist;
+                                    for (int i = 0; i <= (int)query_len - del_len; ++i)
+                                        if (left_mm[i] + right_mm[text_dist - i] < (uint32_t)best_val_mid) {
+                                            best_val_mid = (int)(left_mm[i] + right_mm[text_dist - i]);
+                                            mid_point = i;
+                                        }
+                                    if (best_val_mid <= (int)prm->max_approx_indel_mismatches) {
+                                        const int32_t score = text_dist - best_val_mid;
+                                        if (score > best_score) {
+                                            best_score = score;
+                                            best_left_len = (uint32_t)mid_point;
+                                            best_right_len = (uint32_t)(text_dist - mid_point);
+                                            best_query_pos = 0;
+                                            best_text_pos = (uint32_t)left_text_pos;
+                                            left_exact_len = 0;
+                                            best_exact_len = 0;
+                                            no_mismatches = (uint32_t)best_val_mid;
+                                        }
+                                    }
+                                }
+                            }
+                            checked_right[front] = query_len; /* 445 */
+                        }
+                    }
+                }
+                if (len >= (int32_t)min_exact_len) /* 451-455 */
+                    checked_left[front] = pos_in_query;
+            }
+            if (++ht_pos >= ht_size) /* 459 */
+                ht_pos = 0;
+        }
+    }
+
+    int found = best_score >= (int32_t)min_exact_len; /* 463-464 */
+    uint32_t pos = 0, left_clipping = 0, right_clipping = 0, left_match = 0, right_match = 0;
+    int32_t del_size = 0;
+    if (found) {
+        pos = best_text_pos - 1;
+        if (best_exact_len) { /* 466-474 */
+            left_clipping = best_query_pos;
+            right_clipping = query_len - best_query_pos - best_exact_len;
+        } else { /* 475-492 */
+            left_match = best_left_len;
+            right_match = best_right_len;
+            if (best_left_len + best_right_len == query_len)
+                del_size = (int32_t)(query_len - ((uint32_t)best_score + no_mismatches));
+            else
+                del_size = -(int32_t)(query_len - left_match - right_match);
+            if ((uint32_t)abs(del_size) > 2 * prm->max_approx_indel_len)
+                found = 0;
+        }
+    }
+    if (found) {
+        res->found = 1;
+        res->pos = pos;
+        res->left_clipping = left_clipping;
+        res->right_clipping = right_clipping;
+        res->left_match = left_match;
+        res->right_match = right_match;
+        res->del_size = del_size;
+        res->no_mismatches = no_mismatches;
+
+        /* getExtCigar, 498-589.  tmp_ref_sequence[i] = min(genome[ref_pos + i], N_ref)
+         * (ref_copy_direct, sam.cpp:2350-2375) = min(gp[i + 1], 5); tmp_read_sequence[i + 1] =
+         * min(query[i], N_read) (copy_direct / convert_to_rev_comp, sam.cpp:2296-2347). */
+        static const char decode[] = "ACGTNNXX";
+#define TREF(i) (gp[(i) + 1] > 5 ? 5 : gp[(i) + 1])
+#define TREAD(i) (query[i] > 4 ? 4 : query[i])
+        const uint32_t seq_len = query_len;
+        if (left_match == 0 && right_match == 0) {
+            memset(ext_cigar, '$', left_clipping);
+            memset(ext_cigar + left_clipping, '.', seq_len - right_clipping - left_clipping);
+            memset(ext_cigar + seq_len - right_clipping, '$', right_clipping);
+            ext_cigar[seq_len] = 0;
+            res->cigar_len = seq_len;
+            res->affine_score = (seq_len - left_clipping - right_clipping) * sc->match +
+                                ((left_clipping > 0) ? sc->clipping : 0) + ((right_clipping > 0) ? sc->clipping : 0);
+        } else {
+            int cigar_pos = 0, read_pos = 0;
+            uint32_t p = pos;
+            if (no_mismatches) {
+                for (int i = 0; i < (int)left_match; ++i, ++p, ++read_pos)
+                    ext_cigar[cigar_pos++] = TREF(p) == TREAD(read_pos) ? '.' : (uint8_t)decode[TREF(p)];
+            } else {
+                memset(ext_cigar, '.', left_match);
+                cigar_pos += (int)left_match;
+                read_pos += (int)left_match;
+                p += left_match;
+            }
+            if (del_size > 0) {
+                for (int i = 0; i < del_size; ++i, ++p) {
+                    ext_cigar[cigar_pos++] = '^';
+                    ext_cigar[cigar_pos++] = (uint8_t)decode[TREF(p)];
+                }
+            } else {
+                for (int i = 0; i < -del_size; ++i, ++read_pos) {
+                    ext_cigar[cigar_pos++] = '#';
+                    ext_cigar[cigar_pos++] = (uint8_t)decode[TREAD(read_pos)];
+                }
+            }
+            if (no_mismatches) {
+                for (int i = 0; i < (int)right_match; ++i, ++p, ++read_pos)
+                    ext_cigar[cigar_pos++] = TREF(p) == TREAD(read_pos) ? '.' : (uint8_t)decode[TREF(p)];
+            } else {
+                memset(ext_cigar + cigar_pos, '.', right_match);
+                cigar_pos += (int)right_match;
+            }
+            ext_cigar[cigar_pos] = 0;
+            res->cigar_len = (uint32_t)cigar_pos;
+            res->affine_score = (double)((int64_t)left_match + right_match - no_mismatches) * sc->match +
+                                no_mismatches * sc->mismatch;
+            if (del_size > 0)
+                res->affine_score += sc->gap_del_open + (double)(abs(del_size) - 1ll) * sc->gap_del_extend;
+            else if (del_size < 0)
+                res->affine_score += sc->gap_ins_open + (double)(abs(del_size) - 1ll) * sc->gap_ins_extend;
+        }
+#undef TREF
+#undef TREAD
+    }
+    free(ht);
+    free(gp);
+    free(checked_left);
+    free(checked_right);
+    free(left_mm);
+    free(right_mm);
+    return found;
+}
+
+int wo_softclip_batch(const uint8_t* genome, const uint8_t* reads, const uint64_t* offsets, const uint32_t* lens,
+                      int encoding, const wamd_softclip_task* tasks, uint32_t n, const wamd_softclip_params* prm,
+                      const wamd_scoring* sc, wamd_softclip_result* results, uint8_t* cigars, uint32_t cigar_stride)
+{
+    uint8_t* q = (uint8_t*)malloc(64 * WO_MAX_WORDS + 8);
+    int rc = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const wamd_softclip_task* t = &tasks[i];
+        const uint32_t m = lens[t->read_idx];
+        uint8_t* ec = cigars + (size_t)i * cigar_stride;
+        if (m + 4 * prm->max_approx_indel_len + 1 > cigar_stride) {
+            rc = 1;
+            memset(&results[i], 0, sizeof(results[i]));
+            ec[0] = 0;
+            continue;
+        }
+        { /* preprocess (rev_comp_code: 8..15 -> 7) / preprocessRawSeq, soft_clipping.cpp:50-76, 139-231 */
+            const uint8_t* seq = reads + offsets[t->read_idx];
+            const int rev = t->flags & WAMD_TASK_FLAG_REV_COMP;
+            for (uint32_t z = 0; z < m; ++z)
+                q[z] = encoding == WAMD_READS_NIBBLE
+                           ? (uint8_t)(rev ? rc_code(nib(seq, m - z - 1)) : nib(seq, z))
+                           : (uint8_t)ascii_code((rev ? seq[m - z - 1] : seq[z]) & 0x7f, rev);
+        }
+        if (wo_softclip(genome, q, m, t->ref_pos, t->max_distance_in_ref, t->min_exact_len, prm, sc, &results[i], ec) < 0)
+            rc = 1;
+    }
+    free(q);
+    return rc;
+}
+
 /* ---- wire records ------------------------------------------------------------- */
 
 static uint8_t indel_size_encode(int32_t x) /* types.h:296-302 */

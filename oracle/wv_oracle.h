@@ -157,6 +157,15 @@ int wo_clip_illegal_batch(uint32_t n, const wamd_clip_illegal_task* tasks, wamd_
 int wo_clip_pairs_batch(uint32_t n_pairs, const wamd_clip_pair_task* tasks, wamd_clip_record* records,
                         uint8_t* cigars, uint32_t cigar_stride);
 
+/* CSoftClipping::{preprocess, preprocessRawSeq, match, getExtCigar}, soft_clipping.cpp:139-589 */
+uint32_t wo_softclip_table_size(uint32_t max_query_len);
+int wo_softclip(const uint8_t* genome, const uint8_t* query, uint32_t query_len, uint32_t ref_pos,
+                uint32_t max_distance_in_ref, uint32_t min_exact_len, const wamd_softclip_params* prm,
+                const wamd_scoring* sc, wamd_softclip_result* res, uint8_t* ext_cigar);
+int wo_softclip_batch(const uint8_t* genome, const uint8_t* reads, const uint64_t* offsets, const uint32_t* lens,
+                      int encoding, const wamd_softclip_task* tasks, uint32_t n, const wamd_softclip_params* prm,
+                      const wamd_scoring* sc, wamd_softclip_result* results, uint8_t* cigars, uint32_t cigar_stride);
+
 #ifdef __cplusplus
 }
 #endif

@@ -380,3 +380,66 @@ def clip_pairs_workload(oracle, n_pairs, seed, m=150):
         del la
     rec["cigar_len"] = [len(bytes(c).split(b"\0")[0]) for c in cig]
     return tasks, rec, cig
+
+
+def softclip_workload(n, seed, m=150, W=700, encoding=1, gen=None, lens_jitter=False):
+    """Inputs of CSoftClipping::match (soft_clipping.cpp:234-495) as the mate rescue builds them
+    (sam_matching.cpp:543-558): reads matching exactly except for junk ends (-> clipping), reads
+    with one long deletion / insertion with and without a few substitutions around it, reads that
+    share nothing with the window, in both orientations, anywhere inside a window of W symbols."""
+    import torch
+    from oracle import bindings as ob
+    codes, packed = gen if gen is not None else genome()
+    g = torch.Generator().manual_seed(seed)
+    G = codes.numel()
+    reads, tasks = [], np.zeros(n, ob.SOFTCLIP_TASK)
+
+    def rnd(lo, hi):
+        return int(torch.randint(lo, hi, (1,), generator=g))
+
+    def junk(k):
+        return torch.randint(0, 4, (k,), generator=g, dtype=torch.uint8)
+
+    for i in range(n):
+        mi = m - rnd(0, 8) if lens_jitter else m
+        p = rnd(synth.BOUNDARY_N_LEN + W + 200, G - synth.BOUNDARY_N_LEN - 2 * W - 400)
+        src = codes[p:p + mi + 300].clone()
+        kind = i % 10
+        if kind in (0, 1, 2):                      # exact core, junk at either end or both
+            r = src[:mi].clone()
+            if kind in (0, 2):
+                c = rnd(1, 70)
+                r[:c] = junk(c)
+            if kind in (1, 2):
+                c = rnd(1, 70)
+                r[mi - c:] = junk(c)
+        elif kind in (3, 4):                       # long deletion, (4) with substitutions around it
+            x, L = rnd(22, mi - 22), rnd(1, 120)
+            r = torch.cat([src[:x], src[x + L:x + L + mi - x]])
+        elif kind in (5, 6):                       # long insertion
+            x, L = rnd(22, mi - 45), rnd(1, 60)
+            L = min(L, mi - x - 22)
+            r = torch.cat([src[:x], junk(L), src[x:x + mi - x - L]])
+        elif kind == 7:                            # nothing in common
+            r = junk(mi)
+        elif kind == 8:                            # two exact blocks from different places (long gap)
+            x = rnd(25, mi - 25)
+            r = torch.cat([src[:x], src[200:200 + mi - x]])
+        else:                                      # untouched copy
+            r = src[:mi].clone()
+        if kind in (4, 6) or i % 7 == 0:
+            for _ in range(rnd(1, 6)):
+                z = rnd(0, mi)
+                r[z] = (int(r[z]) + rnd(1, 4)) & 3
+        r = r[:mi].clone()
+        r[r > 3] = 4
+        if i % 23 == 0:
+            r[rnd(0, mi)] = 4
+        rc = bool(i & 1)
+        reads.append(synth.rev_comp(r) if rc else r)
+        start = p - rnd(0, W - mi - 60)
+        if i % 41 == 0:
+            start = p                                 # match at the very first window position
+        tasks[i] = (i, start, W, 20, 1 if rc else 0, 0)
+    blob, off, lens = mixed_reads(reads, encoding)
+    return codes, packed, (blob, off, lens), tasks

@@ -96,6 +96,20 @@ def make_clip_l(ref):
                                          (rec2["right_clipping"] != rec["right_clipping"])).sum()), "of", len(rec))
 
 
+def make_softclip(ref, codes, packed):
+    """Row S fixtures: the reference's CSoftClipping::{preprocessRawSeq, match, getExtCigar}."""
+    for name, W, fresh, n in (("softclip_m150_w700", 700, 0, 700), ("softclip_m150_w1427_fresh", 1427, 1, 500)):
+        _, _, (blob, off, lens), tasks = common.softclip_workload(n, seed=900 + W, W=W, encoding=1,
+                                                                  gen=(codes, packed), lens_jitter=bool(fresh))
+        prm = bindings.default_softclip_params(fresh_object=fresh)
+        rc, res, cig = ref.softclip_match(packed, blob, off, lens, 1, tasks, prm, cigar_stride=384)
+        assert rc == 0
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), kind="softclip", blob=blob, off=off, lens=lens,
+                            encoding=1, tasks=tasks, results=res, cigars=cig, cigar_stride=384, fresh_object=fresh,
+                            max_query_len=151, max_mismatches=12)
+        print(name, "found", int(res["found"].sum()), "of", n, "indels", int((res["del_size"] != 0).sum()))
+
+
 def main():
     ref = bindings.Reference()
     codes = synth.make_genome(GENOME_SYMBOLS, seed=GENOME_SEED)
@@ -106,6 +120,9 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "samcigar":
         make_sam_cigar(ref)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "softclip":
+        make_softclip(ref, codes, packed)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "clipl":
         make_clip_l(ref)
@@ -176,6 +193,7 @@ def main():
     make_cf(ref, codes, packed, ref_size)
     make_sam_cigar(ref)
     make_clip_l(ref)
+    make_softclip(ref, codes, packed)
     rc, rec2, cig2 = ref.clip_boundary(rec, cig)
     np.savez_compressed(os.path.join(HERE, "clip_m150.npz"), kind="clip", records=rec, cigars=cig,
                         out_records=rec2, out_cigars=cig2)

@@ -132,3 +132,15 @@ def test_clip_overlapping_pairs(ctx, name):
     z = gu.load(name)
     rec, cig = ctx.clip_overlapping_pairs(z["tasks"], z["records"], z["cigars"])
     _check_clip_l(z, rec, cig, ("no_clippings",))
+
+
+@pytest.mark.parametrize("name", gu.cases("softclip"))
+def test_softclip_match(ctx, name):
+    z = gu.load(name)
+    prm = api.default_softclip_params(int(z["max_query_len"]), int(z["max_mismatches"]), int(z["fresh_object"]))
+    reads = ctx.upload_reads(z["blob"], z["off"], z["lens"], int(z["encoding"]), orientations=3)
+    res, cig = ctx.softclip_match(reads, z["tasks"], prm, cigar_stride=int(z["cigar_stride"]))
+    reads.free()
+    np.testing.assert_array_equal(res, z["results"])
+    for i in range(len(res)):
+        assert gu.cigar_bytes(cig, i) == gu.cigar_bytes(z["cigars"], i), i

@@ -352,6 +352,47 @@ def test_clip_overlapping_pairs(ctx, oracle):
         ctx.clip_overlapping_pairs(t2, rec2, cig2)
 
 
+@pytest.mark.parametrize("lowcx,fresh,enc,W", [(0, 0, 1, 700), (0, 1, 1, 1427), (1, 0, 1, 700), (1, 1, 0, 260),
+                                                (1, 0, 1, 4000)])
+def test_softclip_match(ctx, oracle, lowcx, fresh, enc, W):
+    """Row S: the hashing mate rescue, CSoftClipping::{preprocess*, match, getExtCigar}."""
+    from oracle import bindings as ob
+    gen = common.low_complexity_genome() if lowcx else common.genome()
+    codes, packed, (blob, off, lens), tasks = common.softclip_workload(2500, seed=50 + W + fresh, W=W, encoding=enc,
+                                                                       gen=gen, lens_jitter=bool(fresh))
+    _, want, wcig = oracle.softclip_match(packed, blob, off, lens, enc, tasks, ob.default_softclip_params(fresh_object=fresh))
+    c2 = api.Context(packed, ref_size=codes.numel(), cur_offset=0)
+    try:
+        reads = c2.upload_reads(blob, off, lens, enc, orientations=3)
+        got, gcig = c2.softclip_match(reads, tasks, api.default_softclip_params(fresh_object=fresh))
+        reads.free()
+    finally:
+        c2.destroy()
+    assert want["found"].sum() > 1500 and (want["del_size"] != 0).sum() > 100
+    np.testing.assert_array_equal(got, want)
+    for i in range(len(want)):
+        n = want["cigar_len"][i] + 1
+        assert bytes(gcig[i, :n]) == bytes(wcig[i, :n]), i
+
+
+def test_softclip_match_errors(ctx, oracle):
+    """Reads shorter than one 20-mer and windows above max_text_len are errors, as is a table beyond LDS."""
+    codes, packed, (blob, off, lens), tasks = common.softclip_workload(64, seed=3, W=300)
+    reads = ctx.upload_reads(blob, off, lens, 1, orientations=3)
+    bad = tasks.copy()
+    bad["max_distance_in_ref"] = 20000
+    with pytest.raises(api.WamdError):
+        ctx.softclip_match(reads, bad)
+    with pytest.raises(api.WamdError):
+        ctx.softclip_match(reads, tasks, api.default_softclip_params(max_query_len=4000))
+    reads.free()
+    short = np.frombuffer(b"ACGTACGTAC", np.uint8).copy()
+    r2 = ctx.upload_reads(short, np.array([0], np.uint64), np.array([10], np.uint32), 1, orientations=3)
+    with pytest.raises(api.WamdError):
+        ctx.softclip_match(r2, tasks[:1], api.default_softclip_params())
+    r2.free()
+
+
 def test_sam_cigar(ctx, oracle):
     """Row X: SAM CIGAR text, BAM operations and MD:Z from ext-CIGARs of every flavour."""
     ext = common.ext_cigar_pool(oracle, n=6000, seed=21)

@@ -136,3 +136,16 @@ def test_clip_overlapping_pairs(oracle, name):
     rc, rec, cig = oracle.clip_overlapping_pairs(z["tasks"], z["records"], z["cigars"])
     assert rc == 0
     _check_clip_l(z, rec, cig, ("no_clippings",))
+
+
+@pytest.mark.parametrize("name", gu.cases("softclip"))
+def test_softclip_match(oracle, name):
+    from oracle import bindings as ob
+    z = gu.load(name)
+    packed, _ = gu.load_genome()
+    prm = ob.default_softclip_params(int(z["max_query_len"]), int(z["max_mismatches"]), int(z["fresh_object"]))
+    rc, res, cig = oracle.softclip_match(packed, z["blob"], z["off"], z["lens"], int(z["encoding"]), z["tasks"], prm,
+                                         cigar_stride=int(z["cigar_stride"]))
+    assert rc == 0
+    np.testing.assert_array_equal(res, z["results"])
+    np.testing.assert_array_equal(cig, z["cigars"])

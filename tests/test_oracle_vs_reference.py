@@ -173,3 +173,22 @@ def test_clip_overlapping_pairs(oracle, reference):
     changed = (ra["left_clipping"] != rec["left_clipping"]) | (ra["right_clipping"] != rec["right_clipping"])
     assert changed.sum() > 1000
     _same_clip_output(ra, ca, rb, cb, skip=("no_clippings",))   # the reference does not say whether it clipped
+
+
+@pytest.mark.parametrize("lowcx,fresh,enc,W", [(0, 0, 1, 700), (0, 1, 1, 1427), (1, 0, 1, 700), (1, 1, 0, 260),
+                                                (1, 0, 0, 260)])
+def test_softclip_match(oracle, reference, lowcx, fresh, enc, W):
+    """Row S: CSoftClipping::{preprocess*, match, getExtCigar} (soft_clipping.cpp:139-589) - random genome
+    and tandem repeats (shared probe chains, fake hits), fresh and long-lived object state."""
+    from oracle import bindings as ob
+    gen = common.low_complexity_genome() if lowcx else None
+    codes, packed, (blob, off, lens), tasks = common.softclip_workload(1500, seed=10 + W + fresh, W=W, encoding=enc,
+                                                                       gen=gen, lens_jitter=bool(fresh))
+    prm = ob.default_softclip_params(fresh_object=fresh)
+    rc1, a, ca = oracle.softclip_match(packed, blob, off, lens, enc, tasks, prm)
+    rc2, b, cb = reference.softclip_match(packed, blob, off, lens, enc, tasks, prm)
+    assert rc1 == 0 and rc2 == 0
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(ca, cb)
+    assert a["found"].sum() > 1000 and (a["del_size"] > 0).sum() > 30 and (a["del_size"] < 0).sum() > 30
+    assert (a["no_mismatches"] > 0).sum() > 20 and (a["found"] == 0).sum() > 100

@@ -38,6 +38,23 @@ CF_TASK = np.dtype([("read_idx", "<u4"), ("position", "<u4"), ("read_offset", "<
 CLIP_ILLEGAL_TASK = np.dtype([("ref_size", "<i4"), ("read_length", "<u2"), ("perfect", "<u2")])
 CLIP_PAIR_TASK = np.dtype([("ref_seq_id", "<i4", (2,)), ("read_length", "<u2", (2,)), ("direct", "u1", (2,)),
                            ("perfect", "u1", (2,))])
+SOFTCLIP_TASK = np.dtype([("read_idx", "<u4"), ("ref_pos", "<u4"), ("max_distance_in_ref", "<u4"),
+                          ("min_exact_len", "<u2"), ("flags", "u1"), ("reserved", "u1")])
+SOFTCLIP_RESULT = np.dtype([("affine_score", "<f8"), ("found", "<u4"), ("pos", "<u4"), ("left_clipping", "<u4"),
+                            ("right_clipping", "<u4"), ("left_match", "<u4"), ("right_match", "<u4"),
+                            ("del_size", "<i4"), ("no_mismatches", "<u4"), ("cigar_len", "<u4"), ("reserved", "<u4")])
+
+
+class SoftclipParams(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("max_query_len", "min_approx_indel_len", "max_approx_indel_len",
+                                          "max_approx_indel_mismatches", "fresh_object", "reserved")]
+
+
+def default_softclip_params(max_query_len=151, max_mismatches=12, fresh_object=0):
+    # mapper/params.h:134-136, 174
+    return SoftclipParams(max_query_len, 3, 50, max_mismatches, fresh_object, 0)
+
+
 SAM_CIGAR_LEN = np.dtype([("cigar_len", "<u4"), ("mdz_len", "<u4"), ("cigar_bin_len", "<u4"), ("reserved", "<u4")])
 INDEL_TASK = np.dtype([("read_idx", "<u4"), ("ref_pos", "<u4"), ("max_indel_size", "<u2"),
                        ("fixed_segment_pos", "<u2"), ("fixed_segment_size", "<u2"),
@@ -71,7 +88,8 @@ EXPORTS = [
     "wamd_levdiag_dev", "wamd_cf_filter", "wamd_cf_filter_dev", "wamd_align", "wamd_align_dev", "wamd_align_workspace_bytes",
     "wamd_indel_match", "wamd_indel_match_dev", "wamd_indel_ext_cigar", "wamd_indel_ext_cigar_dev",
     "wamd_clip_boundary", "wamd_clip_boundary_dev", "wamd_clip_illegal", "wamd_clip_illegal_dev",
-    "wamd_clip_overlapping_pairs", "wamd_clip_overlapping_pairs_dev", "wamd_serialize_mappings",
+    "wamd_clip_overlapping_pairs", "wamd_clip_overlapping_pairs_dev", "wamd_softclip_match",
+    "wamd_softclip_match_dev", "wamd_serialize_mappings",
     "wamd_serialize_mappings_dev", "wamd_sam_cigar", "wamd_sam_cigar_dev", "wamd_records_scratch_bytes", "wamd_emit_lev_records_dev",
 ]
 
@@ -293,6 +311,23 @@ class Context:
         _check(lib().wamd_clip_overlapping_pairs(self.h, C.c_uint32(len(t)), _ptr(t), _ptr(rec), _ptr(cig),
                                                  C.c_uint32(cig.shape[1])))
         return rec, cig
+
+    def softclip_match(self, reads, tasks, params=None, cigar_stride=512):
+        """CSoftClipping::{preprocessRawSeq, match, getExtCigar} for a batch (soft_clipping.cpp:139-589)."""
+        t = np.ascontiguousarray(tasks, SOFTCLIP_TASK)
+        prm = params or default_softclip_params()
+        res = np.zeros(len(t), SOFTCLIP_RESULT)
+        cig = np.zeros((len(t), cigar_stride), np.uint8)
+        _check(lib().wamd_softclip_match(self.h, reads.h, _ptr(t), C.c_uint32(len(t)), C.byref(prm), _ptr(res),
+                                         _ptr(cig), C.c_uint32(cigar_stride)))
+        return res, cig
+
+    def softclip_match_dev(self, reads, d_tasks, n, d_results, d_cigars, cigar_stride, max_window, params=None,
+                           stream=None):
+        prm = params or default_softclip_params()
+        _check(lib().wamd_softclip_match_dev(self.h, reads.h, _ptr(d_tasks), C.c_uint32(n), C.byref(prm),
+                                             C.c_uint32(max_window), _ptr(d_results), _ptr(d_cigars),
+                                             C.c_uint32(cigar_stride), C.c_void_p(stream or 0)))
 
     def sam_cigar(self, ext_cigars, out_stride=None):
         """extract_cigar_and_mdz / extract_cigarbin_and_mdz for a batch (sam.cpp:805-1051):

@@ -1,0 +1,487 @@
+// softclip_match.hip - the hashing mate rescue, one candidate window per wave.
+//
+// Replaces CSoftClipping::{preprocess | preprocessRawSeq, match, getExtCigar}
+// (mapper/soft_clipping.cpp:139-231, 234-495, 498-589): all 20-mers of the read go into an
+// open-addressing table, the window is scanned for 20-mer hits, every hit is extended to a
+// maximal exact run, and the answer is the longest run (-> clippings on both sides) or a
+// left-boundary run + a right-boundary run = one long indel, optionally with a few
+// mismatches around it.
+//
+// What the result depends on, and is therefore reproduced literally:
+//   * the table itself - its size (from max_query_len), the multiplicative hash of which only
+//     the low bits survive the mask (so 20-mers sharing their last ~7 symbols share a probe
+//     chain), insertion order and linear probing: a chain is walked in cell order and every
+//     entry on it is "a hit", real or not;
+//   * the order of hits (text position, then chain order), because best-so-far, the remembered
+//     left-boundary run and the checked_pos marks are all updated on the way;
+//   * checked_pos_left's habit of suppressing only every other hit of a diagonal.
+//
+// Mapping to the wave: the 64 lanes look up 64 text positions at once (the table, the window
+// and the read sit in LDS; only the low 15 bits of a key reach the table index, i.e. the last
+// 8 symbols); positions with a non-empty first cell are then served one by one, in order, with
+// wave-uniform state, and the expensive parts of serving a hit are cooperative again: the
+// extension compares 512 symbols per step, the split search of the approximate indel is a
+// wave scan over mismatch differences.  Blocks are persistent: the table is cleared through
+// the insertion log, as the reference does.
+#include "wamd_internal.h"
+
+namespace wamd {
+
+namespace {
+
+constexpr uint32_t HASH_LEN = 20;          // HashTable::hash_len, soft_clipping.cpp:25
+constexpr uint32_t EMPTY16 = 0xffffu;      // EMPTY_CELL / empty_pos_in_query in 16 bits
+
+struct SoftclipLds {
+    uint32_t* text;        // window, nibble-swapped dwords: symbol s of a dword at bits 4s
+    uint32_t* query;       // oriented read codes, same packing
+    uint16_t* table;       // HashTable::data
+    uint16_t* cell;        // per read position: hashed cell, later the cell it was stored in (data_log)
+    uint16_t* checked_left;
+    uint32_t* checked_right;   // bit per text position: checked_pos_right[p] == query_len
+};
+
+__device__ __forceinline__ uint32_t sym(const uint32_t* a, uint32_t i) { return (a[i >> 3] >> (4 * (i & 7))) & 15u; }
+
+// eight symbols i .. i+7 as one dword (symbol i in the low nibble)
+__device__ __forceinline__ uint32_t sym8(const uint32_t* a, uint32_t i)
+{
+    return __builtin_amdgcn_alignbit(a[(i >> 3) + 1], a[i >> 3], 4 * (i & 7));
+}
+
+// low 15 bits of the rolling key after symbol i: HashTable::increment adds, it does not or, so
+// codes above 3 carry into the next symbol's bits (soft_clipping.h:69-71)
+__device__ __forceinline__ uint32_t key_low(const uint32_t* a, uint32_t i)
+{
+    const uint32_t w = sym8(a, i - 7);   // symbol i-7 in nibble 0 ... symbol i in nibble 7
+    uint32_t k = 0;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+        k += ((w >> (4 * (7 - t))) & 15u) << (2 * t);
+    return k & 0x7fffu;
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan(int32_t v, uint32_t lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int32_t o = __shfl_up(v, d);
+        if (lane >= (uint32_t)d)
+            v += o;
+    }
+    return (uint32_t)v;
+}
+
+__device__ __forceinline__ uint32_t wave_min(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1)
+        v = min(v, (uint32_t)__shfl_xor((int)v, d));
+    return v;
+}
+
+}   // namespace
+
+__global__ __launch_bounds__(64) void softclip_match_kernel(GenomeView g, ReadsView rv,
+                                                            const wamd_softclip_task* __restrict__ tasks, uint32_t n,
+                                                            wamd_softclip_params prm, wamd_scoring sc,
+                                                            uint32_t ht_size, uint32_t max_window, uint32_t max_len,
+                                                            uint32_t max_text_len,
+                                                            wamd_softclip_result* __restrict__ results,
+                                                            uint8_t* __restrict__ cigars, uint32_t cigar_stride,
+                                                            uint32_t* __restrict__ flags)
+{
+    extern __shared__ uint32_t lds_raw[];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t text_dw = (max_window + max_len + 16 + 7) / 8 + 2;
+    const uint32_t query_dw = (max_len + 7) / 8 + 2;
+    SoftclipLds L;
+    L.text = lds_raw;
+    L.query = L.text + text_dw;
+    L.checked_right = L.query + query_dw;
+    L.table = reinterpret_cast<uint16_t*>(L.checked_right + (max_window + 32) / 32);
+    L.cell = L.table + ht_size;
+    L.checked_left = L.cell + ((max_len + 1) & ~1u);
+    const uint32_t ht_mask = ht_size - 1;
+
+    for (uint32_t i = lane; i < ht_size / 2; i += 64)
+        reinterpret_cast<uint32_t*>(L.table)[i] = 0xffffffffu;
+    __syncthreads();
+
+    for (uint32_t task = blockIdx.x; task < n; task += gridDim.x) {
+        const wamd_softclip_task t = tasks[task];
+        wamd_softclip_result res;
+        res.affine_score = 0;
+        res.found = res.pos = res.left_clipping = res.right_clipping = res.left_match = res.right_match = 0;
+        res.del_size = 0;
+        res.no_mismatches = res.cigar_len = res.reserved = 0;
+        uint8_t* ec = cigars + (uint64_t)task * cigar_stride;
+
+        uint32_t err = 0, m = 0;
+        const uint32_t W = t.max_distance_in_ref;
+        const bool rc = t.flags & WAMD_TASK_FLAG_REV_COMP;
+        if (t.read_idx >= rv.n) {
+            err = FLAG_READ_IDX;
+        } else {
+            m = rv.lens[t.read_idx];
+            if (m < HASH_LEN || m > prm.max_query_len || m > max_len)
+                err = FLAG_ARG;   // the reference reads past the read / past its query buffer here
+            else if (W > max_text_len || W > max_window)
+                err = FLAG_TEXT_LEN;
+            else if ((uint64_t)t.ref_pos + W + m + 16 > g.n_symbols)
+                err = FLAG_RANGE;
+            else if (m + 4 * prm.max_approx_indel_len + 1 > cigar_stride)
+                err = FLAG_CIGAR;
+        }
+        if (err) {
+            if (lane == 0) {
+                raise_flag(flags, err);
+                res.found = RESULT_ERROR;
+                results[task] = res;
+                ec[0] = 0;
+            }
+            continue;
+        }
+
+        // ---- stage the window, the oriented read, and clear the marks -------------------
+        const uint32_t skew = t.ref_pos & 7u;          // gp[j] = text symbol skew + j - 1
+        const uint32_t n_text_dw = (skew + W + m + 16 + 7) / 8;
+        for (uint32_t i = lane; i < n_text_dw; i += 64)
+            L.text[i] = load_genome_dword(g, (t.ref_pos >> 3) + i);
+        {
+            const uint32_t* codes = reinterpret_cast<const uint32_t*>(rv.codes + rv.code_off[t.read_idx]);
+            const uint32_t n_dw = (m + 7) / 8;
+            for (uint32_t i = lane; i <= n_dw; i += 64) {
+                uint32_t w;
+                if (!rc) {
+                    w = i < n_dw ? nibble_swap(codes[i]) : 0u;
+                } else {   // oriented symbol p = rc_code(stored symbol m - 1 - p)
+                    w = 0;
+                    for (uint32_t s = 0; s < 8; ++s) {
+                        const uint32_t p = 8 * i + s;
+                        if (p < m) {
+                            const uint32_t z = m - 1 - p;
+                            const uint32_t c = (nibble_swap(codes[z >> 3]) >> (4 * (z & 7))) & 15u;
+                            w |= rc_code(c) << (4 * s);
+                        }
+                    }
+                }
+                L.query[i] = w;   // nibbles past the read are never compared: every run is bounded by its range
+            }
+        }
+        const uint32_t never = prm.fresh_object ? 0u : 0xffffffffu;
+        for (uint32_t i = lane; i <= (W + 1) / 2; i += 64)
+            reinterpret_cast<uint32_t*>(L.checked_left)[i] = never;
+        for (uint32_t i = lane; i <= W / 32; i += 64)
+            L.checked_right[i] = 0;
+        __syncthreads();
+
+        // ---- preprocess: insert every 20-mer in order, linear probing (139-231) ----------
+        for (uint32_t i = HASH_LEN - 1 + lane; i < m; i += 64)
+            L.cell[i] = (uint16_t)((key_low(L.query, i) * 0x5555u) & ht_mask);
+        __syncthreads();
+        for (uint32_t i = HASH_LEN - 1; i < m; ++i) {
+            uint32_t p = L.cell[i];
+            while (L.table[p] != EMPTY16)
+                p = (p + 1) & ht_mask;
+            if (lane == 0) {
+                L.table[p] = (uint16_t)(i - (HASH_LEN - 1));
+                L.cell[i] = (uint16_t)p;
+            }
+            __syncthreads();
+        }
+
+        // ---- match (234-495) ------------------------------------------------------------
+        const uint32_t min_exact = t.min_exact_len;
+        uint32_t no_mismatches = 0;
+        uint32_t best_text_pos = 0, best_query_pos = 0, best_exact_len = 0;
+        int32_t best_score = 0, left_exact_len = 0, left_text_pos = 0;
+        uint32_t best_left_len = 0, best_right_len = 0;
+
+        // symbol of gp[] / query[] helpers; gp[0] (the dummy 7) is never read below
+        auto gp8 = [&](uint32_t j) { return sym8(L.text, skew + j - 1); };
+        auto gp1 = [&](uint32_t j) { return sym(L.text, skew + j - 1); };
+
+        for (uint32_t jb = HASH_LEN; jb <= W; jb += 64) {
+            const uint32_t j = jb + lane;
+            uint32_t first_cell = 0;
+            bool hit = false;
+            if (j <= W) {
+                first_cell = (key_low(L.text, skew + j - 1) * 0x5555u) & ht_mask;
+                hit = L.table[first_cell] != EMPTY16;
+            }
+            uint64_t pending = __ballot(hit);
+            while (pending) {
+                const uint32_t src = (uint32_t)__builtin_ctzll(pending);
+                pending &= pending - 1;
+                const uint32_t jh = jb + src;
+                uint32_t ht_pos = (uint32_t)__shfl((int)first_cell, (int)src);
+                uint32_t pos_in_query;
+                while ((pos_in_query = L.table[ht_pos]) != EMPTY16) {   // 273-460
+                    const uint32_t pos_in_text = jh - (HASH_LEN - 1);
+                    const uint32_t front = pos_in_text - pos_in_query;
+                    if (front <= W) {
+                        int32_t len = 0;
+                        const uint32_t cl = L.checked_left[front];
+                        if ((cl == EMPTY16 ? (1u << 30) : cl) + 1 != pos_in_query) {
+                            // 286-291: common run of query[pos_in_query..] and gp[pos_in_text..]
+                            const uint32_t range = m - pos_in_query;
+                            len = (int32_t)range;
+                            for (uint32_t off = 0; off < range; off += 512) {
+                                const uint32_t o = off + 8 * lane;
+                                uint32_t diff = 0xffffffffu;
+                                if (o < range) {
+                                    diff = sym8(L.query, pos_in_query + o) ^ gp8(pos_in_text + o);
+                                    if (range - o < 8)
+                                        diff |= 0xffffffffu << (4 * (range - o));
+                                }
+                                const uint64_t bad = __ballot(diff != 0);
+                                if (bad) {
+                                    const uint32_t l0 = (uint32_t)__builtin_ctzll(bad);
+                                    const uint32_t d0 = (uint32_t)__shfl((int)diff, (int)l0);
+                                    const uint32_t stop = off + 8 * l0 + ((uint32_t)__builtin_ctz(d0) >> 2);
+                                    len = (int32_t)min(stop, range);
+                                    break;
+                                }
+                            }
+                            if (len >= (int32_t)min_exact) {
+                                if (len > best_score) {   // 295-303
+                                    best_score = len;
+                                    best_query_pos = pos_in_query;
+                                    best_text_pos = front;
+                                    best_left_len = 0;
+                                    best_right_len = 0;
+                                    best_exact_len = (uint32_t)len;
+                                }
+                                if (pos_in_query == 0) {   // 305-309
+                                    left_exact_len = len;
+                                    left_text_pos = (int32_t)front;
+                                } else if (pos_in_query + (uint32_t)len == m && left_exact_len > 0) {   // 310-447
+                                    const int32_t text_dist = (int32_t)(pos_in_text + (uint32_t)len) - left_text_pos;
+                                    bool exact_found = false;
+                                    bool take = false;
+                                    int32_t score = 0;
+                                    uint32_t new_left = 0, new_right = 0;
+                                    if (left_exact_len + len >= (int32_t)m) {   // deletion, 317-338
+                                        left_exact_len -= left_exact_len + len - (int32_t)m;
+                                        if (text_dist > (int32_t)m) {
+                                            score = (int32_t)m - (text_dist - (int32_t)m);
+                                            exact_found = true;
+                                            take = score > best_score;
+                                            new_left = (uint32_t)left_exact_len;
+                                            new_right = (uint32_t)len;
+                                        }
+                                    } else if (left_exact_len + len == text_dist) {   // insertion, 339-355
+                                        score = text_dist;
+                                        exact_found = true;
+                                        take = score > best_score;
+                                        new_left = (uint32_t)left_exact_len;
+                                        new_right = (uint32_t)len;
+                                    }
+                                    if (take) {
+                                        best_score = score;
+                                        best_left_len = new_left;
+                                        best_right_len = new_right;
+                                        best_query_pos = 0;
+                                        best_text_pos = (uint32_t)left_text_pos;
+                                        left_exact_len = 0;
+                                        best_exact_len = 0;
+                                        no_mismatches = 0;
+                                    }
+                                    const int32_t indel_len = abs(text_dist - (int32_t)m);   // 358-360
+                                    if (!exact_found && indel_len >= (int32_t)prm.min_approx_indel_len &&
+                                        indel_len <= (int32_t)prm.max_approx_indel_len &&
+                                        !((L.checked_right[front >> 5] >> (front & 31)) & 1u)) {
+                                        // 362-442.  With lm[i] = the left alignment mismatches at query i and
+                                        // rm[i] = the right alignment mismatches at query i + qs,
+                                        // left_mismatches[i] + right_mismatches[N - i] = sum(rm) + sum_{x<i} (lm - rm)
+                                        const bool deletion = text_dist > (int32_t)m;
+                                        const uint32_t N = deletion ? m : (uint32_t)text_dist;
+                                        const uint32_t qs = deletion ? 0u : m - (uint32_t)text_dist;
+                                        const uint32_t tl = (uint32_t)left_text_pos;                       // left: query i <-> gp[tl + i]
+                                        const uint32_t tr = (uint32_t)(left_text_pos + text_dist) - m + qs;   // right: query i + qs <-> gp[tr + i]
+                                        uint32_t total_rm = 0;
+                                        for (uint32_t off = 0; off < N; off += 64) {
+                                            const uint32_t i = off + lane;
+                                            const bool rm = i < N && sym(L.query, i + qs) != gp1(tr + i);
+                                            total_rm += (uint32_t)__popcll(__ballot(rm));
+                                        }
+                                        uint32_t best = total_rm << 16;   // i = 0
+                                        uint32_t run = total_rm;
+                                        for (uint32_t off = 0; off < N; off += 64) {
+                                            const uint32_t i = off + lane;
+                                            int32_t d = 0;
+                                            if (i < N)
+                                                d = (int32_t)(sym(L.query, i) != gp1(tl + i)) -
+                                                    (int32_t)(sym(L.query, i + qs) != gp1(tr + i));
+                                            const uint32_t incl = wave_incl_scan(d, lane);
+                                            const uint32_t f = run + incl;
+                                            best = min(best, wave_min(i < N ? (f << 16) | (i + 1) : 0xffffffffu));
+                                            run += (uint32_t)__shfl((int)incl, 63);
+                                        }
+                                        const int32_t best_val_mid = (int32_t)(best >> 16);
+                                        const uint32_t mid_point = best & 0xffffu;
+                                        if (best_val_mid <= (int32_t)prm.max_approx_indel_mismatches) {
+                                            const int32_t sc2 = deletion ? (int32_t)m - (text_dist - (int32_t)m) - best_val_mid
+                                                                         : text_dist - best_val_mid;
+                                            if (sc2 > best_score) {
+                                                best_score = sc2;
+                                                best_left_len = mid_point;
+                                                best_right_len = N - mid_point;
+                                                best_query_pos = 0;
+                                                best_text_pos = (uint32_t)left_text_pos;
+                                                left_exact_len = 0;
+                                                best_exact_len = 0;
+                                                no_mismatches = (uint32_t)best_val_mid;
+                                            }
+                                        }
+                                    }
+                                    if (lane == 0)   // 445
+                                        L.checked_right[front >> 5] |= 1u << (front & 31);
+                                }
+                            }
+                        }
+                        if (len >= (int32_t)min_exact && lane == 0)   // 451-455
+                            L.checked_left[front] = (uint16_t)pos_in_query;
+                        __syncthreads();
+                    }
+                    if (++ht_pos >= ht_size)   // 459
+                        ht_pos = 0;
+                }
+            }
+        }
+
+        // ---- outcome (463-494) -----------------------------------------------------------
+        bool found = best_score >= (int32_t)min_exact;
+        uint32_t pos = 0, left_clipping = 0, right_clipping = 0, left_match = 0, right_match = 0;
+        int32_t del_size = 0;
+        if (found) {
+            pos = best_text_pos - 1;
+            if (best_exact_len) {
+                left_clipping = best_query_pos;
+                right_clipping = m - best_query_pos - best_exact_len;
+            } else {
+                left_match = best_left_len;
+                right_match = best_right_len;
+                if (best_left_len + best_right_len == m)
+                    del_size = (int32_t)(m - ((uint32_t)best_score + no_mismatches));
+                else
+                    del_size = -(int32_t)(m - left_match - right_match);
+                if ((uint32_t)abs(del_size) > 2 * prm.max_approx_indel_len)
+                    found = false;
+            }
+        }
+
+        // ---- getExtCigar (498-589), one output byte per lane and step -------------------
+        if (found) {
+            // tmp_ref_sequence[i] = min(gp[i + 1], N_ref), tmp_read_sequence[i + 1] = min(query[i], N_read)
+            auto tref = [&](uint32_t i) { return min(sym(L.text, skew + i), 5u); };
+            auto tread = [&](uint32_t i) { return min(sym(L.query, i), 4u); };
+            const uint64_t decode = 0x58584e4e54474341ull;   // "ACGTNNXX"
+            auto letter = [&](uint32_t c) { return (uint8_t)(decode >> (8 * c)); };
+            uint32_t cigar_len;
+            double score;
+            if (left_match == 0 && right_match == 0) {
+                cigar_len = m;
+                for (uint32_t c = lane; c < m; c += 64)
+                    ec[c] = (c < left_clipping || c >= m - right_clipping) ? '$' : '.';
+                score = (double)(m - left_clipping - right_clipping) * sc.match + ((left_clipping > 0) ? sc.clipping : 0) +
+                        ((right_clipping > 0) ? sc.clipping : 0);
+            } else {
+                const uint32_t dels = del_size > 0 ? (uint32_t)del_size : 0u, ins = del_size < 0 ? (uint32_t)-del_size : 0u;
+                const uint32_t mid = 2 * (dels + ins);
+                cigar_len = left_match + mid + right_match;
+                for (uint32_t c = lane; c < cigar_len; c += 64) {
+                    uint8_t ch;
+                    if (c < left_match) {
+                        ch = (!no_mismatches || tref(pos + c) == tread(c)) ? '.' : letter(tref(pos + c));
+                    } else if (c < left_match + mid) {
+                        const uint32_t k = (c - left_match) >> 1;
+                        if ((c - left_match) & 1)
+                            ch = dels ? letter(tref(pos + left_match + k)) : letter(tread(left_match + k));
+                        else
+                            ch = dels ? '^' : '#';
+                    } else {
+                        const uint32_t i = c - left_match - mid;
+                        const uint32_t rp = pos + left_match + dels + i, qp = left_match + ins + i;
+                        ch = (!no_mismatches || tref(rp) == tread(qp)) ? '.' : letter(tref(rp));
+                    }
+                    ec[c] = ch;
+                }
+                score = (double)((int64_t)left_match + right_match - no_mismatches) * sc.match + no_mismatches * sc.mismatch;
+                if (del_size > 0)
+                    score += sc.gap_del_open + (double)((int64_t)dels - 1) * sc.gap_del_extend;
+                else if (del_size < 0)
+                    score += sc.gap_ins_open + (double)((int64_t)ins - 1) * sc.gap_ins_extend;
+            }
+            res.found = 1;
+            res.pos = pos;
+            res.left_clipping = left_clipping;
+            res.right_clipping = right_clipping;
+            res.left_match = left_match;
+            res.right_match = right_match;
+            res.del_size = del_size;
+            res.no_mismatches = no_mismatches;
+            res.cigar_len = cigar_len;
+            res.affine_score = score;
+            if (lane == 0)
+                ec[cigar_len] = 0;
+        } else if (lane == 0) {
+            ec[0] = 0;
+        }
+        if (lane == 0)
+            results[task] = res;
+
+        // ---- HashTable::reset through the log (soft_clipping.h:45-49) --------------------
+        __syncthreads();
+        for (uint32_t i = HASH_LEN - 1 + lane; i < m; i += 64)
+            L.table[L.cell[i]] = (uint16_t)EMPTY16;
+        __syncthreads();
+    }
+}
+
+uint32_t softclip_table_size(uint32_t max_query_len)   // soft_clipping.cpp:45-48
+{
+    uint64_t s = 256;
+    while (s / max_query_len < 50)
+        s *= 2;
+    return s > 0xffffffffull ? 0u : (uint32_t)s;
+}
+
+static uint64_t softclip_lds_bytes(uint32_t ht_size, uint32_t max_window, uint32_t max_len)
+{
+    const uint64_t text_dw = (max_window + max_len + 16 + 7) / 8 + 2, query_dw = (max_len + 7) / 8 + 2;
+    const uint64_t right_dw = (max_window + 32) / 32;
+    return 4 * (text_dw + query_dw + right_dw) + 2 * ((uint64_t)ht_size + ((max_len + 1) & ~1u) + max_window + 4);
+}
+
+int launch_softclip_match(wamd_ctx* ctx, const wamd_reads* r, const wamd_softclip_task* d_tasks, uint32_t n,
+                          const wamd_softclip_params* prm, uint32_t max_window, wamd_softclip_result* d_results,
+                          uint8_t* d_cigars, uint32_t cigar_stride, hipStream_t s)
+{
+    WAMD_HIP(hipSetDevice(ctx->device));
+    if (n == 0)
+        return WAMD_OK;
+    const uint32_t ht_size = softclip_table_size(prm->max_query_len);
+    if (max_window > ctx->max_text_len)
+        max_window = ctx->max_text_len;
+    const uint64_t lds = softclip_lds_bytes(ht_size, max_window, r->max_len);
+    if (ht_size == 0 || ht_size > 32768 || lds > 160 * 1024) {
+        set_error("wamd_softclip_match: max_query_len %u needs a %u-cell table (limit 32768 cells = max_query_len 655)",
+                  prm->max_query_len, ht_size);
+        return WAMD_ERR_TOO_LONG;
+    }
+    if (lds > 64 * 1024)
+        WAMD_HIP(hipFuncSetAttribute((const void*)softclip_match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds));
+    uint32_t per_cu = (uint32_t)((160 * 1024) / lds);
+    per_cu = per_cu < 1 ? 1 : (per_cu > 16 ? 16 : per_cu);
+    const uint32_t blocks = n < 256u * per_cu ? n : 256u * per_cu;
+    hipLaunchKernelGGL(softclip_match_kernel, dim3(blocks), dim3(64), (uint32_t)lds, s, genome_view(ctx), r->view(),
+                       d_tasks, n, *prm, ctx->scoring, ht_size, max_window, r->max_len, ctx->max_text_len, d_results,
+                       d_cigars, cigar_stride, ctx->d_flags);
+    WAMD_HIP(hipGetLastError());
+    return WAMD_OK;
+}
+
+}   // namespace wamd

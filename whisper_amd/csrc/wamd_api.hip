@@ -780,6 +780,58 @@ int wamd_clip_overlapping_pairs(wamd_ctx* ctx, uint32_t n_pairs, const wamd_clip
                           });
 }
 
+int wamd_softclip_match_dev(wamd_ctx* ctx, const wamd_reads* reads, const wamd_softclip_task* d_tasks, uint32_t n,
+                            const wamd_softclip_params* params, uint32_t max_window, wamd_softclip_result* d_results,
+                            uint8_t* d_cigars, uint32_t cigar_stride, void* stream)
+{
+    if (n == 0)
+        return WAMD_OK;
+    if (!ctx || !reads || !d_tasks || !params || !d_results || !d_cigars || params->max_query_len == 0 ||
+        reads->ctx != ctx) {
+        set_error("wamd_softclip_match_dev: missing argument, or reads of another context");
+        return WAMD_ERR_INVALID_ARG;
+    }
+    return launch_softclip_match(ctx, reads, d_tasks, n, params, max_window, d_results, d_cigars, cigar_stride,
+                                 pick(ctx, stream));
+}
+
+int wamd_softclip_match(wamd_ctx* ctx, const wamd_reads* reads, const wamd_softclip_task* tasks, uint32_t n,
+                        const wamd_softclip_params* params, wamd_softclip_result* results, uint8_t* cigars,
+                        uint32_t cigar_stride)
+{
+    if (n == 0)
+        return WAMD_OK;
+    int rc = check_batch(ctx, reads, tasks, results, "wamd_softclip_match");
+    if (rc)
+        return rc;
+    if (!params || !cigars)
+        return WAMD_ERR_INVALID_ARG;
+    uint32_t max_window = 0;
+    for (uint32_t i = 0; i < n; ++i)
+        max_window = tasks[i].max_distance_in_ref > max_window ? tasks[i].max_distance_in_ref : max_window;
+    WAMD_HIP(hipSetDevice(ctx->device));
+    auto up = [](uint64_t x) { return (x + 255) / 256 * 256; };
+    const uint64_t tb = (uint64_t)n * sizeof(wamd_softclip_task), rb = (uint64_t)n * sizeof(wamd_softclip_result),
+                   cb = (uint64_t)n * cigar_stride;
+    rc = ensure_stage(ctx, up(tb) + up(rb) + up(cb), 0);
+    if (rc)
+        return rc;
+    char* base = (char*)ctx->d_stage;
+    auto* d_tasks = (wamd_softclip_task*)base;
+    auto* d_res = (wamd_softclip_result*)(base + up(tb));
+    auto* d_cig = (uint8_t*)(base + up(tb) + up(rb));
+    hipStream_t s = ctx->stream;
+    WAMD_HIP(hipMemcpyAsync(d_tasks, tasks, tb, hipMemcpyHostToDevice, s));
+    rc = wamd_softclip_match_dev(ctx, reads, d_tasks, n, params, max_window, d_res, d_cig, cigar_stride, s);
+    if (rc)
+        return rc;
+    WAMD_HIP(hipMemcpyAsync(results, d_res, rb, hipMemcpyDeviceToHost, s));
+    WAMD_HIP(hipMemcpyAsync(cigars, d_cig, cb, hipMemcpyDeviceToHost, s));
+    uint32_t flags = 0;
+    rc = fetch_flags(ctx, s, &flags);
+    return rc ? rc : flags_to_status(flags);
+}
+
 int wamd_sam_cigar_dev(wamd_ctx* ctx, uint32_t n, const uint8_t* d_ext_cigars, uint32_t ext_stride,
                        uint8_t* d_cigars, uint32_t cigar_stride, uint8_t* d_mdz, uint32_t mdz_stride,
                        uint32_t* d_cigar_bin, uint32_t bin_stride, wamd_sam_cigar_len* d_lens, void* stream)

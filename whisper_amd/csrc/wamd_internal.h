@@ -143,6 +143,10 @@ int launch_sam_cigar(wamd_ctx* ctx, uint32_t n, const uint8_t* d_ext, uint32_t e
                      uint32_t cigar_stride, uint8_t* d_mdz, uint32_t mdz_stride, uint32_t* d_bin, uint32_t bin_stride,
                      wamd_sam_cigar_len* d_lens, hipStream_t s);
 
+int launch_softclip_match(wamd_ctx* ctx, const wamd_reads* r, const wamd_softclip_task* d_tasks, uint32_t n,
+                          const wamd_softclip_params* prm, uint32_t max_window, wamd_softclip_result* d_results,
+                          uint8_t* d_cigars, uint32_t cigar_stride, hipStream_t s);
+
 uint64_t records_scratch_bytes(uint32_t n);
 int launch_emit_lev_records(wamd_ctx* ctx, uint32_t n, const wamd_dist_task* d_tasks,
                             const wamd_dist_result* d_results, const uint32_t* d_record_pos,
