@@ -201,6 +201,24 @@ def run_extras(ctx, device, genome_symbols, stream, n_small):
     out["S8_indel_match"] = {"shape": "CIndelMatching::Match m=150 max_indel=50 k=12", "tasks": na, "kernel_ms": ms,
                              "candidates_per_s": na / ms * 1e3, "found_fraction": float((res["found"] != 0).mean())}
     reads.free()
+    del d_t, d_r
+
+    # row S: the hashing mate rescue, m = 150, W = 660 (mu + 7 sigma + 2k' of a 400 +- 30 library)
+    ns = na // 4
+    rc, fields = synth.softclip_workload(codes, ns, 150, 660, 81)
+    reads = ctx.upload_reads(*host(rc, 1), api.READS_ASCII, orientations=1)
+    t = np.zeros(ns, api.SOFTCLIP_TASK)
+    for k_, v in fields.items():
+        t[k_] = v
+    d_t = torch.from_numpy(t.view(np.uint8)).to(device)
+    d_r = torch.zeros(ns * api.SOFTCLIP_RESULT.itemsize, dtype=torch.uint8, device=device)
+    d_c = torch.zeros(ns * 384, dtype=torch.uint8, device=device)
+    ms = timed(lambda: ctx.softclip_match_dev(reads, d_t, ns, d_r, d_c, 384, 660))
+    res = d_r.cpu().numpy().view(api.SOFTCLIP_RESULT)
+    out["S_softclip_match"] = {"shape": "CSoftClipping::match + getExtCigar m=150 W=660", "tasks": ns, "kernel_ms": ms,
+                               "candidates_per_s": ns / ms * 1e3, "found_fraction": float((res["found"] == 1).mean()),
+                               "indel_fraction": float((res["del_size"] != 0).mean())}
+    reads.free()
     return out
 
 

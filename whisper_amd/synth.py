@@ -211,3 +211,34 @@ def indel_match_workload(genome, n, m, seed, max_indel=50, max_mm=12, stage_majo
                   fixed_segment_size=(fr - fl).cpu().numpy().astype(np.uint16),
                   max_no_mismatches=np.full(n, max_mm, np.uint8), flags=np.zeros(n, np.uint8))
     return out, fields
+
+
+def softclip_workload(genome, n, m, W, seed):
+    """Mate-rescue shape, vectorised: windows of W symbols holding, a third each,
+    a read whose first symbols are junk (-> clipping), a read with one long deletion (3..50), and
+    nothing related.  Returns the read codes [n, m] and the wamd_softclip_task fields."""
+    dev = genome.device
+    g = _gen(seed, dev)
+    G = genome.numel()
+    p = torch.randint(BOUNDARY_N_LEN + W + 200, G - BOUNDARY_N_LEN - 2 * W - 400, (n,), generator=g, device=dev)
+    kind = torch.arange(n, device=dev) % 3
+    L = torch.randint(3, 51, (n,), generator=g, device=dev)
+    x = torch.randint(25, m - 25, (n,), generator=g, device=dev)
+    c = torch.randint(1, 60, (n,), generator=g, device=dev)
+    ar = torch.arange(m, device=dev)
+    out = torch.empty((n, m), dtype=torch.uint8, device=dev)
+    chunk = 1 << 16
+    for b in range(0, n, chunk):
+        e = min(n, b + chunk)
+        k = kind[b:e]
+        shift = torch.where((k == 1)[:, None] & (ar[None, :] >= x[b:e, None]), L[b:e, None], torch.zeros_like(ar)[None, :])
+        r = genome[p[b:e, None] + ar[None, :] + shift]
+        rnd = torch.randint(0, 4, (e - b, m), generator=g, device=dev, dtype=torch.uint8)
+        junk = ((k == 0)[:, None] & (ar[None, :] < c[b:e, None])) | (k == 2)[:, None]
+        r = torch.where(junk, rnd, r)
+        out[b:e] = torch.where(r > 3, torch.full_like(r, 4), r)
+    start = p - torch.randint(0, W - m - 60, (n,), generator=g, device=dev)
+    fields = dict(read_idx=np.arange(n, dtype=np.uint32), ref_pos=start.cpu().numpy().astype(np.uint32),
+                  max_distance_in_ref=np.full(n, W, np.uint32), min_exact_len=np.full(n, 20, np.uint16),
+                  flags=np.zeros(n, np.uint8))
+    return out, fields
