@@ -20,7 +20,11 @@
 //           the true ones - and per column only a window of 2ed+3 rows around the
 //           end diagonal is kept, of VP, VN and D0 (24 B per column instead of
 //           40 B x words).  HP/HN at a cell follow from VP/VN of the column to the
-//           left.  The traceback records 2 bits per step; a forward replay writes
+//           left.  For bands of up to 64 rows (every practical case) the forward pass
+//           stores what the walk decides on instead: "diagonal with match", "diagonal
+//           with mismatch", "horizontal", "vertical" as four windows (16 B per column
+//           for bands of up to 32 rows), so the walk neither fetches symbols nor
+//           tracks the cell value.  The traceback records 2 bits per step; a forward replay writes
 //           the ext-CIGAR in its final order and spots the refinement pattern on
 //           the fly.  The affine score is summed during the backward walk in the
 //           reference's order (double adds only), so it is bit-identical.
@@ -69,14 +73,14 @@ struct NibStream {
 };
 
 // ---- pass 2a: sort accepted tasks into classes by band width ------------------------
-// class 0: 2ed+3 <= 64 rows, class 1: <= 128 rows, class 2: whole columns
+// class 0: 2ed+3 <= 32 rows, class 1: <= 64 rows, class 2: <= 128 rows, class 3: whole columns
 __global__ __launch_bounds__(256) void align_classify_kernel(
     ReadsView rv, const wamd_dist_task* __restrict__ tasks, const wamd_dist_result* __restrict__ dist,
     uint32_t n, wamd_align_result* __restrict__ results, uint8_t* __restrict__ cigars,
     uint32_t cigar_stride, uint32_t* __restrict__ lists, uint32_t* __restrict__ counters)
 {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t cls = 3;   // 3: not accepted, no traceback
+    uint32_t cls = 4;   // 4: not accepted, no traceback
     if (gid < n) {
         const wamd_dist_result d = dist[gid];
         wamd_align_result r;
@@ -98,12 +102,12 @@ __global__ __launch_bounds__(256) void align_classify_kernel(
             results[gid] = r;
         } else {
             const uint32_t rows = 2 * d.edit_distance + 3;
-            cls = rows <= 64 ? 0u : (rows <= 128 ? 1u : 2u);
+            cls = rows <= 32 ? 0u : (rows <= 64 ? 1u : (rows <= 128 ? 2u : 3u));
         }
     }
     // one atomic per wave and class, slots handed out by lane rank
 #pragma unroll
-    for (uint32_t c = 0; c < 3; ++c) {
+    for (uint32_t c = 0; c < 4; ++c) {
         const uint64_t mask = __ballot(cls == c);
         if (!mask)
             continue;
@@ -140,6 +144,20 @@ __device__ __forceinline__ void extract_window(const uint64_t (&V)[NW], uint32_t
     }
 }
 
+// 32 rows of V starting at row bit off
+template <int NW>
+__device__ __forceinline__ uint32_t extract32(const uint64_t (&V)[NW], uint32_t off)
+{
+    const uint32_t wq = off >> 6, sh = off & 63u;
+    uint64_t s0 = 0, s1 = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        s0 = (wq == (uint32_t)w) ? V[w] : s0;
+        s1 = (wq + 1 == (uint32_t)w) ? V[w] : s1;
+    }
+    return (uint32_t)(sh ? ((s0 >> sh) | (s1 << (64u - sh))) : s0);
+}
+
 struct AlignParams {
     const wamd_dist_task* tasks;
     const wamd_dist_result* dist;
@@ -162,23 +180,32 @@ struct AlignParams {
 template <int NW, int WW, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void align_traceback_kernel(GenomeView g, ReadsView rv, AlignParams ap)
 {
-    constexpr int WWE = WW >= NW ? NW : WW;   // words actually kept per vector and column
+    // WW = 0: 32-row windows kept as dwords; otherwise WW 64-bit words per window (at most NW)
+    constexpr bool HALF = WW == 0;
+    constexpr int WWE = HALF ? 1 : (WW >= NW ? NW : WW);   // words actually kept per vector and column
+    constexpr bool DECIDED = WWE == 1;   // the forward pass stores the walk's four decision bits per cell
+    constexpr int NVEC = DECIDED ? 4 : 3;
+    using WT = typename std::conditional<HALF, uint32_t, uint64_t>::type;
+    constexpr uint32_t WMASK = HALF ? 31u : 63u;
+    constexpr bool WINDOWED = HALF || WW < NW;   // windows slide with the column; else whole columns from row 0
     // One wave per block: its LDS holds the pattern-match vectors during the forward pass and,
     // once that is over, the read and the genome window the two walks fetch symbols from
     // (a fetch from HBM on every eighth step of every lane would stall the whole wave).
     static_assert(BLOCK == 64, "phases reuse the LDS without a barrier: one wave per block");
     constexpr int RD = 8 * NW + 1;                                               // read dwords
-    constexpr int GD = (WW == 1 && NW > 1 ? 64 * NW + 32 : (WW == 2 && NW > 2 ? 64 * NW + 64 : 128 * NW + 2)) / 8 + 4;
+    constexpr int GD = (WW <= 1 && NW > 1 ? 64 * NW + 32 : (WW == 2 && NW > 2 ? 64 * NW + 64 : 128 * NW + 2)) / 8 + 4;
     constexpr int CH = 8;                                      // columns per refill of the walk's LDS chunk
-    constexpr int CHB = WWE <= 2 ? (CH + 1) * 3 * WWE * 2 : 0;  // chunk dwords per lane
-    constexpr int LDS_DW = (10 * NW > RD + GD + CHB ? 10 * NW : RD + GD + CHB);
+    constexpr int CHB = WWE == 2 ? (CH + 1) * 3 * WWE * 2 : 0;  // chunk dwords per lane
+    constexpr int LDS_DW = (12 * NW > RD + GD + CHB ? 12 * NW : RD + GD + CHB);
     __shared__ uint64_t lds_all[LDS_DW * BLOCK / 2];
     uint64_t* pm_lds = lds_all;
 
     const uint32_t tid = threadIdx.x;
     const uint32_t count = *ap.count;
     uint64_t* mat = ap.slots + (uint64_t)blockIdx.x * ap.slot_words;
-    uint32_t* path = reinterpret_cast<uint32_t*>(mat + (uint64_t)ap.max_cols * 3 * WWE * BLOCK);
+    WT* matw = reinterpret_cast<WT*>(mat);   // decision windows: [col][4][lane]
+    uint32_t* path = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(mat) +
+                                                 (uint64_t)ap.max_cols * NVEC * WWE * sizeof(WT) * BLOCK);
     uint64_t* my_pm = pm_lds + tid;
     // decode = "ACGTNNXX" (LevMyers64.cpp:398), one byte per code
     auto decode = [](uint32_t c) -> uint32_t { return (uint32_t)(0x58584e4e54474341ull >> (8 * (c & 7u))) & 0xffu; };
@@ -222,8 +249,10 @@ __global__ __launch_bounds__(BLOCK) void align_traceback_kernel(GenomeView g, Re
                 for (int w = 0; w < NW; ++w)
                     my_pm[(c * NW + w) * BLOCK] = (valid && (uint32_t)w <= wn) ? src[c * rv.words + w] : 0;
 #pragma unroll
-            for (int w = 0; w < NW; ++w)
+            for (int w = 0; w < NW; ++w) {
                 my_pm[(4 * NW + w) * BLOCK] = 0;
+                my_pm[(5 * NW + w) * BLOCK] = 0;
+            }
             if (valid)
                 presence = rv.meta[(uint64_t)read_idx * rv.n_orient + slot] & 0xffffu;
         }
@@ -256,22 +285,29 @@ __global__ __launch_bounds__(BLOCK) void align_traceback_kernel(GenomeView g, Re
                     const uint32_t c = (syms >> (4 * u)) & 15u;
                     const uint32_t row = c < 4u ? c : 4u;
                     const bool act = ci < n_cols;
-                    const bool exotic = act && c >= 4u && ((presence >> c) & 1u);
+                    // the walk compares min(c, N_ref) with the read's walk code (>3 -> N_read for ASCII reads)
+                    const uint32_t cw = c > 5u ? 5u : c;
+                    const bool exotic = act && c >= 4u && (((presence >> c) | (presence >> cw)) & 1u);
                     if (exotic) {
                         for (uint32_t w = 0; w <= wn; ++w) {
                             uint64_t eq = 0;
                             const uint32_t lo = w * 64, hi = min(m, lo + 64);
+                            uint64_t weq = 0;
                             for (uint32_t i = lo; i < hi; ++i) {
                                 const uint32_t rcode = rev ? rc_code(packed_symbol(my_codes, m - 1 - i))
                                                            : packed_symbol(my_codes, i);
                                 eq |= (uint64_t)(rcode == c) << (i - lo);
+                                weq |= (uint64_t)(((ap.ascii && rcode > 3u) ? 4u : rcode) == cw) << (i - lo);
                             }
                             my_pm[(4 * NW + w) * BLOCK] = eq;
+                            my_pm[(5 * NW + w) * BLOCK] = weq;
                         }
                     }
                     const uint64_t* eqrow = my_pm + row * (NW * BLOCK);
+                    const uint64_t* weqrow = my_pm + (row < 4u ? row : 5u) * (NW * BLOCK);
                     uint64_t hn_in = 0, hp_in = 0;
                     uint64_t D0v[NW];
+                    uint64_t FDM[DECIDED ? NW : 1], FDX[DECIDED ? NW : 1], FH[DECIDED ? NW : 1];
 #pragma unroll
                     for (int w = 0; w < NW; ++w) {
                         uint64_t X = eqrow[w * BLOCK] | hn_in;
@@ -285,15 +321,44 @@ __global__ __launch_bounds__(BLOCK) void align_traceback_kernel(GenomeView g, Re
                         hn_in = HN >> 63;
                         hp_in = HP >> 63;
                         D0v[w] = D0;
+                        if constexpr (DECIDED) {
+                            // what getExtCigar tests at a cell (LevMyers64.cpp:419-442), as bits:
+                            // d_val + mismatch == c  <=>  D0 == match;  h_val + 1 == c  <=>  HP;  v_val + 1 == c  <=>  VP
+                            const uint64_t we = weqrow[w * BLOCK];
+                            FDM[w] = D0 & we;
+                            FDX[w] = ~(D0 | we);
+                            FH[w] = HP;
+                        }
                     }
                     if (exotic) {
-                        for (uint32_t w = 0; w <= wn; ++w)
+                        for (uint32_t w = 0; w <= wn; ++w) {
                             my_pm[(4 * NW + w) * BLOCK] = 0;
+                            my_pm[(5 * NW + w) * BLOCK] = 0;
+                        }
                     }
                     if (act) {
                         const uint32_t j = s_col + ci;
                         const int32_t o = (int32_t)m - 2 - (int32_t)ed - (int32_t)(end_pos - j);
-                        const uint32_t off = o > 0 ? (uint32_t)o : 0u;
+                        const uint32_t off = (WINDOWED && o > 0) ? (uint32_t)o : 0u;
+                        if constexpr (DECIDED) {
+                            WT* dw = matw + ((uint64_t)ci * 4) * BLOCK + tid;
+                            if constexpr (HALF) {
+                                dw[0 * BLOCK] = extract32<NW>(FDM, off);
+                                dw[1 * BLOCK] = extract32<NW>(FDX, off);
+                                dw[2 * BLOCK] = extract32<NW>(FH, off);
+                                dw[3 * BLOCK] = extract32<NW>(VP, off);
+                            } else {
+                                uint64_t w1[1];
+                                extract_window<NW, 1>(FDM, off, w1);
+                                dw[0 * BLOCK] = w1[0];
+                                extract_window<NW, 1>(FDX, off, w1);
+                                dw[1 * BLOCK] = w1[0];
+                                extract_window<NW, 1>(FH, off, w1);
+                                dw[2 * BLOCK] = w1[0];
+                                extract_window<NW, 1>(VP, off, w1);
+                                dw[3 * BLOCK] = w1[0];
+                            }
+                        } else {
                         uint64_t wv[WWE];
                         uint64_t* dst = mat + ((uint64_t)ci * 3 * WWE) * BLOCK + tid;
                         extract_window<NW, WWE>(VP, off, wv);
@@ -308,6 +373,7 @@ __global__ __launch_bounds__(BLOCK) void align_traceback_kernel(GenomeView g, Re
 #pragma unroll
                         for (int t = 0; t < WWE; ++t)
                             dst[(2 * WWE + t) * BLOCK] = wv[t];
+                        }
                     }
                 }
             }
@@ -319,7 +385,7 @@ __global__ __launch_bounds__(BLOCK) void align_traceback_kernel(GenomeView g, Re
         // classes keep CH + 1 columns per lane in LDS: when any lane of the wave runs out of
         // its chunk, every lane reloads the CH + 1 columns ending at its own position, all
         // requests in flight at once.  The widest class reads the words where they lie.
-        constexpr bool CACHED = WWE <= 2;
+        constexpr bool CACHED = WWE == 2;
         constexpr int CW = CACHED ? 3 * WWE : 1;
         auto window_off = [&](uint32_t j) -> uint32_t {
             if constexpr (WW < NW) {
@@ -430,6 +496,72 @@ __global__ __launch_bounds__(BLOCK) void align_traceback_kernel(GenomeView g, Re
         const double c_match = ap.sc.match, c_mism = ap.sc.mismatch, c_do = ap.sc.gap_del_open,
                      c_de = ap.sc.gap_del_extend, c_io = ap.sc.gap_ins_open, c_ie = ap.sc.gap_ins_extend;
 
+        if constexpr (DECIDED) {
+            // ---- bands of up to 64 rows: column-synchronous walk over decision bits ----------
+            // Super-step s serves column end_pos - s in every lane: any number of vertical
+            // moves, then the one diagonal or horizontal move that leaves the column.  Which
+            // column a lane is in is then a function of s alone, so the four window words of
+            // a column sit in registers with static indices (four columns per batch of loads,
+            // the next batch already in flight); no symbol is fetched and the cell value is
+            // not tracked - the forward pass has already turned them into the four tests.
+            const int32_t A = WINDOWED ? (int32_t)m - 2 - (int32_t)ed : 0;   // window_off(end_pos - s) = max(0, A - s)
+            const uint32_t last_s = end_pos - s_col;          // columns further left do not exist for the walk
+            auto load_col = [&](uint32_t sc_, WT (&dst)[4]) {
+                const bool inside = valid && sc_ <= last_s;
+                const WT* src = matw + ((uint64_t)(inside ? last_s - sc_ : 0u) * 4) * BLOCK + tid;
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    dst[v] = src[v * BLOCK];
+            };
+            auto step = [&](const WT (&cur)[4], uint32_t s_) {
+                const int32_t oc = A - (int32_t)s_;
+                const uint32_t off_c = oc > 0 ? (uint32_t)oc : 0u;
+                bool pending = read_pos && pos;
+                while (__any(pending)) {
+                    const uint32_t b = ((pending ? read_pos : 1u) - 1u - off_c) & WMASK;
+                    const bool fdm = (cur[0] >> b) & 1u, fdx = (cur[1] >> b) & 1u;
+                    const bool from_h = (cur[2] >> b) & 1u, from_v = (cur[3] >> b) & 1u;
+                    const bool from_d = fdm || fdx;
+                    // D > H > V, but a move that continues the previous direction wins (LevMyers64.cpp:431-442)
+                    const bool take_d = from_d && (prev_dir == DIR_D || (prev_dir == DIR_H && !from_h) ||
+                                                   (prev_dir == DIR_V && !from_v));
+                    const bool take_h = !take_d && from_h && (prev_dir == DIR_H || (prev_dir == DIR_D && !from_d) ||
+                                                              (prev_dir == DIR_V && !from_v));
+                    const int dir = take_d ? DIR_D : (take_h ? DIR_H : DIR_V);
+                    const double cost_d = fdx ? c_mism : c_match;
+                    const double cost_h = in_indel ? c_de : c_do;
+                    const double cost_v = in_indel ? c_ie : c_io;
+                    const double cost = take_d ? cost_d : (take_h ? cost_h : cost_v);
+                    if (pending) {
+                        score += cost;
+                        events += (!take_d && !in_indel) ? 1u : 0u;
+                        in_indel = !take_d;
+                        read_pos -= take_h ? 0u : 1u;
+                        pos -= (take_d || take_h) ? 1u : 0u;
+                        prev_dir = dir;
+                        push_step(dir);
+                        pending = dir == DIR_V && read_pos != 0;
+                    }
+                }
+            };
+            WT C[4][4], N[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                load_col(u, N[u]);
+            for (uint32_t k = 0; __any(read_pos && pos); ++k) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        C[u][v] = N[u][v];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    load_col(4 * k + 4 + u, N[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    step(C[u], 4 * k + u);
+            }
+        } else {
         refill(end_pos, valid);
         while (__any(read_pos && pos)) {
             const bool on = read_pos && pos;
@@ -482,6 +614,7 @@ __global__ __launch_bounds__(BLOCK) void align_traceback_kernel(GenomeView g, Re
                 prev_dir = dir;
                 push_step(dir);
             }
+        }
         }
         while (__any(read_pos)) {   // LevMyers64.cpp:498-513
             if (read_pos) {
@@ -614,7 +747,7 @@ struct AlignLayout {
     uint64_t slot_bytes_max;   // one block of the widest class
     uint32_t blocks;           // blocks of class 0 the slot region is sized for
     uint32_t block;            // threads per block
-    uint32_t cols[3], wwe[3], path_dwords;
+    uint32_t cols[4], col_bytes[4], path_dwords;   // per class: columns kept, bytes per column and lane
 };
 
 static AlignLayout align_layout(const wamd_reads* r, uint32_t n)
@@ -624,17 +757,20 @@ static AlignLayout align_layout(const wamd_reads* r, uint32_t n)
     const uint32_t m = r->max_len ? r->max_len : 1;
     L.block = 64;   // one wave per block, see align_traceback_kernel
     L.path_dwords = (2 * m + 15) / 16 + 1;
-    // class 0: ed <= 30, class 1: ed <= 62, class 2: ed <= m
-    L.cols[0] = m + 30 + 2;
-    L.cols[1] = m + 62 + 2;
-    L.cols[2] = 2 * m + 2;
-    L.wwe[0] = nw < 1 ? nw : 1;
-    L.wwe[1] = nw < 2 ? nw : 2;
-    L.wwe[2] = nw;
-    uint64_t per_block[3];
+    // class 0: ed <= 14 (32-row windows), 1: ed <= 30 (64 rows), 2: ed <= 62, 3: ed <= m; classes 0 and 1
+    // keep four decision windows per column, the others VP, VN and D0
+    L.cols[0] = m + 14 + 2;
+    L.cols[1] = m + 30 + 2;
+    L.cols[2] = m + 62 + 2;
+    L.cols[3] = 2 * m + 2;
+    L.col_bytes[0] = 4 * 4;
+    L.col_bytes[1] = 4 * 8;
+    L.col_bytes[2] = nw < 2 ? 4 * 8 : 3 * 2 * 8;   // a one-word class is a decision-window class in the kernel
+    L.col_bytes[3] = nw < 2 ? 4 * 8 : 3 * nw * 8;
+    uint64_t per_block[4];
     L.slot_bytes_max = 0;
-    for (int c = 0; c < 3; ++c) {
-        per_block[c] = ((uint64_t)L.cols[c] * 3 * L.wwe[c] * 8 + (uint64_t)L.path_dwords * 4) * L.block;
+    for (int c = 0; c < 4; ++c) {
+        per_block[c] = ((uint64_t)L.cols[c] * L.col_bytes[c] + (uint64_t)L.path_dwords * 4) * L.block;
         per_block[c] = up256(per_block[c]);
         L.slot_bytes_max = per_block[c] > L.slot_bytes_max ? per_block[c] : L.slot_bytes_max;
     }
@@ -648,7 +784,7 @@ static AlignLayout align_layout(const wamd_reads* r, uint32_t n)
         region = L.slot_bytes_max;
     L.dist_off = 0;
     L.lists_off = up256((uint64_t)n * sizeof(wamd_dist_result));
-    L.counters_off = L.lists_off + up256((uint64_t)3 * n * sizeof(uint32_t));
+    L.counters_off = L.lists_off + up256((uint64_t)4 * n * sizeof(uint32_t));
     L.slots_off = L.counters_off + 256;
     L.total = L.slots_off + region;
     return L;
@@ -669,8 +805,10 @@ static int launch_tb_class(int cls, const GenomeView& g, const ReadsView& rv, co
                            uint32_t blocks, hipStream_t s)
 {
     if (cls == 0)
-        return launch_tb<NW, 1, BLOCK>(g, rv, ap, blocks, s);
+        return launch_tb<NW, 0, BLOCK>(g, rv, ap, blocks, s);
     if (cls == 1)
+        return launch_tb<NW, 1, BLOCK>(g, rv, ap, blocks, s);
+    if (cls == 2)
         return launch_tb<NW, 2, BLOCK>(g, rv, ap, blocks, s);
     return launch_tb<NW, NW, BLOCK>(g, rv, ap, blocks, s);
 }
@@ -704,7 +842,7 @@ int launch_align(wamd_ctx* ctx, const wamd_reads* r, const wamd_dist_task* d_tas
                        n, d_results, d_cigars, cigar_stride, d_lists, d_counters);
     WAMD_HIP(hipGetLastError());
 
-    for (int cls = 0; cls < 3; ++cls) {
+    for (int cls = 0; cls < 4; ++cls) {
         AlignParams ap;
         ap.tasks = d_tasks;
         ap.dist = d_dist;
@@ -721,7 +859,7 @@ int launch_align(wamd_ctx* ctx, const wamd_reads* r, const wamd_dist_task* d_tas
         ap.refine = refine;
         ap.ascii = r->encoding == WAMD_READS_ASCII;
         const uint64_t per_block =
-            up256(((uint64_t)L.cols[cls] * 3 * L.wwe[cls] * 8 + (uint64_t)L.path_dwords * 4) * L.block);
+            up256(((uint64_t)L.cols[cls] * L.col_bytes[cls] + (uint64_t)L.path_dwords * 4) * L.block);
         ap.slot_words = per_block / 8;
         uint64_t blocks64 = region / per_block;
         const uint32_t need = (n + L.block - 1) / L.block;
