@@ -93,10 +93,10 @@ __global__ __launch_bounds__(256) void align_classify_kernel(
         r.cigar_len = 0;
         r.refined = 0;
         r.reserved = 0;
-        cigars[(uint64_t)gid * cigar_stride] = 0;
         const bool error = d.edit_distance == RESULT_ERROR;
         const bool ok = !error && d.edit_distance <= tasks[gid].max_ed;
         if (!ok) {
+            cigars[(uint64_t)gid * cigar_stride] = 0;   // accepted tasks get theirs from the traceback
             if (error)
                 r.end_pos = 0;
             results[gid] = r;
@@ -167,6 +167,7 @@ struct AlignParams {
     uint8_t* cigars;
     uint64_t* slots;          // per block: [col][vec][ww][tid] then path dwords [q][tid]
     uint64_t slot_words;      // 64-bit words per block
+    uint32_t* paths;          // split classes: [group of 64 tasks][16 steps][lane]
     uint32_t* flags;
     wamd_scoring sc;
     uint32_t cigar_stride;
@@ -177,7 +178,10 @@ struct AlignParams {
 };
 
 // ---- pass 2b: windowed recompute + traceback + forward emission --------------------
-template <int NW, int WW, int BLOCK>
+// PHASE 0: everything in one kernel.  The banded class is split in two so that each half only
+// pays for its own LDS: PHASE 1 = forward pass + walk (path and totals go to memory),
+// PHASE 2 = forward replay of the recorded path (ext-CIGAR, refinement).
+template <int NW, int WW, int BLOCK, int PHASE>
 __global__ __launch_bounds__(BLOCK) void align_traceback_kernel(GenomeView g, ReadsView rv, AlignParams ap)
 {
     // WW = 0: 32-row windows kept as dwords; otherwise WW 64-bit words per window (at most NW)
@@ -196,7 +200,12 @@ __global__ __launch_bounds__(BLOCK) void align_traceback_kernel(GenomeView g, Re
     constexpr int GD = (WW <= 1 && NW > 1 ? 64 * NW + 32 : (WW == 2 && NW > 2 ? 64 * NW + 64 : 128 * NW + 2)) / 8 + 4;
     constexpr int CH = 8;                                      // columns per refill of the walk's LDS chunk
     constexpr int CHB = WWE == 2 ? (CH + 1) * 3 * WWE * 2 : 0;  // chunk dwords per lane
-    constexpr int LDS_DW = (12 * NW > RD + GD + CHB ? 12 * NW : RD + GD + CHB);
+    // banded pass: dwords per shifted pattern row = bits 0 .. (columns + 63), one more for the funnel
+    constexpr int SD = (64 * NW + 16 + 64 + 31) / 32 + 1;
+    constexpr int LDS_A = HALF ? 4 * SD : 12 * NW;              // forward pass
+    constexpr int LDS_B = RD + GD + CHB;                        // staged symbols (+ the old walk's chunk)
+    constexpr int LDS_DW = PHASE == 1 ? LDS_A : (PHASE == 2 ? LDS_B : (LDS_A > LDS_B ? LDS_A : LDS_B));
+    static_assert(PHASE == 0 || HALF, "only the banded class is split");
     __shared__ uint64_t lds_all[LDS_DW * BLOCK / 2];
     uint64_t* pm_lds = lds_all;
 
@@ -204,8 +213,8 @@ __global__ __launch_bounds__(BLOCK) void align_traceback_kernel(GenomeView g, Re
     const uint32_t count = *ap.count;
     uint64_t* mat = ap.slots + (uint64_t)blockIdx.x * ap.slot_words;
     WT* matw = reinterpret_cast<WT*>(mat);   // decision windows: [col][4][lane]
-    uint32_t* path = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(mat) +
-                                                 (uint64_t)ap.max_cols * NVEC * WWE * sizeof(WT) * BLOCK);
+    uint32_t* const block_path = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(mat) +
+                                                             (uint64_t)ap.max_cols * NVEC * WWE * sizeof(WT) * BLOCK);
     uint64_t* my_pm = pm_lds + tid;
     // decode = "ACGTNNXX" (LevMyers64.cpp:398), one byte per code
     auto decode = [](uint32_t c) -> uint32_t { return (uint32_t)(0x58584e4e54474341ull >> (8 * (c & 7u))) & 0xffu; };
@@ -214,6 +223,8 @@ __global__ __launch_bounds__(BLOCK) void align_traceback_kernel(GenomeView g, Re
         const uint32_t li = base + tid;
         bool valid = li < count;
         const uint32_t gid = valid ? ap.list[li] : 0;
+        // recorded steps, [16 steps][lane]: in the block's slot, or per group of 64 tasks when split
+        uint32_t* const path = PHASE == 0 ? block_path : ap.paths + (uint64_t)(base / BLOCK) * ap.path_dwords * BLOCK;
 
         uint32_t m = 1, wn = 0, ed = 0, end_pos = 1, ref_pos = 0, read_idx = 0, presence = 0;
         bool rev = false;
@@ -239,6 +250,132 @@ __global__ __launch_bounds__(BLOCK) void align_traceback_kernel(GenomeView g, Re
             n_cols = 0;
         }
 
+        // ---- banded class: common pieces of the forward pass and of the walk's recomputation ----
+        const uint32_t F = (ap.max_cols + 7u) & ~7u;   // iterations of every lane
+        uint64_t VPb = 0, VNb = 0;
+        auto low_ones = [](int32_t nbits) -> uint64_t {   // ones in bits 0 .. nbits-1
+            return nbits <= 0 ? 0ull : (nbits >= 64 ? ~0ull : ((1ull << nbits) - 1ull));
+        };
+        // genome symbols under iterations fb .. fb + 7 (fb a multiple of 8)
+        auto band_syms = [&](uint32_t fb) -> uint32_t {
+            int64_t x = (int64_t)ref_pos + (int64_t)s_col - 1 - (int64_t)(F - n_cols) + (int64_t)fb;
+            x = x < 0 ? 0 : x;   // iterations before the lane's first column: any symbol will do
+            const uint32_t d0 = load_genome_dword(g, (uint32_t)(x >> 3)), d1 = load_genome_dword(g, (uint32_t)(x >> 3) + 1);
+            return __builtin_amdgcn_alignbit(d1, d0, 4u * ((uint32_t)x & 7u));
+        };
+        // one banded column: updates VPb / VNb, returns the four decision windows of the column
+        auto band_col = [&](uint32_t f, uint32_t c, uint32_t (&win)[4]) {
+            const uint32_t* S = reinterpret_cast<const uint32_t*>(lds_all) + tid;
+            const uint32_t delay = F - n_cols;
+            const bool act = valid && f >= delay;
+            const uint32_t kd = f >> 5, sh = f & 31u;
+            const uint32_t* sp = S + ((c & 3u) * SD + kd) * BLOCK;
+            const uint32_t a0 = sp[0], a1 = sp[BLOCK], a2 = sp[2 * BLOCK];
+            uint64_t eq = ((uint64_t)__builtin_amdgcn_alignbit(a2, a1, sh) << 32) | __builtin_amdgcn_alignbit(a1, a0, sh);
+            uint64_t we = eq;
+            if (__any(act && c >= 4u)) {   // N runs and other non-ACGT symbols
+                if (c >= 4u) {
+                    // read row of bit 0
+                    const int32_t r0 = (int32_t)f + (int32_t)s_col + (int32_t)m - 2 - (int32_t)ed - (int32_t)end_pos - 16 -
+                                       (int32_t)delay;
+                    eq = low_ones(-r0);
+                    we = 0;
+                    // the walk compares min(c, N_ref) with the read's walk code (> 3 -> N_read for ASCII reads)
+                    const uint32_t cw = c > 5u ? 5u : c;
+                    if (act && (((presence >> c) | (presence >> cw)) & 1u)) {
+                        const uint8_t* codes = rv.codes + rv.code_off[read_idx];
+                        for (int32_t t = 0; t < 64; ++t) {
+                            const int32_t r = r0 + t;
+                            if (r >= 0 && r < (int32_t)m) {
+                                const uint32_t rcode = rev ? rc_code(packed_symbol(codes, m - 1 - (uint32_t)r))
+                                                           : packed_symbol(codes, (uint32_t)r);
+                                eq |= (uint64_t)(rcode == c) << t;
+                                we |= (uint64_t)(((ap.ascii && rcode > 3u) ? 4u : rcode) == cw) << t;
+                            }
+                        }
+                    }
+                }
+            }
+            const uint64_t D0 = (((eq & VPb) + VPb) ^ VPb) | eq | VNb;
+            const uint64_t HP = VNb | ~(D0 | VPb);
+            const uint64_t HN = D0 & VPb;
+            const uint64_t D0s = D0 >> 1;
+            const uint64_t vp_new = HN | ~(D0s | HP);   // vertical deltas of this column, in the NEXT column's frame
+            const uint64_t vn_new = D0s & HP;
+            VPb = act ? vp_new : VPb;
+            VNb = act ? vn_new : VNb;
+            // what getExtCigar tests at a cell (LevMyers64.cpp:419-442), as bits:
+            // d_val + mismatch == c  <=>  D0 == match;  h_val + 1 == c  <=>  HP;  v_val + 1 == c  <=>  VP
+            win[0] = (uint32_t)((D0 & we) >> 16);
+            win[1] = (uint32_t)(~(D0 | we) >> 16);
+            win[2] = (uint32_t)(HP >> 16);
+            win[3] = (uint32_t)(vp_new >> 15);
+        };
+        const uint8_t* my_codes = rv.codes + rv.code_off[read_idx];
+        if constexpr (PHASE == 2) {
+            // the path and the totals are already in memory
+        } else if constexpr (HALF) {
+            // ---- banded forward pass (bands of up to 32 rows, ed <= 14) --------------------------
+            // Only a diagonal band of 64 rows is computed (Hyyro's band form of the recurrence:
+            // the frame moves down one row per column, so D0 shifts right instead of HP/HN
+            // shifting left).  Bit t of a column is read row  column + const + t; the 32 rows
+            // the walk may look at are bits 16..47.  A cell the walk tests as a predecessor has
+            // value <= ed and sits within ed + 1 diagonals of the end diagonal, so its optimal
+            // paths stay within 2ed + 1 diagonals: inside the band (16 rows of margin below the
+            // window, 61 - 2ed above), hence its banded value is the true one; every other value
+            // can only be too large, which fails the same tests.  Rows above the read's first
+            // symbol are phantom rows (match everything, VP = 0: the free start of the text).
+            //
+            // Nothing of the matrix is stored.  Every lane runs the same F iterations and its
+            // columns are the LAST n_cols of them, so "iteration f" is "column end_pos - (F-1-f)"
+            // in every lane; the state before every eighth iteration is kept (16 B), and the
+            // walk recomputes eight columns at a time from it into registers.  The pattern-match
+            // rows go to LDS pre-shifted per lane so that iteration f reads bits f .. f + 63 of
+            // them: dword index and funnel shift are wave-uniform.
+            static_assert(4 * SD <= LDS_DW, "LDS plan");
+            uint32_t* S = reinterpret_cast<uint32_t*>(lds_all) + tid;                 // [c][d][lane]
+            const uint32_t delay = F - n_cols;                                        // iterations before column s_col
+            // read row under bit 0 of iteration f is f + Zf
+            const int32_t Zf = (int32_t)s_col + (int32_t)m - 2 - (int32_t)ed - (int32_t)end_pos - 16 - (int32_t)delay;
+            {
+                const uint32_t slot = valid ? (uint32_t)(rev ? rv.slot_rc : rv.slot_direct) : 0;
+                const uint32_t* src = rv.pm32 + ((uint64_t)read_idx * rv.n_orient + slot) * 4 * rv.words32;
+                if (valid)
+                    presence = rv.meta[(uint64_t)read_idx * rv.n_orient + slot] & 0xffffu;
+                // pm32 is top-aligned: read row r is bit r + pad, the bits below are ones (phantom rows)
+                const int32_t zq = Zf + (int32_t)(32u * rv.words32 - m);   // bit of the pm32 row under x = 0
+                const int32_t k0 = zq >> 5;                                // floor
+                const uint32_t o = (uint32_t)zq & 31u;
+                auto pext = [&](int c, int32_t k) -> uint32_t {
+                    const int32_t kc = k < 0 ? 0 : (k >= (int32_t)rv.words32 ? (int32_t)rv.words32 - 1 : k);
+                    const uint32_t v = src[c * rv.words32 + kc];   // 80 B per read and strand: cached after the first touch
+                    return k < 0 ? ~0u : (k >= (int32_t)rv.words32 ? 0u : v);
+                };
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    uint32_t lo = pext(c, k0);
+#pragma unroll
+                    for (int d = 0; d < SD; ++d) {
+                        const uint32_t hi = pext(c, k0 + d + 1);
+                        S[(c * SD + d) * BLOCK] = valid ? __builtin_amdgcn_alignbit(hi, lo, o) : 0u;
+                        lo = hi;
+                    }
+                }
+            }
+            VPb = ~low_ones(-(Zf + (int32_t)delay));   // column s_col - 1: D = row, phantom rows flat
+            VNb = 0;
+            for (uint32_t fb = 0; fb < F; fb += 8) {
+                uint64_t* ck = mat + ((uint64_t)(fb / 8) * 2) * BLOCK + tid;
+                ck[0] = VPb;
+                ck[BLOCK] = VNb;
+                const uint32_t syms = band_syms(fb);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    uint32_t win[4];
+                    band_col(fb + u, (syms >> (4 * u)) & 15u, win);
+                }
+            }
+        } else {
         // ---- pattern-match vectors -> LDS (as in the distance kernel) ---------------
         {
             const uint32_t slot = valid ? (uint32_t)(rev ? rv.slot_rc : rv.slot_direct) : 0;
@@ -256,7 +393,6 @@ __global__ __launch_bounds__(BLOCK) void align_traceback_kernel(GenomeView g, Re
             if (valid)
                 presence = rv.meta[(uint64_t)read_idx * rv.n_orient + slot] & 0xffffu;
         }
-        const uint8_t* my_codes = rv.codes + rv.code_off[read_idx];
 
         // ---- forward recompute over columns s_col .. end_pos --------------------------
         // window of column j starts at row bit off(j) = max(0, m - 2 - ed - (end_pos - j))
@@ -379,6 +515,7 @@ __global__ __launch_bounds__(BLOCK) void align_traceback_kernel(GenomeView g, Re
             }
         }
 
+        }
         // ---- backward walk (getExtCigar, LevMyers64.cpp:413-513) ----------------------
         // The walk reads columns pos and pos - 1 and moves left one column at a time.  Fetching
         // their words from HBM as it goes leaves every step waiting for memory, so the narrow
@@ -455,7 +592,7 @@ __global__ __launch_bounds__(BLOCK) void align_traceback_kernel(GenomeView g, Re
         const int64_t g_origin = (g_first < 0 ? 0 : g_first) >> 3;
         int32_t gd_n = valid ? (int32_t)((((int64_t)ref_pos + end_pos - 1) >> 3) - g_origin + 1) : 1;
         gd_n = gd_n > GD ? GD : (gd_n < 1 ? 1 : gd_n);
-        {
+        if constexpr (PHASE != 1) {
             const uint32_t* src = reinterpret_cast<const uint32_t*>(my_codes);
 #pragma unroll 4
             for (int d = 0; d < RD; ++d)
@@ -496,7 +633,17 @@ __global__ __launch_bounds__(BLOCK) void align_traceback_kernel(GenomeView g, Re
         const double c_match = ap.sc.match, c_mism = ap.sc.mismatch, c_do = ap.sc.gap_del_open,
                      c_de = ap.sc.gap_del_extend, c_io = ap.sc.gap_ins_open, c_ie = ap.sc.gap_ins_extend;
 
-        if constexpr (DECIDED) {
+        if constexpr (PHASE == 2) {
+            // totals of the walk, left in the result record by the first half
+            if (valid) {
+                const wamd_align_result h = ap.results[gid];
+                score = h.affine_score;
+                events = h.num_events;
+                nsteps = h.cigar_len;
+                pos = h.begin_pos;
+            }
+            read_pos = 0;
+        } else if constexpr (DECIDED) {
             // ---- bands of up to 64 rows: column-synchronous walk over decision bits ----------
             // Super-step s serves column end_pos - s in every lane: any number of vertical
             // moves, then the one diagonal or horizontal move that leaves the column.  Which
@@ -504,7 +651,7 @@ __global__ __launch_bounds__(BLOCK) void align_traceback_kernel(GenomeView g, Re
             // a column sit in registers with static indices (four columns per batch of loads,
             // the next batch already in flight); no symbol is fetched and the cell value is
             // not tracked - the forward pass has already turned them into the four tests.
-            const int32_t A = WINDOWED ? (int32_t)m - 2 - (int32_t)ed : 0;   // window_off(end_pos - s) = max(0, A - s)
+            const int32_t A = WINDOWED ? (int32_t)m - 2 - (int32_t)ed : 0;   // window_off(end_pos - s) = max(0, A - s), A - s when banded
             const uint32_t last_s = end_pos - s_col;          // columns further left do not exist for the walk
             auto load_col = [&](uint32_t sc_, WT (&dst)[4]) {
                 const bool inside = valid && sc_ <= last_s;
@@ -515,7 +662,7 @@ __global__ __launch_bounds__(BLOCK) void align_traceback_kernel(GenomeView g, Re
             };
             auto step = [&](const WT (&cur)[4], uint32_t s_) {
                 const int32_t oc = A - (int32_t)s_;
-                const uint32_t off_c = oc > 0 ? (uint32_t)oc : 0u;
+                const uint32_t off_c = (HALF || oc > 0) ? (uint32_t)oc : 0u;   // banded windows keep sliding above row 0
                 bool pending = read_pos && pos;
                 while (__any(pending)) {
                     const uint32_t b = ((pending ? read_pos : 1u) - 1u - off_c) & WMASK;
@@ -544,6 +691,35 @@ __global__ __launch_bounds__(BLOCK) void align_traceback_kernel(GenomeView g, Re
                     }
                 }
             };
+            if constexpr (HALF) {
+                // eight columns at a time: reload the state kept before iteration F - 8(q+1), run the
+                // band forward into registers, then walk those columns right to left
+                const uint32_t n_chunks = F / 8;
+                auto ck_load = [&](uint32_t q, uint64_t& vp, uint64_t& vn) {
+                    const uint32_t idx = q < n_chunks ? n_chunks - 1 - q : 0u;
+                    const uint64_t* ck = mat + ((uint64_t)idx * 2) * BLOCK + tid;
+                    vp = ck[0];
+                    vn = ck[BLOCK];
+                };
+                uint64_t nvp, nvn;
+                ck_load(0, nvp, nvn);
+                uint32_t nsyms = band_syms(F - 8);
+                for (uint32_t q = 0; q < n_chunks && __any(read_pos && pos); ++q) {
+                    const uint32_t fb = F - 8 * (q + 1);
+                    VPb = nvp;
+                    VNb = nvn;
+                    const uint32_t syms = nsyms;
+                    ck_load(q + 1, nvp, nvn);
+                    nsyms = band_syms(fb >= 8 ? fb - 8 : 0u);
+                    uint32_t D[8][4];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        band_col(fb + u, (syms >> (4 * u)) & 15u, D[u]);
+#pragma unroll
+                    for (int u = 7; u >= 0; --u)
+                        step(D[u], F - 1 - (fb + u));
+                }
+            } else {
             WT C[4][4], N[4][4];
 #pragma unroll
             for (int u = 0; u < 4; ++u)
@@ -560,6 +736,7 @@ __global__ __launch_bounds__(BLOCK) void align_traceback_kernel(GenomeView g, Re
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
                     step(C[u], 4 * k + u);
+            }
             }
         } else {
         refill(end_pos, valid);
@@ -629,13 +806,29 @@ __global__ __launch_bounds__(BLOCK) void align_traceback_kernel(GenomeView g, Re
                 push_step(DIR_V);
             }
         }
-        if (nsteps & 15u)
+        if (PHASE != 2 && (nsteps & 15u))
             path[(uint64_t)(nsteps / 16) * BLOCK + tid] = pacc;
         const uint32_t begin_pos = pos;
+        if constexpr (PHASE == 1) {   // hand over to the replay kernel
+            if (li < count) {
+                wamd_align_result h{};
+                h.affine_score = score;
+                h.num_events = events;
+                h.cigar_len = nsteps;
+                h.begin_pos = begin_pos;
+                h.edit_distance = valid ? ed : RESULT_ERROR;
+                ap.results[gid] = h;
+            }
+            continue;
+        }
 
         // ---- forward replay: ext-CIGAR in final order + refinement -----------------------
         uint32_t cur = 0, acc = 0, refined = 0;
         uint8_t* slot = ap.cigars + (uint64_t)gid * ap.cigar_stride;
+        if constexpr (PHASE == 2) {
+            if (valid && ap.results[gid].edit_distance == RESULT_ERROR)
+                valid = false;
+        }
         if (valid && (2 * nsteps + 4 > ap.cigar_stride)) {
             raise_flag(ap.flags, FLAG_CIGAR);
             valid = false;
@@ -734,6 +927,7 @@ __global__ __launch_bounds__(BLOCK) void align_traceback_kernel(GenomeView g, Re
             wamd_align_result r{};
             r.edit_distance = RESULT_ERROR;
             ap.results[gid] = r;
+            slot[0] = 0;
         }
     }
 }
@@ -743,11 +937,12 @@ __global__ __launch_bounds__(BLOCK) void align_traceback_kernel(GenomeView g, Re
 static inline uint64_t up256(uint64_t x) { return (x + 255) / 256 * 256; }
 
 struct AlignLayout {
-    uint64_t dist_off, lists_off, counters_off, slots_off, total;
+    uint64_t dist_off, lists_off, counters_off, paths_off, slots_off, total;
     uint64_t slot_bytes_max;   // one block of the widest class
     uint32_t blocks;           // blocks of class 0 the slot region is sized for
     uint32_t block;            // threads per block
-    uint32_t cols[4], col_bytes[4], path_dwords;   // per class: columns kept, bytes per column and lane
+    uint32_t cols[4], path_dwords;   // per class: columns recomputed at most
+    uint64_t per_block[4];           // per class: bytes of one block's slot
 };
 
 static AlignLayout align_layout(const wamd_reads* r, uint32_t n)
@@ -757,20 +952,19 @@ static AlignLayout align_layout(const wamd_reads* r, uint32_t n)
     const uint32_t m = r->max_len ? r->max_len : 1;
     L.block = 64;   // one wave per block, see align_traceback_kernel
     L.path_dwords = (2 * m + 15) / 16 + 1;
-    // class 0: ed <= 14 (32-row windows), 1: ed <= 30 (64 rows), 2: ed <= 62, 3: ed <= m; classes 0 and 1
-    // keep four decision windows per column, the others VP, VN and D0
+    // class 0: ed <= 14 (banded: only the state before every eighth column is kept, 16 B), 1: ed <= 30
+    // (four 64-row decision windows per column), 2: ed <= 62 and 3: ed <= m (VP, VN and D0 windows)
     L.cols[0] = m + 14 + 2;
     L.cols[1] = m + 30 + 2;
     L.cols[2] = m + 62 + 2;
     L.cols[3] = 2 * m + 2;
-    L.col_bytes[0] = 4 * 4;
-    L.col_bytes[1] = 4 * 8;
-    L.col_bytes[2] = nw < 2 ? 4 * 8 : 3 * 2 * 8;   // a one-word class is a decision-window class in the kernel
-    L.col_bytes[3] = nw < 2 ? 4 * 8 : 3 * nw * 8;
-    uint64_t per_block[4];
+    const uint64_t col_bytes[4] = {0, 4 * 8, nw < 2 ? 4 * 8u : 3 * 2 * 8u, nw < 2 ? 4 * 8u : 3 * nw * 8u};
+    uint64_t* per_block = L.per_block;
     L.slot_bytes_max = 0;
     for (int c = 0; c < 4; ++c) {
-        per_block[c] = ((uint64_t)L.cols[c] * L.col_bytes[c] + (uint64_t)L.path_dwords * 4) * L.block;
+        per_block[c] = ((uint64_t)L.cols[c] * col_bytes[c] + (uint64_t)L.path_dwords * 4) * L.block;
+        if (c == 0)
+            per_block[c] = (uint64_t)((L.cols[0] + 7) / 8) * 16 * L.block;   // its paths live in their own region
         per_block[c] = up256(per_block[c]);
         L.slot_bytes_max = per_block[c] > L.slot_bytes_max ? per_block[c] : L.slot_bytes_max;
     }
@@ -779,13 +973,19 @@ static AlignLayout align_layout(const wamd_reads* r, uint32_t n)
     L.blocks = need_blocks < cap_blocks ? need_blocks : cap_blocks;
     if (L.blocks == 0)
         L.blocks = 1;
+    // the region serves the classes one after the other: all blocks of the banded class, and at
+    // least 2048 blocks (eight waves per CU) of the 64-row class when the batch has that many
     uint64_t region = (uint64_t)L.blocks * per_block[0];
+    const uint64_t wide = (uint64_t)(need_blocks < 2048u ? (need_blocks ? need_blocks : 1u) : 2048u) * per_block[1];
+    region = region < wide ? wide : region;
     if (region < L.slot_bytes_max)
         region = L.slot_bytes_max;
     L.dist_off = 0;
     L.lists_off = up256((uint64_t)n * sizeof(wamd_dist_result));
     L.counters_off = L.lists_off + up256((uint64_t)4 * n * sizeof(uint32_t));
-    L.slots_off = L.counters_off + 256;
+    // recorded paths of the split (banded) class, per group of 64 tasks
+    L.paths_off = L.counters_off + 256;
+    L.slots_off = L.paths_off + up256((uint64_t)need_blocks * L.path_dwords * 4 * L.block);
     L.total = L.slots_off + region;
     return L;
 }
@@ -793,24 +993,31 @@ static AlignLayout align_layout(const wamd_reads* r, uint32_t n)
 uint64_t align_workspace_bytes(const wamd_reads* r, uint32_t n) { return align_layout(r, n).total; }
 
 template <int NW, int WW, int BLOCK>
-static int launch_tb(const GenomeView& g, const ReadsView& rv, AlignParams ap, uint32_t blocks, hipStream_t s)
+static int launch_tb(const GenomeView& g, const ReadsView& rv, AlignParams ap, uint32_t blocks, uint32_t groups,
+                     hipStream_t s)
 {
-    hipLaunchKernelGGL((align_traceback_kernel<NW, WW, BLOCK>), dim3(blocks), dim3(BLOCK), 0, s, g, rv, ap);
+    if constexpr (WW == 0) {
+        hipLaunchKernelGGL((align_traceback_kernel<NW, WW, BLOCK, 1>), dim3(blocks), dim3(BLOCK), 0, s, g, rv, ap);
+        const uint32_t b2 = groups < 256u * 32u ? (groups ? groups : 1u) : 256u * 32u;
+        hipLaunchKernelGGL((align_traceback_kernel<NW, WW, BLOCK, 2>), dim3(b2), dim3(BLOCK), 0, s, g, rv, ap);
+    } else {
+        hipLaunchKernelGGL((align_traceback_kernel<NW, WW, BLOCK, 0>), dim3(blocks), dim3(BLOCK), 0, s, g, rv, ap);
+    }
     WAMD_HIP(hipGetLastError());
     return WAMD_OK;
 }
 
 template <int NW, int BLOCK>
 static int launch_tb_class(int cls, const GenomeView& g, const ReadsView& rv, const AlignParams& ap,
-                           uint32_t blocks, hipStream_t s)
+                           uint32_t blocks, uint32_t groups, hipStream_t s)
 {
     if (cls == 0)
-        return launch_tb<NW, 0, BLOCK>(g, rv, ap, blocks, s);
+        return launch_tb<NW, 0, BLOCK>(g, rv, ap, blocks, groups, s);
     if (cls == 1)
-        return launch_tb<NW, 1, BLOCK>(g, rv, ap, blocks, s);
+        return launch_tb<NW, 1, BLOCK>(g, rv, ap, blocks, groups, s);
     if (cls == 2)
-        return launch_tb<NW, 2, BLOCK>(g, rv, ap, blocks, s);
-    return launch_tb<NW, NW, BLOCK>(g, rv, ap, blocks, s);
+        return launch_tb<NW, 2, BLOCK>(g, rv, ap, blocks, groups, s);
+    return launch_tb<NW, NW, BLOCK>(g, rv, ap, blocks, groups, s);
 }
 
 int launch_align(wamd_ctx* ctx, const wamd_reads* r, const wamd_dist_task* d_tasks, uint32_t n,
@@ -851,6 +1058,7 @@ int launch_align(wamd_ctx* ctx, const wamd_reads* r, const wamd_dist_task* d_tas
         ap.results = d_results;
         ap.cigars = d_cigars;
         ap.slots = d_slots;
+        ap.paths = (uint32_t*)(ws + L.paths_off);
         ap.flags = ctx->d_flags;
         ap.sc = ctx->scoring;
         ap.cigar_stride = cigar_stride;
@@ -858,8 +1066,7 @@ int launch_align(wamd_ctx* ctx, const wamd_reads* r, const wamd_dist_task* d_tas
         ap.path_dwords = L.path_dwords;
         ap.refine = refine;
         ap.ascii = r->encoding == WAMD_READS_ASCII;
-        const uint64_t per_block =
-            up256(((uint64_t)L.cols[cls] * L.col_bytes[cls] + (uint64_t)L.path_dwords * 4) * L.block);
+        const uint64_t per_block = L.per_block[cls];
         ap.slot_words = per_block / 8;
         uint64_t blocks64 = region / per_block;
         const uint32_t need = (n + L.block - 1) / L.block;
@@ -867,15 +1074,15 @@ int launch_align(wamd_ctx* ctx, const wamd_reads* r, const wamd_dist_task* d_tas
         if (blocks == 0)
             blocks = 1;
         switch (rv.words) {
-        case 1: rc = launch_tb_class<1, 64>(cls, g, rv, ap, blocks, s); break;
-        case 2: rc = launch_tb_class<2, 64>(cls, g, rv, ap, blocks, s); break;
-        case 3: rc = launch_tb_class<3, 64>(cls, g, rv, ap, blocks, s); break;
-        case 4: rc = launch_tb_class<4, 64>(cls, g, rv, ap, blocks, s); break;
+        case 1: rc = launch_tb_class<1, 64>(cls, g, rv, ap, blocks, need, s); break;
+        case 2: rc = launch_tb_class<2, 64>(cls, g, rv, ap, blocks, need, s); break;
+        case 3: rc = launch_tb_class<3, 64>(cls, g, rv, ap, blocks, need, s); break;
+        case 4: rc = launch_tb_class<4, 64>(cls, g, rv, ap, blocks, need, s); break;
         default:
             if (rv.words <= 8)
-                rc = launch_tb_class<8, 64>(cls, g, rv, ap, blocks, s);
+                rc = launch_tb_class<8, 64>(cls, g, rv, ap, blocks, need, s);
             else if (rv.words <= 16)
-                rc = launch_tb_class<16, 64>(cls, g, rv, ap, blocks, s);
+                rc = launch_tb_class<16, 64>(cls, g, rv, ap, blocks, need, s);
             else
                 rc = WAMD_ERR_TOO_LONG;
         }
