@@ -21,6 +21,7 @@ constexpr int IM_SIDE = 7;          // min_side_size, indels.h:210
 constexpr int IM_SIDE_ERRORS = 1;   // max_no_side_errors
 constexpr uint32_t IM_MAX_READ = 256;   // longest read the LDS-staged variant takes
 constexpr uint32_t IM_MAX_INDEL = 80;   // largest max_indel_size it takes
+constexpr uint32_t IM_HITS = 12;        // seed hits per side and lane that wait for the lock-step pass
 
 struct IndelKernelParams {
     wamd_scoring sc;
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(64) void indel_match_kernel(const uint8_t* __restri
                                                          uint64_t genome_symbols, ReadsView rv, int ascii,
                                                          const wamd_indel_task* __restrict__ tasks, uint32_t n,
                                                          IndelKernelParams prm, uint32_t text_bytes,
-                                                         wamd_mapping* __restrict__ results,
+                                                         uint32_t hits_offset, wamd_mapping* __restrict__ results,
                                                          uint32_t* __restrict__ flags)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // (text_bytes + read bytes) x 64
@@ -189,6 +190,58 @@ __global__ __launch_bounds__(64) void indel_match_kernel(const uint8_t* __restri
     uint32_t best_no_left_mis_clipped = 0, best_no_right_mis_clipped = 0;
     const uint64_t sig_mask = ~0ull >> (4 * (16 - IM_SIDE));
 
+    // Seed hits are scored in lock step: every lane first lists where its 7-mer signature hits
+    // (cheap, same trip count for everybody), then round h scores the h-th hit of every lane
+    // together.  Scoring a hit where it is found would make the wave run the long split search
+    // once per hit of every lane.  Order per lane is kept (strict > on costs: the first best wins).
+    uint16_t* hit_list = reinterpret_cast<uint16_t*>(lds + hits_offset) + lane;   // [side * IM_HITS + h][lane]
+    uint32_t n_left_hits = 0, n_right_hits = 0;
+    auto score_left = [&](uint32_t i) {   // indels.cpp:205-230
+        const uint32_t g_left = i - IM_SIDE + 1;
+        uint32_t c_mis, indel_pos;
+        split_mismatches(s, query_len, g_left, max_indel + fpos + 1, 0, fpos + 1, true, c_mis, indel_pos);
+        if (c_mis > max_mis)
+            return;
+        const int c_indel = (int)max_indel - (int)g_left;
+        if ((c_indel < 0 ? -c_indel : c_indel) > (int)max_indel)
+            return;
+        double cost = (fpos - c_mis) * match_score + c_mis * mismatch_score;
+        if (c_indel > 0)
+            cost += gap_del_open + (c_indel - 1) * gap_del_extend;
+        else if (c_indel < 0)
+            cost += gap_ins_open + (-c_indel - 1) * gap_ins_extend;
+        if (cost > best_left_cost) {
+            best_left_cost = cost;
+            no_left_mis_indel = c_mis;
+            best_left_indel_pos = indel_pos;
+            left_indel_size = c_indel;
+            left_indel_found = c_indel != 0;
+        }
+    };
+    auto score_right = [&](uint32_t i) {   // indels.cpp:262-292
+        const uint32_t right_pos = i - IM_SIDE + 1;
+        uint32_t c_mis, indel_pos;
+        split_mismatches(s, query_len, fpos + fsize - 1 + max_indel, right_pos + IM_SIDE, fpos + fsize - 1, query_len,
+                         false, c_mis, indel_pos);
+        if (c_mis > max_mis)
+            return;
+        const int c_indel = ((int)right_pos + IM_SIDE) - ((int)text_size - (int)max_indel);
+        if ((c_indel < 0 ? -c_indel : c_indel) > (int)max_indel)
+            return;
+        double cost = (query_len - fpos - fsize - c_mis) * match_score + c_mis * mismatch_score;
+        if (c_indel > 0)
+            cost += gap_del_open + (c_indel - 1) * gap_del_extend;
+        else if (c_indel < 0)
+            cost += gap_ins_open + (-c_indel - 1) * gap_ins_extend;
+        if (cost > best_right_cost) {
+            best_right_cost = cost;
+            no_right_mis_indel = c_mis;
+            best_right_indel_pos = indel_pos;
+            right_indel_size = c_indel;
+            right_indel_found = c_indel != 0;
+        }
+    };
+
     // ---- left part: raw mismatches and best clipping point, 173-194
     uint32_t no_left_mis_raw = 0;
     double clipping_cost = clipping_score;
@@ -228,26 +281,13 @@ __global__ __launch_bounds__(64) void indel_match_kernel(const uint8_t* __restri
                 d = ((d << 4) + (1ull << c)) & sig_mask;
             if (__popcll(d & qsig) < IM_SIDE - IM_SIDE_ERRORS)
                 continue;
-            const uint32_t g_left = i - IM_SIDE + 1;
-            uint32_t c_mis, indel_pos;
-            split_mismatches(s, query_len, g_left, max_indel + fpos + 1, 0, fpos + 1, true, c_mis, indel_pos);
-            if (c_mis > max_mis)
-                continue;
-            const int c_indel = (int)max_indel - (int)g_left;
-            if ((c_indel < 0 ? -c_indel : c_indel) > (int)max_indel)
-                continue;
-            double cost = (fpos - c_mis) * match_score + c_mis * mismatch_score;
-            if (c_indel > 0)
-                cost += gap_del_open + (c_indel - 1) * gap_del_extend;
-            else if (c_indel < 0)
-                cost += gap_ins_open + (-c_indel - 1) * gap_ins_extend;
-            if (cost > best_left_cost) {
-                best_left_cost = cost;
-                no_left_mis_indel = c_mis;
-                best_left_indel_pos = indel_pos;
-                left_indel_size = c_indel;
-                left_indel_found = c_indel != 0;
+            // a seed hit: scored at once only when the list is full, else with everybody else's below
+            if (n_left_hits == IM_HITS) {   // list full (repeats): score what is listed, in order, and go on
+                for (uint32_t h = 0; h < IM_HITS; ++h)
+                    score_left(hit_list[h * 64]);
+                n_left_hits = 0;
             }
+            hit_list[(n_left_hits++) * 64] = (uint16_t)i;
         }
     }
 
@@ -288,29 +328,21 @@ __global__ __launch_bounds__(64) void indel_match_kernel(const uint8_t* __restri
                 d = ((d << 4) + (1ull << c)) & sig_mask;
             if (__popcll(d & qsig) < IM_SIDE - IM_SIDE_ERRORS)
                 continue;
-            const uint32_t right_pos = i - IM_SIDE + 1;
-            uint32_t c_mis, indel_pos;
-            split_mismatches(s, query_len, fpos + fsize - 1 + max_indel, right_pos + IM_SIDE, fpos + fsize - 1,
-                             query_len, false, c_mis, indel_pos);
-            if (c_mis > max_mis)
-                continue;
-            const int c_indel = ((int)right_pos + IM_SIDE) - ((int)text_size - (int)max_indel);
-            if ((c_indel < 0 ? -c_indel : c_indel) > (int)max_indel)
-                continue;
-            double cost = (query_len - fpos - fsize - c_mis) * match_score + c_mis * mismatch_score;
-            if (c_indel > 0)
-                cost += gap_del_open + (c_indel - 1) * gap_del_extend;
-            else if (c_indel < 0)
-                cost += gap_ins_open + (-c_indel - 1) * gap_ins_extend;
-            if (cost > best_right_cost) {
-                best_right_cost = cost;
-                no_right_mis_indel = c_mis;
-                best_right_indel_pos = indel_pos;
-                right_indel_size = c_indel;
-                right_indel_found = c_indel != 0;
+            if (n_right_hits == IM_HITS) {
+                for (uint32_t h = 0; h < IM_HITS; ++h)
+                    score_right(hit_list[(IM_HITS + h) * 64]);
+                n_right_hits = 0;
             }
+            hit_list[(IM_HITS + n_right_hits++) * 64] = (uint16_t)i;
         }
     }
+
+    for (uint32_t h = 0; __any(h < n_left_hits); ++h)
+        if (h < n_left_hits)
+            score_left(hit_list[h * 64]);
+    for (uint32_t h = 0; __any(h < n_right_hits); ++h)
+        if (h < n_right_hits)
+            score_right(hit_list[(IM_HITS + h) * 64]);
 
     auto rescale = [&](uint32_t size) { return size * max_mis / query_len; };   // indels.h:252-255
     const uint32_t left_pos =
@@ -442,16 +474,18 @@ int launch_indel_match(wamd_ctx* ctx, const wamd_reads* r, const wamd_indel_task
     const uint32_t blocks = (n + 63) / 64;
     const ReadsView rv = r->view();
     const int ascii = r->encoding == WAMD_READS_ASCII;
+    const uint32_t hit_bytes = 2 * IM_HITS * 2 * 64;   // seed-hit lists: two sides, uint16 per hit and lane
     // staged variant: reads up to 256 symbols with max_indel up to 80; tasks beyond that are
     // flagged by the kernel, so pick the unstaged one when the batch has longer reads
     if (r->max_len <= IM_MAX_READ) {
         const uint32_t text_bytes = (r->max_len + 2 * IM_MAX_INDEL + 3) / 2;
-        const uint32_t lds_bytes = (text_bytes + (r->max_len + 1) / 2) * 64;
-        hipLaunchKernelGGL(indel_match_kernel<true>, dim3(blocks), dim3(64), lds_bytes, s, ctx->d_genome,
-                           2 * ctx->genome_bytes, rv, ascii, d_tasks, n, kp, text_bytes, d_results, ctx->d_flags);
+        const uint32_t seq_bytes = ((text_bytes + (r->max_len + 1) / 2) * 64 + 15u) & ~15u;
+        hipLaunchKernelGGL(indel_match_kernel<true>, dim3(blocks), dim3(64), seq_bytes + hit_bytes, s, ctx->d_genome,
+                           2 * ctx->genome_bytes, rv, ascii, d_tasks, n, kp, text_bytes, seq_bytes, d_results,
+                           ctx->d_flags);
     } else {
-        hipLaunchKernelGGL(indel_match_kernel<false>, dim3(blocks), dim3(64), 0, s, ctx->d_genome,
-                           2 * ctx->genome_bytes, rv, ascii, d_tasks, n, kp, 0u, d_results, ctx->d_flags);
+        hipLaunchKernelGGL(indel_match_kernel<false>, dim3(blocks), dim3(64), hit_bytes, s, ctx->d_genome,
+                           2 * ctx->genome_bytes, rv, ascii, d_tasks, n, kp, 0u, 0u, d_results, ctx->d_flags);
     }
     WAMD_HIP(hipGetLastError());
     return WAMD_OK;
