@@ -7,10 +7,13 @@
 // at most one error), each scored by the best split of prefix / suffix mismatch counts,
 // and finally eight combinations tried in a fixed order with strict `>` on double costs.
 //
-// MI355X mapping: one wave per 64 candidates, both sequences of a lane unpacked once into
-// LDS, two symbols per byte ([byte][lane]: a wave reading the same index touches 16
-// dwords, no bank conflicts), everything else lane-private registers.  The split search
-// keeps running prefix / suffix counts instead of the reference's two arrays.  Costs are
+// MI355X mapping: one wave per 64 candidates, both sequences of a lane staged once in LDS
+// as dwords of eight 4-bit symbols ([dword][lane], conflict-free), everything else in
+// lane-private registers.  Comparisons run eight symbols at a time: two funnel-shifted
+// dwords, an xor, and one flag bit per differing nibble; the loops that have to visit every
+// position (running costs in the reference's order, best split) then only peel bits off
+// that mask.  The split search keeps running prefix / suffix counts instead of the
+// reference's two arrays.  Seed hits are listed and scored in lock step.  Costs are
 // evaluated with the reference's expressions in the reference's order (-ffp-contract=off),
 // so accepted mappings and their tie-breaks are identical.
 #include "wamd_internal.h"
@@ -33,30 +36,73 @@ __device__ __forceinline__ uint32_t rc_code_indel(uint32_t c) { return c < 4 ? 3
 
 template <bool STAGED>
 struct Seqs {
-    // STAGED: bytes in LDS; otherwise straight from packed global memory
-    const uint8_t* lds_g;
-    const uint8_t* lds_q;
+    // STAGED: nibble dwords in LDS ([dword][lane], symbol s of a dword at bits 4s);
+    // otherwise straight from packed global memory
+    const uint32_t* lds_g;
+    const uint32_t* lds_q;
     const uint8_t* genome;
     const uint8_t* codes;
     uint64_t g0;
     uint32_t m;
     bool rev;
-    // LDS image: two symbols per byte, first in the high nibble, [byte][lane]
     __device__ __forceinline__ uint32_t G(uint32_t i) const
     {
         if constexpr (STAGED)
-            return (lds_g[(i >> 1) * 64] >> ((i & 1u) ? 0 : 4)) & 15u;
+            return (lds_g[(i >> 3) * 64] >> (4 * (i & 7u))) & 15u;
         else
             return packed_symbol(genome, g0 + i);
     }
     __device__ __forceinline__ uint32_t Q(uint32_t i) const
     {
         if constexpr (STAGED)
-            return (lds_q[(i >> 1) * 64] >> ((i & 1u) ? 0 : 4)) & 15u;
+            return (lds_q[(i >> 3) * 64] >> (4 * (i & 7u))) & 15u;
         else
-            return rev ? rc_code_indel(packed_symbol(codes, m - 1 - i)) : packed_symbol(codes, i);
+            return i < m ? (rev ? rc_code_indel(packed_symbol(codes, m - 1 - i)) : packed_symbol(codes, i)) : 15u;
+    }
+    // symbols i .. i+7, symbol i in the low nibble (whatever lies past the sequence comes along:
+    // callers mask the positions they mean)
+    __device__ __forceinline__ uint32_t G8(uint32_t i) const
+    {
+        if constexpr (STAGED) {
+            return __builtin_amdgcn_alignbit(lds_g[((i >> 3) + 1) * 64], lds_g[(i >> 3) * 64], 4 * (i & 7u));
+        } else {
+            uint32_t w = 0;
+            for (uint32_t t = 0; t < 8; ++t)
+                w |= G(i + t) << (4 * t);
+            return w;
+        }
+    }
+    __device__ __forceinline__ uint32_t Q8(uint32_t i) const
+    {
+        if constexpr (STAGED) {
+            return __builtin_amdgcn_alignbit(lds_q[((i >> 3) + 1) * 64], lds_q[(i >> 3) * 64], 4 * (i & 7u));
+        } else {
+            uint32_t w = 0;
+            for (uint32_t t = 0; t < 8; ++t)
+                w |= Q(i + t) << (4 * t);
+            return w;
+        }
+    }
+    // symbols 8d .. 8d+7 of the genome window
+    __device__ __forceinline__ uint32_t Gw(uint32_t d) const
+    {
+        if constexpr (STAGED)
+            return lds_g[d * 64];
+        else
+            return G8(8 * d);
+    }
+    // bit 4t set when genome symbol gi + t differs from read symbol qi + t
+    __device__ __forceinline__ uint32_t mm8(uint32_t gi, uint32_t qi) const
+    {
+        const uint32_t x = G8(gi) ^ Q8(qi);
+        return (x | (x >> 1) | (x >> 2) | (x >> 3)) & 0x11111111u;
     }
 };
+
+__device__ __forceinline__ uint32_t low_flags(uint32_t n)   // flag bits of positions 0 .. n-1, n <= 8
+{
+    return n >= 8 ? 0x11111111u : (0x11111111u & ((1u << (4 * n)) - 1u));
+}
 
 // calc_mismatches_with_indel, indels.cpp:495-563, without the two arrays
 template <bool STAGED>
@@ -75,17 +121,24 @@ __device__ void split_mismatches(const Seqs<STAGED>& s, uint32_t query_len, uint
     const uint32_t end = stats - (left_margin ? 0 : IM_SIDE);
     const uint32_t g_r = g_left + text_size - stats, q_r = q_left + query_size - stats;
     uint32_t R = 0;
-    for (uint32_t t = 0; t < stats; ++t)
-        R += s.G(g_r + t) != s.Q(q_r + t);
+    for (uint32_t t = 0; t < stats; t += 8)
+        R += (uint32_t)__popc(s.mm8(g_r + t, q_r + t) & low_flags(stats - t));
     uint32_t L = 0;
     int best = (int)query_len + 1, best_pos = 0;
-    for (uint32_t i = 0; i < end; ++i) {
-        if (i >= start && (int)(L + R) < best) {
-            best = (int)(L + R);
-            best_pos = (int)i;
+    for (uint32_t ib = 0; ib < end; ib += 8) {
+        const uint32_t nl = s.mm8(g_left + ib, q_left + ib), nr = s.mm8(g_r + ib, q_r + ib);
+#pragma unroll
+        for (uint32_t t = 0; t < 8; ++t) {
+            const uint32_t i = ib + t;
+            if (i < end) {
+                if (i >= start && (int)(L + R) < best) {
+                    best = (int)(L + R);
+                    best_pos = (int)i;
+                }
+                L += (nl >> (4 * t)) & 1u;
+                R -= (nr >> (4 * t)) & 1u;
+            }
         }
-        L += s.G(g_left + i) != s.Q(q_left + i);
-        R -= s.G(g_r + i) != s.Q(q_r + i);
     }
     no_mis = (uint32_t)best;
     indel_pos = q_left + (uint32_t)best_pos;
@@ -95,11 +148,11 @@ template <bool STAGED>
 __global__ __launch_bounds__(64) void indel_match_kernel(const uint8_t* __restrict__ genome,
                                                          uint64_t genome_symbols, ReadsView rv, int ascii,
                                                          const wamd_indel_task* __restrict__ tasks, uint32_t n,
-                                                         IndelKernelParams prm, uint32_t text_bytes,
+                                                         IndelKernelParams prm, uint32_t text_dw,
                                                          uint32_t hits_offset, wamd_mapping* __restrict__ results,
                                                          uint32_t* __restrict__ flags)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // (text_bytes + read bytes) x 64
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // (text_dw + read dwords) x 64 dwords, then the hit lists
     const uint32_t lane = threadIdx.x;
     const uint32_t gid = blockIdx.x * 64 + lane;
     if (gid >= n)
@@ -126,9 +179,9 @@ __global__ __launch_bounds__(64) void indel_match_kernel(const uint8_t* __restri
     const uint32_t max_mis = t.max_no_mismatches, ref_pos = t.ref_pos;
     const uint32_t text_size = query_len + 2 * max_indel;
     if (!err && (fpos + fsize > query_len ||
-                 (STAGED && (query_len > IM_MAX_READ || max_indel > IM_MAX_INDEL || (text_size + 3) / 2 > text_bytes))))
+                 (STAGED && (query_len > IM_MAX_READ || max_indel > IM_MAX_INDEL || (text_size + 2 + 7) / 8 + 1 > text_dw))))
         err = FLAG_ARG;
-    if (!err && (ref_pos < max_indel || (uint64_t)ref_pos - max_indel + text_size + 3 > genome_symbols))
+    if (!err && (ref_pos < max_indel || (uint64_t)ref_pos - max_indel + text_size + 11 > genome_symbols))
         err = FLAG_RANGE;
     if (err) {
         raise_flag(flags, err);
@@ -143,19 +196,46 @@ __global__ __launch_bounds__(64) void indel_match_kernel(const uint8_t* __restri
     s.g0 = (uint64_t)ref_pos - max_indel;   // prefetch_genome(ref_pos - max_indel_size, text_size)
     s.m = query_len;
     s.rev = t.flags & WAMD_TASK_FLAG_REV_COMP;
-    s.lds_g = lds + lane;
-    s.lds_q = lds + (STAGED ? text_bytes * 64 : 0) + lane;
+    s.lds_g = reinterpret_cast<const uint32_t*>(lds) + lane;
+    s.lds_q = reinterpret_cast<const uint32_t*>(lds) + (STAGED ? text_dw * 64 : 0) + lane;
     if constexpr (STAGED) {
-        uint8_t* lg = lds + lane;
-        uint8_t* lq = lds + text_bytes * 64 + lane;
-        for (uint32_t i = 0; i < text_size + 2; i += 2)
-            lg[(i >> 1) * 64] = (uint8_t)((packed_symbol(genome, s.g0 + i) << 4) | packed_symbol(genome, s.g0 + i + 1));
-        for (uint32_t i = 0; i < query_len; i += 2) {
-            const uint32_t a = s.rev ? rc_code_indel(packed_symbol(s.codes, query_len - 1 - i)) : packed_symbol(s.codes, i);
-            const uint32_t b = i + 1 < query_len
-                                   ? (s.rev ? rc_code_indel(packed_symbol(s.codes, query_len - 2 - i)) : packed_symbol(s.codes, i + 1))
-                                   : 15u;
-            lq[(i >> 1) * 64] = (uint8_t)((a << 4) | b);
+        uint32_t* lg = reinterpret_cast<uint32_t*>(lds) + lane;
+        uint32_t* lq = lg + text_dw * 64;
+        // genome window: dword d = symbols g0 + 8d .. g0 + 8d + 7, funnel-shifted out of the packed genome
+        const uint32_t* gd = reinterpret_cast<const uint32_t*>(genome);
+        const uint32_t n_gd = (text_size + 2 + 7) / 8 + 1;
+        const uint32_t gk = (uint32_t)(s.g0 >> 3), gsh = 4u * ((uint32_t)s.g0 & 7u);
+        const uint32_t last_gd = (uint32_t)((genome_symbols - 1) >> 3);
+        uint32_t lo = nibble_swap(gd[gk]);
+        for (uint32_t d = 0; d < n_gd; ++d) {
+            const uint32_t k = gk + d + 1;
+            const uint32_t hi = nibble_swap(gd[k < last_gd ? k : last_gd]);
+            lg[d * 64] = __builtin_amdgcn_alignbit(hi, lo, gsh);
+            lo = hi;
+        }
+        // oriented read; nibbles past its end are 15
+        const uint32_t* cd = reinterpret_cast<const uint32_t*>(s.codes);
+        const uint32_t n_qd = (query_len + 7) / 8;
+        for (uint32_t d = 0; d <= n_qd; ++d) {
+            uint32_t w = 0xffffffffu;
+            if (d < n_qd) {
+                if (!s.rev) {
+                    w = nibble_swap(cd[d]);
+                } else {   // oriented symbol p = rc(stored symbol m - 1 - p)
+                    w = 0;
+                    for (uint32_t z = 0; z < 8; ++z) {
+                        const uint32_t pp = 8 * d + z;
+                        if (pp < query_len) {
+                            const uint32_t st = query_len - 1 - pp;
+                            w |= rc_code_indel((nibble_swap(cd[st >> 3]) >> (4 * (st & 7u))) & 15u) << (4 * z);
+                        }
+                    }
+                }
+                const uint32_t left = query_len - 8 * d;   // symbols of the read in this dword
+                if (left < 8)
+                    w |= 0xffffffffu << (4 * left);
+            }
+            lq[d * 64] = w;
         }
     }
     (void)ascii;   // ASCII reads were canonicalised with raw_code at upload (indels.cpp:977-991)
@@ -167,8 +247,8 @@ __global__ __launch_bounds__(64) void indel_match_kernel(const uint8_t* __restri
 
     // anchor, indels.cpp:167-169
     bool anchor_ok = true;
-    for (uint32_t i = 0; i < fsize; ++i)
-        if (s.Q(fpos + i) != s.G(max_indel + fpos + i)) {
+    for (uint32_t i = 0; i < fsize; i += 8)
+        if (s.mm8(max_indel + fpos + i, fpos + i) & low_flags(fsize - i)) {
             anchor_ok = false;
             break;
         }
@@ -188,7 +268,7 @@ __global__ __launch_bounds__(64) void indel_match_kernel(const uint8_t* __restri
     uint32_t best_no_left_clipped = 0, best_no_right_clipped = 0;
     uint32_t no_left_mis_clipped = 0, no_right_mis_clipped = 0;
     uint32_t best_no_left_mis_clipped = 0, best_no_right_mis_clipped = 0;
-    const uint64_t sig_mask = ~0ull >> (4 * (16 - IM_SIDE));
+    const uint32_t sig_mask = ~0u >> (4 * (8 - IM_SIDE));
 
     // Seed hits are scored in lock step: every lane first lists where its 7-mer signature hits
     // (cheap, same trip count for everybody), then round h scores the h-th hit of every lane
@@ -245,95 +325,139 @@ __global__ __launch_bounds__(64) void indel_match_kernel(const uint8_t* __restri
     // ---- left part: raw mismatches and best clipping point, 173-194
     uint32_t no_left_mis_raw = 0;
     double clipping_cost = clipping_score;
-    for (int i = (int)fpos - 1; i >= 0; --i) {
-        if (s.Q(i) != s.G(max_indel + i)) {
-            ++no_left_mis_raw;
-            ++no_left_mis_clipped;
-            clipping_cost += mismatch_score;
-        } else {
-            clipping_cost += match_score;
-            if (clipping_cost > best_left_clip_cost) {
-                best_left_clip_cost = clipping_cost;
-                best_no_left_clipped = (uint32_t)i;
-                best_no_left_mis_clipped = no_left_mis_clipped;
+    for (int base = ((int)fpos - 1) & ~7; base >= 0 && fpos > 0; base -= 8) {
+        const uint32_t nz = s.mm8(max_indel + (uint32_t)base, (uint32_t)base);
+#pragma unroll
+        for (int tt = 7; tt >= 0; --tt) {
+            const int i = base + tt;
+            if (i >= (int)fpos)
+                continue;
+            if ((nz >> (4 * tt)) & 1u) {
+                ++no_left_mis_raw;
+                ++no_left_mis_clipped;
+                clipping_cost += mismatch_score;
+            } else {
+                clipping_cost += match_score;
+                if (clipping_cost > best_left_clip_cost) {
+                    best_left_clip_cost = clipping_cost;
+                    best_no_left_clipped = (uint32_t)i;
+                    best_no_left_mis_clipped = no_left_mis_clipped;
+                }
             }
         }
     }
     if (fpos > (uint32_t)IM_SIDE) {   // 198-231
         // CBitCharsSingleWord (indels.h:162-206): newest symbol in the lowest 4-bit cell;
         // a symbol >= 4 is not inserted at all (the window does not advance)
-        uint64_t qsig = 0;
-        for (int i = 0; i < IM_SIDE; ++i) {
-            const uint32_t c = s.Q(i);
-            if (c < 4)
-                qsig += 1ull << (c + 4 * (IM_SIDE - i - 1));
+        uint32_t qsig = 0;   // seven one-hot cells of 4 bits: 28 bits
+        {
+            const uint32_t w = s.Q8(0);
+#pragma unroll
+            for (int i = 0; i < IM_SIDE; ++i) {
+                const uint32_t c = (w >> (4 * i)) & 15u;
+                if (c < 4)
+                    qsig += 1u << (c + 4 * (IM_SIDE - i - 1));
+            }
         }
-        uint64_t d = 0;
-        for (int i = 0; i < IM_SIDE - 1; ++i) {
-            const uint32_t c = s.G(i);
-            if (c < 4)
-                d += 1ull << (c + 4 * (IM_SIDE - i - 2));
+        uint32_t d = 0;
+        {
+            const uint32_t w = s.Gw(0);
+#pragma unroll
+            for (int i = 0; i < IM_SIDE - 1; ++i) {
+                const uint32_t c = (w >> (4 * i)) & 15u;
+                if (c < 4)
+                    d += 1u << (c + 4 * (IM_SIDE - i - 2));
+            }
         }
         const uint32_t end = max_indel + fpos;
-        for (uint32_t i = IM_SIDE - 1; i < end; ++i) {
-            const uint32_t c = s.G(i);
-            if (c < 4)
-                d = ((d << 4) + (1ull << c)) & sig_mask;
-            if (__popcll(d & qsig) < IM_SIDE - IM_SIDE_ERRORS)
-                continue;
-            // a seed hit: scored at once only when the list is full, else with everybody else's below
-            if (n_left_hits == IM_HITS) {   // list full (repeats): score what is listed, in order, and go on
-                for (uint32_t h = 0; h < IM_HITS; ++h)
-                    score_left(hit_list[h * 64]);
-                n_left_hits = 0;
+        for (uint32_t base = 0; base < end; base += 8) {
+            const uint32_t w = s.Gw(base >> 3);
+#pragma unroll
+            for (uint32_t tt = 0; tt < 8; ++tt) {
+                const uint32_t i = base + tt;
+                if (i < (uint32_t)IM_SIDE - 1 || i >= end)
+                    continue;
+                const uint32_t c = (w >> (4 * tt)) & 15u;
+                if (c < 4)
+                    d = ((d << 4) + (1u << c)) & sig_mask;
+                if (__popc(d & qsig) < IM_SIDE - IM_SIDE_ERRORS)
+                    continue;
+                // a seed hit: listed, and scored below together with everybody else's
+                if (n_left_hits == IM_HITS) {   // list full (repeats): score what is listed, in order, and go on
+                    for (uint32_t h = 0; h < IM_HITS; ++h)
+                        score_left(hit_list[h * 64]);
+                    n_left_hits = 0;
+                }
+                hit_list[(n_left_hits++) * 64] = (uint16_t)i;
             }
-            hit_list[(n_left_hits++) * 64] = (uint16_t)i;
         }
     }
 
     // ---- right part, 235-293
     uint32_t no_right_mis_raw = 0;
     clipping_cost = clipping_score;
-    for (uint32_t i = fpos + fsize; i < query_len; ++i) {
-        if (s.Q(i) != s.G(max_indel + i)) {
-            ++no_right_mis_raw;
-            ++no_right_mis_clipped;
-            clipping_cost += mismatch_score;
-        } else {
-            clipping_cost += match_score;
-            if (clipping_cost > best_right_clip_cost) {
-                best_right_clip_cost = clipping_cost;
-                best_no_right_mis_clipped = no_right_mis_clipped;
-                best_no_right_clipped = query_len - i - 1;
+    for (uint32_t base = (fpos + fsize) & ~7u; base < query_len; base += 8) {
+        const uint32_t nz = s.mm8(max_indel + base, base);
+#pragma unroll
+        for (uint32_t tt = 0; tt < 8; ++tt) {
+            const uint32_t i = base + tt;
+            if (i < fpos + fsize || i >= query_len)
+                continue;
+            if ((nz >> (4 * tt)) & 1u) {
+                ++no_right_mis_raw;
+                ++no_right_mis_clipped;
+                clipping_cost += mismatch_score;
+            } else {
+                clipping_cost += match_score;
+                if (clipping_cost > best_right_clip_cost) {
+                    best_right_clip_cost = clipping_cost;
+                    best_no_right_mis_clipped = no_right_mis_clipped;
+                    best_no_right_clipped = query_len - i - 1;
+                }
             }
         }
     }
     if (fpos + fsize + IM_SIDE < query_len) {
-        uint64_t qsig = 0;
-        for (int i = 0; i < IM_SIDE; ++i) {
-            const uint32_t c = s.Q(query_len - IM_SIDE + i);
-            if (c < 4)
-                qsig += 1ull << (c + 4 * (IM_SIDE - i - 1));
+        uint32_t qsig = 0;
+        {
+            const uint32_t w = s.Q8(query_len - IM_SIDE);
+#pragma unroll
+            for (int i = 0; i < IM_SIDE; ++i) {
+                const uint32_t c = (w >> (4 * i)) & 15u;
+                if (c < 4)
+                    qsig += 1u << (c + 4 * (IM_SIDE - i - 1));
+            }
         }
         const uint32_t begin = max_indel + fpos + fsize;
-        uint64_t d = 0;
-        for (int i = 0; i < IM_SIDE - 1; ++i) {
-            const uint32_t c = s.G(begin + i);
-            if (c < 4)
-                d += 1ull << (c + 4 * (IM_SIDE - i - 2));
-        }
-        for (uint32_t i = begin + IM_SIDE - 1; i < text_size; ++i) {
-            const uint32_t c = s.G(i);
-            if (c < 4)
-                d = ((d << 4) + (1ull << c)) & sig_mask;
-            if (__popcll(d & qsig) < IM_SIDE - IM_SIDE_ERRORS)
-                continue;
-            if (n_right_hits == IM_HITS) {
-                for (uint32_t h = 0; h < IM_HITS; ++h)
-                    score_right(hit_list[(IM_HITS + h) * 64]);
-                n_right_hits = 0;
+        uint32_t d = 0;
+        {
+            const uint32_t w = s.G8(begin);
+#pragma unroll
+            for (int i = 0; i < IM_SIDE - 1; ++i) {
+                const uint32_t c = (w >> (4 * i)) & 15u;
+                if (c < 4)
+                    d += 1u << (c + 4 * (IM_SIDE - i - 2));
             }
-            hit_list[(IM_HITS + n_right_hits++) * 64] = (uint16_t)i;
+        }
+        for (uint32_t base = (begin + IM_SIDE - 1) & ~7u; base < text_size; base += 8) {
+            const uint32_t w = s.Gw(base >> 3);
+#pragma unroll
+            for (uint32_t tt = 0; tt < 8; ++tt) {
+                const uint32_t i = base + tt;
+                if (i < begin + IM_SIDE - 1 || i >= text_size)
+                    continue;
+                const uint32_t c = (w >> (4 * tt)) & 15u;
+                if (c < 4)
+                    d = ((d << 4) + (1u << c)) & sig_mask;
+                if (__popc(d & qsig) < IM_SIDE - IM_SIDE_ERRORS)
+                    continue;
+                if (n_right_hits == IM_HITS) {
+                    for (uint32_t h = 0; h < IM_HITS; ++h)
+                        score_right(hit_list[(IM_HITS + h) * 64]);
+                    n_right_hits = 0;
+                }
+                hit_list[(IM_HITS + n_right_hits++) * 64] = (uint16_t)i;
+            }
         }
     }
 
@@ -478,10 +602,10 @@ int launch_indel_match(wamd_ctx* ctx, const wamd_reads* r, const wamd_indel_task
     // staged variant: reads up to 256 symbols with max_indel up to 80; tasks beyond that are
     // flagged by the kernel, so pick the unstaged one when the batch has longer reads
     if (r->max_len <= IM_MAX_READ) {
-        const uint32_t text_bytes = (r->max_len + 2 * IM_MAX_INDEL + 3) / 2;
-        const uint32_t seq_bytes = ((text_bytes + (r->max_len + 1) / 2) * 64 + 15u) & ~15u;
+        const uint32_t text_dw = (r->max_len + 2 * IM_MAX_INDEL + 2 + 7) / 8 + 1;
+        const uint32_t seq_bytes = (text_dw + (r->max_len + 7) / 8 + 1) * 4 * 64;
         hipLaunchKernelGGL(indel_match_kernel<true>, dim3(blocks), dim3(64), seq_bytes + hit_bytes, s, ctx->d_genome,
-                           2 * ctx->genome_bytes, rv, ascii, d_tasks, n, kp, text_bytes, seq_bytes, d_results,
+                           2 * ctx->genome_bytes, rv, ascii, d_tasks, n, kp, text_dw, seq_bytes, d_results,
                            ctx->d_flags);
     } else {
         hipLaunchKernelGGL(indel_match_kernel<false>, dim3(blocks), dim3(64), hit_bytes, s, ctx->d_genome,
