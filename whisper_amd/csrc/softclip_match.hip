@@ -32,10 +32,13 @@ namespace {
 constexpr uint32_t HASH_LEN = 20;          // HashTable::hash_len, soft_clipping.cpp:25
 constexpr uint32_t EMPTY16 = 0xffffu;      // EMPTY_CELL / empty_pos_in_query in 16 bits
 
+// CELL: a table cell holds a read position; bytes do when every read of the batch is short enough
+// (positions <= 254), which halves the kernel's LDS and nearly doubles the waves per CU
+template <typename CELL>
 struct SoftclipLds {
     uint32_t* text;        // window, nibble-swapped dwords: symbol s of a dword at bits 4s
     uint32_t* query;       // oriented read codes, same packing
-    uint16_t* table;       // HashTable::data
+    CELL* table;           // HashTable::data
     uint16_t* cell;        // per read position: hashed cell, later the cell it was stored in (data_log)
     uint16_t* checked_left;
     uint32_t* checked_right;   // bit per text position: checked_pos_right[p] == query_len
@@ -82,6 +85,7 @@ __device__ __forceinline__ uint32_t wave_min(uint32_t v)
 
 }   // namespace
 
+template <typename CELL>
 __global__ __launch_bounds__(64) void softclip_match_kernel(GenomeView g, ReadsView rv,
                                                             const wamd_softclip_task* __restrict__ tasks, uint32_t n,
                                                             wamd_softclip_params prm, wamd_scoring sc,
@@ -95,16 +99,17 @@ __global__ __launch_bounds__(64) void softclip_match_kernel(GenomeView g, ReadsV
     const uint32_t lane = threadIdx.x;
     const uint32_t text_dw = (max_window + max_len + 16 + 7) / 8 + 2;
     const uint32_t query_dw = (max_len + 7) / 8 + 2;
-    SoftclipLds L;
+    constexpr uint32_t EMPTY = (uint32_t)(CELL)~(CELL)0;   // EMPTY_CELL in a cell
+    SoftclipLds<CELL> L;
     L.text = lds_raw;
     L.query = L.text + text_dw;
     L.checked_right = L.query + query_dw;
-    L.table = reinterpret_cast<uint16_t*>(L.checked_right + (max_window + 32) / 32);
-    L.cell = L.table + ht_size;
+    L.table = reinterpret_cast<CELL*>(L.checked_right + (max_window + 32) / 32);
+    L.cell = reinterpret_cast<uint16_t*>(L.table + ht_size);
     L.checked_left = L.cell + ((max_len + 1) & ~1u);
     const uint32_t ht_mask = ht_size - 1;
 
-    for (uint32_t i = lane; i < ht_size / 2; i += 64)
+    for (uint32_t i = lane; i < ht_size * sizeof(CELL) / 4; i += 64)
         reinterpret_cast<uint32_t*>(L.table)[i] = 0xffffffffu;
     __syncthreads();
 
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(64) void softclip_match_kernel(GenomeView g, ReadsV
             err = FLAG_READ_IDX;
         } else {
             m = rv.lens[t.read_idx];
-            if (m < HASH_LEN || m > prm.max_query_len || m > max_len)
+            if (m < HASH_LEN || m > prm.max_query_len || m > max_len || m - HASH_LEN >= EMPTY)
                 err = FLAG_ARG;   // the reference reads past the read / past its query buffer here
             else if (W > max_text_len || W > max_window)
                 err = FLAG_TEXT_LEN;
@@ -177,19 +182,22 @@ __global__ __launch_bounds__(64) void softclip_match_kernel(GenomeView g, ReadsV
         __syncthreads();
 
         // ---- preprocess: insert every 20-mer in order, linear probing (139-231) ----------
-        for (uint32_t i = HASH_LEN - 1 + lane; i < m; i += 64)
-            L.cell[i] = (uint16_t)((key_low(L.query, i) * 0x5555u) & ht_mask);
-        __syncthreads();
-        for (uint32_t i = HASH_LEN - 1; i < m; ++i) {
-            uint32_t p = L.cell[i];
-            while (L.table[p] != EMPTY16)
-                p = (p + 1) & ht_mask;
-            if (lane == 0) {
-                L.table[p] = (uint16_t)(i - (HASH_LEN - 1));
-                L.cell[i] = (uint16_t)p;
+        // (the wave's DS operations execute in program order, so a probe sees every earlier insert
+        // without a barrier; the hashed cells of 64 consecutive 20-mers sit one per lane)
+        for (uint32_t ib = HASH_LEN - 1; ib < m; ib += 64) {
+            const uint32_t mine = ib + lane < m ? (key_low(L.query, ib + lane) * 0x5555u) & ht_mask : 0u;
+            const uint32_t cnt = min(64u, m - ib);
+            for (uint32_t u = 0; u < cnt; ++u) {
+                uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)u);
+                while (L.table[p] != EMPTY)
+                    p = (p + 1) & ht_mask;
+                if (lane == 0) {
+                    L.table[p] = (CELL)(ib + u - (HASH_LEN - 1));
+                    L.cell[ib + u] = (uint16_t)p;
+                }
             }
-            __syncthreads();
         }
+        __syncthreads();
 
         // ---- match (234-495) ------------------------------------------------------------
         const uint32_t min_exact = t.min_exact_len;
@@ -197,6 +205,10 @@ __global__ __launch_bounds__(64) void softclip_match_kernel(GenomeView g, ReadsV
         uint32_t best_text_pos = 0, best_query_pos = 0, best_exact_len = 0;
         int32_t best_score = 0, left_exact_len = 0, left_text_pos = 0;
         uint32_t best_left_len = 0, best_right_len = 0;
+        // the last extension: query[run_q ..) and the text on diagonal run_front agree up to query index run_end
+        uint32_t run_front = 0xffffffffu, run_q = 0, run_end = 0;
+        // checked_pos_left of the text position touched last (hits of one run share it)
+        uint32_t cl_front = 0xffffffffu, cl_val = 0;
 
         // symbol of gp[] / query[] helpers; gp[0] (the dummy 7) is never read below
         auto gp8 = [&](uint32_t j) { return sym8(L.text, skew + j - 1); };
@@ -204,30 +216,41 @@ __global__ __launch_bounds__(64) void softclip_match_kernel(GenomeView g, ReadsV
 
         for (uint32_t jb = HASH_LEN; jb <= W; jb += 64) {
             const uint32_t j = jb + lane;
-            uint32_t first_cell = 0;
-            bool hit = false;
+            // every lane reads the first two cells of its chain now; serving a hit below then costs no
+            // LDS round trip unless the chain is longer (readlane hands the values to the whole wave)
+            uint32_t first_cell = 0, cell_q0 = EMPTY, cell_q1 = EMPTY;
             if (j <= W) {
                 first_cell = (key_low(L.text, skew + j - 1) * 0x5555u) & ht_mask;
-                hit = L.table[first_cell] != EMPTY16;
+                cell_q0 = L.table[first_cell];
+                cell_q1 = L.table[first_cell + 1 >= ht_size ? 0u : first_cell + 1];
             }
-            uint64_t pending = __ballot(hit);
+            uint64_t pending = __ballot(cell_q0 != EMPTY);
             while (pending) {
-                const uint32_t src = (uint32_t)__builtin_ctzll(pending);
+                const int src = __builtin_ctzll(pending);
                 pending &= pending - 1;
-                const uint32_t jh = jb + src;
-                uint32_t ht_pos = (uint32_t)__shfl((int)first_cell, (int)src);
-                uint32_t pos_in_query;
-                while ((pos_in_query = L.table[ht_pos]) != EMPTY16) {   // 273-460
+                const uint32_t jh = jb + (uint32_t)src;
+                uint32_t ht_pos = (uint32_t)__builtin_amdgcn_readlane((int)first_cell, src);
+                const uint32_t second = (uint32_t)__builtin_amdgcn_readlane((int)cell_q1, src);
+                uint32_t pos_in_query = (uint32_t)__builtin_amdgcn_readlane((int)cell_q0, src);
+                for (uint32_t link = 0; pos_in_query != EMPTY; ++link) {   // 273-460
                     const uint32_t pos_in_text = jh - (HASH_LEN - 1);
                     const uint32_t front = pos_in_text - pos_in_query;
                     if (front <= W) {
                         int32_t len = 0;
-                        const uint32_t cl = L.checked_left[front];
+                        if (front != cl_front) {
+                            cl_front = front;
+                            cl_val = L.checked_left[front];
+                        }
+                        const uint32_t cl = cl_val;
                         if ((cl == EMPTY16 ? (1u << 30) : cl) + 1 != pos_in_query) {
                             // 286-291: common run of query[pos_in_query..] and gp[pos_in_text..]
                             const uint32_t range = m - pos_in_query;
                             len = (int32_t)range;
-                            for (uint32_t off = 0; off < range; off += 512) {
+                            // a hit on the diagonal of the last extension, inside its run, ends where that run ended
+                            const bool known = front == run_front && pos_in_query >= run_q && pos_in_query < run_end;
+                            if (known)
+                                len = (int32_t)(run_end - pos_in_query);
+                            for (uint32_t off = 0; !known && off < range; off += 512) {
                                 const uint32_t o = off + 8 * lane;
                                 uint32_t diff = 0xffffffffu;
                                 if (o < range) {
@@ -243,6 +266,11 @@ __global__ __launch_bounds__(64) void softclip_match_kernel(GenomeView g, ReadsV
                                     len = (int32_t)min(stop, range);
                                     break;
                                 }
+                            }
+                            if (!known) {
+                                run_front = front;
+                                run_q = pos_in_query;
+                                run_end = pos_in_query + (uint32_t)len;
                             }
                             if (len >= (int32_t)min_exact) {
                                 if (len > best_score) {   // 295-303
@@ -341,12 +369,15 @@ __global__ __launch_bounds__(64) void softclip_match_kernel(GenomeView g, ReadsV
                                 }
                             }
                         }
-                        if (len >= (int32_t)min_exact && lane == 0)   // 451-455
-                            L.checked_left[front] = (uint16_t)pos_in_query;
-                        __syncthreads();
+                        if (len >= (int32_t)min_exact) {   // 451-455
+                            if (lane == 0)
+                                L.checked_left[front] = (uint16_t)pos_in_query;
+                            cl_val = pos_in_query;
+                        }
                     }
                     if (++ht_pos >= ht_size)   // 459
                         ht_pos = 0;
+                    pos_in_query = link == 0 ? second : L.table[ht_pos];
                 }
             }
         }
@@ -435,7 +466,7 @@ __global__ __launch_bounds__(64) void softclip_match_kernel(GenomeView g, ReadsV
         // ---- HashTable::reset through the log (soft_clipping.h:45-49) --------------------
         __syncthreads();
         for (uint32_t i = HASH_LEN - 1 + lane; i < m; i += 64)
-            L.table[L.cell[i]] = (uint16_t)EMPTY16;
+            L.table[L.cell[i]] = (CELL)EMPTY;
         __syncthreads();
     }
 }
@@ -448,11 +479,12 @@ uint32_t softclip_table_size(uint32_t max_query_len)   // soft_clipping.cpp:45-4
     return s > 0xffffffffull ? 0u : (uint32_t)s;
 }
 
-static uint64_t softclip_lds_bytes(uint32_t ht_size, uint32_t max_window, uint32_t max_len)
+static uint64_t softclip_lds_bytes(uint32_t ht_size, uint32_t cell_bytes, uint32_t max_window, uint32_t max_len)
 {
     const uint64_t text_dw = (max_window + max_len + 16 + 7) / 8 + 2, query_dw = (max_len + 7) / 8 + 2;
     const uint64_t right_dw = (max_window + 32) / 32;
-    return 4 * (text_dw + query_dw + right_dw) + 2 * ((uint64_t)ht_size + ((max_len + 1) & ~1u) + max_window + 4);
+    return 4 * (text_dw + query_dw + right_dw) + (uint64_t)ht_size * cell_bytes +
+           2 * ((uint64_t)((max_len + 1) & ~1u) + max_window + 4);
 }
 
 int launch_softclip_match(wamd_ctx* ctx, const wamd_reads* r, const wamd_softclip_task* d_tasks, uint32_t n,
@@ -465,21 +497,28 @@ int launch_softclip_match(wamd_ctx* ctx, const wamd_reads* r, const wamd_softcli
     const uint32_t ht_size = softclip_table_size(prm->max_query_len);
     if (max_window > ctx->max_text_len)
         max_window = ctx->max_text_len;
-    const uint64_t lds = softclip_lds_bytes(ht_size, max_window, r->max_len);
+    const bool bytes = r->max_len >= 20 && r->max_len - 20 < 255;   // every read position fits a byte cell
+    const uint64_t lds = softclip_lds_bytes(ht_size, bytes ? 1 : 2, max_window, r->max_len);
     if (ht_size == 0 || ht_size > 32768 || lds > 160 * 1024) {
         set_error("wamd_softclip_match: max_query_len %u needs a %u-cell table (limit 32768 cells = max_query_len 655)",
                   prm->max_query_len, ht_size);
         return WAMD_ERR_TOO_LONG;
     }
     if (lds > 64 * 1024)
-        WAMD_HIP(hipFuncSetAttribute((const void*)softclip_match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)lds));
+        WAMD_HIP(hipFuncSetAttribute(bytes ? (const void*)softclip_match_kernel<uint8_t>
+                                           : (const void*)softclip_match_kernel<uint16_t>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     uint32_t per_cu = (uint32_t)((160 * 1024) / lds);
     per_cu = per_cu < 1 ? 1 : (per_cu > 16 ? 16 : per_cu);
     const uint32_t blocks = n < 256u * per_cu ? n : 256u * per_cu;
-    hipLaunchKernelGGL(softclip_match_kernel, dim3(blocks), dim3(64), (uint32_t)lds, s, genome_view(ctx), r->view(),
-                       d_tasks, n, *prm, ctx->scoring, ht_size, max_window, r->max_len, ctx->max_text_len, d_results,
-                       d_cigars, cigar_stride, ctx->d_flags);
+    if (bytes)
+        hipLaunchKernelGGL(softclip_match_kernel<uint8_t>, dim3(blocks), dim3(64), (uint32_t)lds, s, genome_view(ctx),
+                           r->view(), d_tasks, n, *prm, ctx->scoring, ht_size, max_window, r->max_len,
+                           ctx->max_text_len, d_results, d_cigars, cigar_stride, ctx->d_flags);
+    else
+        hipLaunchKernelGGL(softclip_match_kernel<uint16_t>, dim3(blocks), dim3(64), (uint32_t)lds, s, genome_view(ctx),
+                           r->view(), d_tasks, n, *prm, ctx->scoring, ht_size, max_window, r->max_len,
+                           ctx->max_text_len, d_results, d_cigars, cigar_stride, ctx->d_flags);
     WAMD_HIP(hipGetLastError());
     return WAMD_OK;
 }
