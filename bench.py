@@ -188,6 +188,42 @@ def run_extras(ctx, device, genome_symbols, stream, n_small):
     reads.free()
     del d_t, d_r, d_c, d_w
 
+    # S3 / S6: mate rescue with traceback - long windows, k' = 2 * floor(0.09 m) (W = mu + 7 sigma + 2k')
+    def rescue(tag, m, k, W, seed, count):
+        rd_ = synth.make_reads(codes, count, m, k, seed, true_frac=1.0, chunk=1 << 15)
+        reads_ = ctx.upload_reads(*host(rd_["codes"], 1), api.READS_ASCII, orientations=3)
+        t_ = synth.distance_tasks(rd_, m, k, W=W)
+        off_ = np.random.default_rng(seed).integers(k, W - m - k, count)      # the mate sits anywhere in the window
+        t_["ref_pos"] = (rd_["p"].cpu().numpy() - off_).astype(np.uint32)
+        d_t_ = torch.from_numpy(t_.view(np.uint8)).to(device)
+        stride_ = 4 * ((2 * (m + k) + 8 + 3) // 4)
+        d_r_ = torch.zeros(count * api.ALIGN_RESULT.itemsize, dtype=torch.uint8, device=device)
+        d_c_ = torch.zeros(count * stride_, dtype=torch.uint8, device=device)
+        wsb_ = ctx.align_workspace_bytes(reads_, count)
+        d_w_ = torch.zeros(wsb_, dtype=torch.uint8, device=device)
+        ms_ = timed(lambda: ctx.align_dev(reads_, d_t_, count, d_r_, d_c_, stride_, d_w_, wsb_, last_symbol=0, refine=1))
+        res_ = d_r_.cpu().numpy().view(api.ALIGN_RESULT)
+        out[tag] = {"shape": "mate rescue: dynamicProgramming + getExtCigar m=%d k=%d W=%d" % (m, k, W), "tasks": count,
+                    "total_ms": ms_, "alignments_per_s": count / ms_ * 1e3, "ok_fraction": float(res_["ok"].mean()),
+                    "mean_edit_distance": float(res_["edit_distance"][res_["ok"] == 1].mean())}
+        reads_.free()
+
+    rescue("S3_rescue_150bp", 150, 26, 660, 83, na // 4)
+    rescue("S6_rescue_250bp", 250, 44, 700, 84, na // 4)
+
+    # S7: the other two variants - LevMyers128 (m = 100) and LevMyers64 (m = 300), distance only
+    for tag, m, k in (("S7_distance_100bp_M128", 100, 10), ("S7_distance_300bp_M64", 300, 20)):
+        rd = synth.make_reads(codes, na, m, k, 85 + m, chunk=1 << 16)
+        reads = ctx.upload_reads(*host(rd["codes"], 0), api.READS_NIBBLE, orientations=3)
+        t = synth.distance_tasks(rd, m, k)
+        d_t = torch.from_numpy(t.view(np.uint8)).to(device)
+        d_r = torch.zeros(na * 2, dtype=torch.int32, device=device)
+        ms = timed(lambda: ctx.dynamic_programming_dev(reads, d_t, na, d_r, last_symbol=-1))
+        out[tag] = {"shape": "distance m=%d k=%d W=%d" % (m, k, m + 2 * k), "tasks": na, "kernel_ms": ms,
+                    "candidates_per_s": na / ms * 1e3}
+        reads.free()
+        del d_t, d_r
+
     # S8: CIndelMatching::Match, max_indel = 50
     rc, fields = synth.indel_match_workload(codes, na, 150, 80)
     reads = ctx.upload_reads(*host(rc, 0), api.READS_NIBBLE, orientations=1)
