@@ -269,6 +269,17 @@ WAMD_API int wamd_ctx_set_scoring(wamd_ctx* ctx, const wamd_scoring* scoring);
  * max_distance_in_ref above it fail with WAMD_ERR_TEXT_LEN.  Default 16384
  * (mapper/sam.cpp:190). */
 WAMD_API int wamd_ctx_set_max_text_len(wamd_ctx* ctx, uint32_t max_text_len);
+/* What wamd_verify_distance[_dev] reports for candidates the reference rejects.
+ * WAMD_DISTANCE_EXACT (default): edit_distance is what dynamicProgramming leaves in its
+ * reference argument, also above k (LevMyers256.hpp:239-244).
+ * WAMD_DISTANCE_ACCEPTED_ONLY: accepted candidates (edit_distance <= k) come back exactly as
+ * above - distance and end column with the variant's tie-break - and every other one as
+ * {k + 1, 0}.  That is all the mapping stages consume (`cur_match <= max_mismatches`,
+ * mapper/mapping_core_sa.cpp:237-241, 289-293), and it lets the library compute only the band
+ * of diagonals an accepted alignment can use (Hyyro's banded form of the recurrence).
+ * wamd_align[_dev] is not affected. */
+enum { WAMD_DISTANCE_EXACT = 0, WAMD_DISTANCE_ACCEPTED_ONLY = 1 };
+WAMD_API int wamd_ctx_set_distance_mode(wamd_ctx* ctx, int mode);
 /* What SetReference's ref_size / cur_offset arguments change between stages
  * (every CMappingCore is built with its stage's anchor offset, mapping_core.cpp:156);
  * the genome itself stays where it is. */

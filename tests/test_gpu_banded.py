@@ -1,0 +1,171 @@
+"""Accepted-only mode of the distance path (banded kernels, WAMD_DISTANCE_ACCEPTED_ONLY) vs the
+oracle: every candidate the reference accepts (edit_distance <= k) must come back with the
+reference's distance AND end column (variant tie-break included); every other one as {k + 1, 0}.
+Bit-exact bar.  The shapes walk across the band limits: 64-row band (n_cols - m + 2k + 2 <= 64),
+96-row band, whole columns, and waves that mix lengths, rules and windows."""
+import numpy as np
+import pytest
+import torch
+
+import common
+from whisper_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+ACCEPTED_ONLY = 1
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    codes, packed = common.genome()
+    c = api.Context(packed, ref_size=codes.numel(), cur_offset=0)
+    c.set_distance_mode(ACCEPTED_ONLY)
+    yield c
+    c.destroy()
+
+
+def clamp(want, k):
+    k = np.asarray(k, np.uint32)
+    out = want.copy()
+    rej = want["edit_distance"] > k
+    out["edit_distance"] = np.where(rej, k + 1, want["edit_distance"])
+    out["pos"] = np.where(rej, 0, want["pos"])
+    return out
+
+
+def check(ctx, oracle, packed, blob, off, lens, enc, tasks, last, min_accepted):
+    rc, want = oracle.distance(packed, blob, off, lens, enc, tasks, last)
+    assert rc == 0
+    want = clamp(want, tasks["max_ed"])
+    reads = ctx.upload_reads(blob, off, lens, enc)
+    got = ctx.dynamic_programming(reads, tasks, last)
+    reads.free()
+    assert (want["edit_distance"] <= tasks["max_ed"]).sum() >= min_accepted
+    bad = np.flatnonzero((got["edit_distance"] != want["edit_distance"]) | (got["pos"] != want["pos"]))
+    assert len(bad) == 0, "first differences (task, got, want): %s" % [
+        (int(i), tuple(got[i]), tuple(want[i])) for i in bad[:5]]
+
+
+BAND_CASES = [
+    # m, k, W, variant, encoding, last_symbol
+    (150, 12, None, 0, 0, -1),      # S1: 64-row band, 128 sliding columns
+    (150, 12, None, 0, 1, 0),       # ASCII reads, stale last_symbol
+    (150, 12, None, 0, 1, 3),
+    (150, 5, None, 0, 0, -1),
+    (150, 1, None, 0, 0, -1),
+    (150, 0, None, 0, 0, -1),       # nothing can be accepted: the skewed loop stops before column m
+    (150, 15, None, 0, 0, -1),      # last k of the 64-row band at W = m + 2k
+    (150, 16, None, 0, 0, -1),      # 96-row band
+    (150, 23, None, 0, 0, -1),      # last k of the 96-row band
+    (150, 24, None, 0, 0, -1),      # whole columns
+    (150, 13, 177, 0, 1, 0),        # fill_cigar_with_lev window
+    (150, 12, 150, 0, 0, -1),       # window as long as the read
+    (150, 12, 145, 0, 0, -1),       # shorter than the read
+    (151, 12, None, 0, 0, -1),
+    (250, 7, None, 0, 0, -1),       # S5: 64-row band on 8 dwords
+    (250, 17, None, 0, 0, -1),      # S5 sensitive: 96-row band
+    (100, 10, None, 0, 0, -1),      # M128 tie-break
+    (100, 3, None, 0, 0, -1),
+    (127, 8, None, 0, 0, -1),
+    (128, 8, None, 0, 0, -1),
+    (193, 8, None, 0, 0, -1),
+    (255, 10, None, 0, 0, -1),
+    (256, 10, None, 0, 0, -1),      # M64: W columns
+    (300, 20, None, 0, 0, -1),
+    (300, 12, None, 0, 0, -1),
+    (150, 12, None, 1, 0, -1),      # M64 forced on a short read
+    (150, 26, 660, 0, 1, 0),        # mate rescue window: nothing fits a band
+    (64, 6, None, 0, 0, -1),        # short reads: whole columns
+    (30, 3, None, 0, 0, -1),
+    (97, 9, None, 0, 0, -1),
+]
+
+
+@pytest.mark.parametrize("m,k,W,variant,enc,last", BAND_CASES)
+def test_accepted_only(ctx, oracle, m, k, W, variant, enc, last):
+    codes, packed, (blob, off, lens), tasks = common.distance_workload(m, k, 6000, seed=500 + m + 7 * k,
+                                                                      encoding=enc, W=W, variant=variant)
+    check(ctx, oracle, packed, blob, off, lens, enc, tasks, last, 0 if (W or 1 << 30) <= m or k == 0 else 800)
+
+
+def test_accepted_only_mixed_waves(ctx, oracle):
+    """Lengths, budgets and windows vary inside every wave: different tie-break rules, band
+    fits and fixed-phase starts side by side (deferred lanes go down the chain)."""
+    codes, packed = common.genome()
+    g = torch.Generator().manual_seed(11)
+    lens_ = [150, 151, 150, 149, 151, 150, 100, 250, 127, 128, 150, 256, 300, 33, 150, 151]
+    reads_codes, tasks = [], []
+    for i, m in enumerate(lens_ * 250):
+        p = int(torch.randint(20000, 900000, (1,), generator=g))
+        r = codes[p:p + m].clone()
+        ne = int(torch.randint(0, 9, (1,), generator=g))
+        for _ in range(ne):
+            x = int(torch.randint(0, m, (1,), generator=g))
+            kind = int(torch.randint(0, 10, (1,), generator=g))
+            if kind < 7:
+                r[x] = (int(r[x]) + 1 + int(torch.randint(0, 3, (1,), generator=g))) & 3
+            elif kind == 7 and x + 1 < m:      # deletion from the read
+                r[x:-1] = r[x + 1:].clone()
+            elif x + 1 < m:                    # insertion into the read
+                r[x + 1:] = r[x:-1].clone()
+        r[r > 3] = 4
+        reads_codes.append(r)
+        k = int(torch.randint(0, 14, (1,), generator=g))
+        k = min(k, m - 1)
+        extra = int(torch.randint(0, 6, (1,), generator=g))
+        tasks.append((i, p - k, m + 2 * k + extra, k, 0, 0))
+    blob, off, lens = common.mixed_reads(reads_codes, 0)
+    tasks = np.array(tasks, api.DIST_TASK)
+    check(ctx, oracle, packed, blob, off, lens, 0, tasks, -1, 1000)
+
+
+def test_accepted_only_n_runs(oracle):
+    """Windows full of N_ref runs: the per-lane slow groups of both phases."""
+    codes = synth.make_genome(1 << 18, seed=9, n_frac=0.05, n_run=7)
+    packed = synth.pack_nibbles(codes).numpy()
+    c = api.Context(packed, ref_size=codes.numel(), cur_offset=0)
+    c.set_distance_mode(ACCEPTED_ONLY)
+    try:
+        for m, k, enc in ((150, 12, 0), (150, 12, 1), (250, 17, 0), (100, 10, 0), (300, 12, 0)):
+            rd = synth.make_reads(codes, 4000, m, k, seed=40 + m, n_read_frac=0.2)
+            blob, off, lens = common.host_reads(rd, enc)
+            tasks = synth.distance_tasks(rd, m, k)
+            # ASCII reads come through preprocessRawSeq, which leaves last_symbol alone (0 in CSamGenerator)
+            check(c, oracle, packed, blob, off, lens, enc, tasks, 0 if enc else -1, 300)
+    finally:
+        c.destroy()
+
+
+def test_accepted_only_low_complexity(oracle):
+    """Tandem repeats: many co-optimal end columns, so the tie-break rules decide."""
+    codes, packed = common.low_complexity_genome()
+    c = api.Context(packed, ref_size=codes.numel(), cur_offset=0)
+    c.set_distance_mode(ACCEPTED_ONLY)
+    try:
+        for m, k in ((150, 12), (100, 10), (250, 17), (300, 20), (150, 15)):
+            rd = synth.make_reads(codes, 5000, m, k, seed=60 + m + k, true_frac=0.9)
+            blob, off, lens = common.host_reads(rd, 0)
+            tasks = synth.distance_tasks(rd, m, k)
+            check(c, oracle, packed, blob, off, lens, 0, tasks, -1, 1500)
+    finally:
+        c.destroy()
+
+
+def test_mode_switch_and_errors(ctx, oracle):
+    codes, packed, (blob, off, lens), tasks = common.distance_workload(150, 12, 600, seed=3)
+    reads = ctx.upload_reads(blob, off, lens, 0)
+    bad = tasks.copy()
+    bad["max_distance_in_ref"][5] = 0
+    with pytest.raises(api.WamdError) as e:
+        ctx.dynamic_programming(reads, bad)
+    assert e.value.status == 5
+    rc, want = oracle.distance(packed, blob, off, lens, 0, tasks, -1)
+    ctx.set_distance_mode(0)
+    try:
+        np.testing.assert_array_equal(ctx.dynamic_programming(reads, tasks), want)
+    finally:
+        ctx.set_distance_mode(ACCEPTED_ONLY)
+    np.testing.assert_array_equal(ctx.dynamic_programming(reads, tasks), clamp(want, tasks["max_ed"]))
+    with pytest.raises(api.WamdError):
+        ctx.set_distance_mode(7)
+    reads.free()

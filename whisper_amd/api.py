@@ -82,7 +82,7 @@ STATUS = {0: "WAMD_OK", 1: "WAMD_ERR_INVALID_ARG", 2: "WAMD_ERR_HIP", 3: "WAMD_E
 EXPORTS = [
     "wamd_version", "wamd_last_error", "wamd_device_count", "wamd_ctx_create",
     "wamd_ctx_create_dev", "wamd_ctx_destroy", "wamd_ctx_set_scoring",
-    "wamd_ctx_set_max_text_len", "wamd_ctx_set_reference_params", "wamd_ctx_stream",
+    "wamd_ctx_set_max_text_len", "wamd_ctx_set_distance_mode", "wamd_ctx_set_reference_params", "wamd_ctx_stream",
     "wamd_ctx_synchronize", "wamd_ctx_take_flags", "wamd_reads_upload", "wamd_reads_free",
     "wamd_reads_count", "wamd_verify_distance", "wamd_verify_distance_dev", "wamd_levdiag",
     "wamd_levdiag_dev", "wamd_cf_filter", "wamd_cf_filter_dev", "wamd_align", "wamd_align_dev", "wamd_align_workspace_bytes",
@@ -210,6 +210,9 @@ class Context:
 
     def set_max_text_len(self, v):
         _check(lib().wamd_ctx_set_max_text_len(self.h, C.c_uint32(v)))
+
+    def set_distance_mode(self, mode):
+        _check(lib().wamd_ctx_set_distance_mode(self.h, C.c_int(mode)))
 
     def set_reference_params(self, ref_size, cur_offset):
         _check(lib().wamd_ctx_set_reference_params(self.h, C.c_uint32(ref_size),

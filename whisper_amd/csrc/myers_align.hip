@@ -1040,7 +1040,7 @@ int launch_align(wamd_ctx* ctx, const wamd_reads* r, const wamd_dist_task* d_tas
     const uint64_t region = L.total - L.slots_off;
 
     WAMD_HIP(hipMemsetAsync(d_counters, 0, 256, s));
-    int rc = launch_distance(ctx, r, d_tasks, n, last_symbol, d_dist, s);
+    int rc = launch_distance(ctx, r, d_tasks, n, last_symbol, d_dist, WAMD_DISTANCE_EXACT, s);
     if (rc)
         return rc;
     const ReadsView rv = r->view();

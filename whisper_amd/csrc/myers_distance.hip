@@ -42,6 +42,7 @@ namespace wamd {
 constexpr int TEXT_CHUNK = WAMD_TEXT_CHUNK;   // genome dwords (8 columns each) fetched per batch and lane
 
 enum { RULE_M64 = 0, RULE_M128 = 1, RULE_M256 = 2 };
+constexpr uint32_t RESULT_DEFERRED = 0xFFFFFFFEu;   // left to the next kernel of the banded chain
 
 // a value the compiler must keep in a VGPR: VALU ops with an SGPR operand issue at the
 // slow (VOP3) rate on gfx950, see scripts/ubench/valu_rates.hip
@@ -117,9 +118,11 @@ constexpr int TT_AND3 = 0xf0 & 0xcc & 0xaa;                // a & b & c
 
 // One text column over the whole NW-dword vector (LevMyers64.cpp:312-325 as a single
 // wide word).  Returns HP, HN and D0 of the top dword (score row = bit 31).
-template <int NW>
+// HIN: the row above the vector is a real matrix row that is not computed (banded kernel);
+// its horizontal delta is taken as +1 where `hin` is all ones, 0 where it is zero.
+template <int NW, bool HIN = false>
 __device__ __forceinline__ void column_core(const uint32_t (&eq)[NW], uint32_t (&VP)[NW], uint32_t (&VN)[NW],
-                                            uint32_t& hp_top, uint32_t& hn_top, uint32_t& d0_top)
+                                            uint32_t& hp_top, uint32_t& hn_top, uint32_t& d0_top, uint32_t hin = 0)
 {
     // stage-major order: the dwords of one stage are independent, so no instruction has to
     // wait for its neighbour's result (the compiler pads a dependent pair of asm ops)
@@ -148,7 +151,8 @@ __device__ __forceinline__ void column_core(const uint32_t (&eq)[NW], uint32_t (
         hn[w] = v_and(d0[w], VP[w]);
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
-        hps[w] = w ? __builtin_amdgcn_alignbit(hp[w], hp[w ? w - 1 : 0], 31) : v_add(hp[w], hp[w]);
+        hps[w] = w ? __builtin_amdgcn_alignbit(hp[w], hp[w ? w - 1 : 0], 31)
+                   : (HIN ? __builtin_amdgcn_alignbit(hp[w], hin, 31) : v_add(hp[w], hp[w]));
         hns[w] = w ? __builtin_amdgcn_alignbit(hn[w], hn[w ? w - 1 : 0], 31) : v_add(hn[w], hn[w]);
     }
 #pragma unroll
@@ -166,7 +170,7 @@ __device__ __forceinline__ void column_core(const uint32_t (&eq)[NW], uint32_t (
 template <int NW>
 __device__ __forceinline__ uint32_t phantom_mask(uint32_t m, int j)
 {
-    const uint32_t s = 32u * NW - m;   // phantom rows
+    const uint32_t s = m >= 32u * NW ? 0u : 32u * NW - m;   // phantom rows
     const uint32_t lo = 32u * (uint32_t)j;
     return s >= lo + 32u ? ~0u : (s <= lo ? 0u : ((1u << (s - lo)) - 1u));
 }
@@ -193,6 +197,7 @@ struct Lane {
 struct FastGroup {
     uint32_t lane_addr, syms, symsA, nz, nzA, gconst, nbase;   // per group
     uint32_t exit_t, n_left, rowmask, sgn, bit16;              // per lane / constants held in VGPRs
+    uint32_t hin;                                              // banded kernel: see column_core
 };
 
 // LDS reads of the pattern-match vectors for symbol U of the group
@@ -209,7 +214,7 @@ __device__ __forceinline__ void load_eq(const FastGroup& f, uint32_t (&eq)[NW])
         eq[w] = *(lds_ptr)(uintptr_t)(addr + (uint32_t)w * (4u * BLOCK * 4u));
 }
 
-template <int NW, int BLOCK, int RULE, bool ENDS, int U>
+template <int NW, int BLOCK, int RULE, bool ENDS, bool HIN, int U>
 __device__ __forceinline__ void fast_column(const FastGroup& f, uint32_t (&eq)[NW], uint32_t (&VP)[NW],
                                             uint32_t (&VN)[NW], uint32_t& E, uint32_t& key, uint32_t& deadf)
 {
@@ -218,7 +223,7 @@ __device__ __forceinline__ void fast_column(const FastGroup& f, uint32_t (&eq)[N
     if (U < 7)
         load_eq<NW, BLOCK, (U < 7 ? U + 1 : 0)>(f, eq_next);
     uint32_t hp, hn, d0;
-    column_core<NW>(eq, VP, VN, hp, hn, d0);
+    column_core<NW, HIN>(eq, VP, VN, hp, hn, d0, f.hin);
     if (U < 7) {
 #pragma unroll
         for (int w = 0; w < NW; ++w)
@@ -247,13 +252,14 @@ __device__ __forceinline__ void fast_column(const FastGroup& f, uint32_t (&eq)[N
         deadf = v_bitop3<TT_OR_AND>(deadf, v_sub(f.exit_t, E), nhn);
 }
 
-template <int NW, int BLOCK, int RULE, bool ENDS>
+template <int NW, int BLOCK, int RULE, bool ENDS, bool HIN>
 __device__ __forceinline__ void group_fast(uint32_t lane_addr, uint32_t syms, uint32_t base, uint32_t lsrep,
                                            uint32_t exit_t, uint32_t n_left, uint32_t rowmask, uint32_t sgn,
-                                           uint32_t bit16, uint32_t (&VP)[NW], uint32_t (&VN)[NW], uint32_t& E,
-                                           uint32_t& key, uint32_t& deadf)
+                                           uint32_t bit16, uint32_t hin, uint32_t (&VP)[NW], uint32_t (&VN)[NW],
+                                           uint32_t& E, uint32_t& key, uint32_t& deadf)
 {
     FastGroup f;
+    f.hin = hin;
     f.lane_addr = lane_addr;
     f.syms = syms;
     f.symsA = syms << 12;
@@ -277,14 +283,14 @@ __device__ __forceinline__ void group_fast(uint32_t lane_addr, uint32_t syms, ui
     f.bit16 = bit16;
     uint32_t eq[NW];
     load_eq<NW, BLOCK, 0>(f, eq);
-    fast_column<NW, BLOCK, RULE, ENDS, 0>(f, eq, VP, VN, E, key, deadf);
-    fast_column<NW, BLOCK, RULE, ENDS, 1>(f, eq, VP, VN, E, key, deadf);
-    fast_column<NW, BLOCK, RULE, ENDS, 2>(f, eq, VP, VN, E, key, deadf);
-    fast_column<NW, BLOCK, RULE, ENDS, 3>(f, eq, VP, VN, E, key, deadf);
-    fast_column<NW, BLOCK, RULE, ENDS, 4>(f, eq, VP, VN, E, key, deadf);
-    fast_column<NW, BLOCK, RULE, ENDS, 5>(f, eq, VP, VN, E, key, deadf);
-    fast_column<NW, BLOCK, RULE, ENDS, 6>(f, eq, VP, VN, E, key, deadf);
-    fast_column<NW, BLOCK, RULE, ENDS, 7>(f, eq, VP, VN, E, key, deadf);
+    fast_column<NW, BLOCK, RULE, ENDS, HIN, 0>(f, eq, VP, VN, E, key, deadf);
+    fast_column<NW, BLOCK, RULE, ENDS, HIN, 1>(f, eq, VP, VN, E, key, deadf);
+    fast_column<NW, BLOCK, RULE, ENDS, HIN, 2>(f, eq, VP, VN, E, key, deadf);
+    fast_column<NW, BLOCK, RULE, ENDS, HIN, 3>(f, eq, VP, VN, E, key, deadf);
+    fast_column<NW, BLOCK, RULE, ENDS, HIN, 4>(f, eq, VP, VN, E, key, deadf);
+    fast_column<NW, BLOCK, RULE, ENDS, HIN, 5>(f, eq, VP, VN, E, key, deadf);
+    fast_column<NW, BLOCK, RULE, ENDS, HIN, 6>(f, eq, VP, VN, E, key, deadf);
+    fast_column<NW, BLOCK, RULE, ENDS, HIN, 7>(f, eq, VP, VN, E, key, deadf);
 }
 
 // What one task asks for, derived exactly as the reference's caller and loop do.
@@ -320,21 +326,198 @@ __device__ __forceinline__ uint32_t decode_task(const wamd_dist_task& task, cons
     return 0;
 }
 
+// ---- the column loop: columns base0 + 1 .. n_cols of every lane, bookkeeping in `t` -----------
+// pm_lds: this block's pattern-match rows [NW dwords][A,C,G,T][BLOCK lanes] (the banded kernel
+// passes the top NW dwords of longer vectors); VP / VN: the state before column base0 + 1;
+// t.curr_ed / min_ed / min_pos / stopped as they stand there.  `valid` lanes take part in the
+// wave-uniform decisions, the others only ride along.
+template <int NW, int BLOCK, bool HIN>
+__device__ __forceinline__ void run_columns(const GenomeView& g, Lane& t, const bool valid, uint32_t (&VP)[NW],
+                                            uint32_t (&VN)[NW], const uint32_t* pm_lds, const uint32_t tid,
+                                            const uint8_t* my_codes, const uint32_t ref_pos, const uint32_t base0,
+                                            const uint32_t hin)
+{
+    // ---- wave-uniform facts ------------------------------------------------------------------
+    const uint64_t live0 = __ballot(valid);
+    const uint32_t rule0 =
+        __builtin_amdgcn_readfirstlane(__shfl((int)t.rule, live0 ? __ffsll((long long)live0) - 1 : 0));
+    const bool uniform_rule = __all(!valid || t.rule == rule0);
+    // the packed key holds 15 bits of distance + column and 16 bits of column
+    const bool fits = __all(!valid || t.m + t.n_cols < 32000u);
+    const bool can_fast = uniform_rule && fits;
+
+    const uint32_t lsrep = t.last_sym * 0x11111111u;
+    const uint32_t rowmask = in_vgpr(3u << (BLOCK == 256 ? 10 : (BLOCK == 128 ? 9 : 8)));
+    const uint32_t sgn = in_vgpr(0x80000000u);
+    const uint32_t bit16 = in_vgpr(0x10000u);
+    // LDS byte address of this lane's slot in row A of dword 0
+    const uint32_t lane_addr =
+        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint32_t*)pm_lds + tid * 4u;
+
+    // ---- text stream: R = nibble-swapped dwords of the current chunk (+1 for the funnel),
+    // NX = raw dwords of the next one, already in flight
+    bool packed = false;   // wave-uniform: which bookkeeping form is current
+    uint32_t E = 0, key = 0, deadf = 0;
+    uint32_t base = base0;   // columns done (wave-uniform, a multiple of 8)
+
+    const uint32_t shift = (ref_pos & 7u) * 4u;
+    uint32_t didx = (ref_pos >> 3) + (base0 >> 3);
+    uint32_t R[TEXT_CHUNK + 1], NX[TEXT_CHUNK];
+#pragma unroll
+    for (int c = 0; c <= TEXT_CHUNK; ++c)
+        R[c] = load_genome_dword(g, didx + c);
+    didx += TEXT_CHUNK + 1;
+
+    for (;;) {
+        // next chunk's loads go out before this chunk's columns
+#pragma unroll
+        for (int c = 0; c < TEXT_CHUNK; ++c) {
+            const uint32_t idx = didx + c;
+            NX[c] = g.dwords[idx < g.last_dword ? idx : g.last_dword];
+        }
+        didx += TEXT_CHUNK;
+
+        bool done = false;
+        for (int gi = 0; gi < TEXT_CHUNK; ++gi, base += 8) {
+            const bool alive = packed ? (int32_t)deadf >= 0 : !t.stopped;
+            if (!__any(alive)) {
+                done = true;
+                break;
+            }
+            const uint32_t syms = __builtin_amdgcn_alignbit(R[1], R[0], shift);
+#pragma unroll
+            for (int c = 0; c < TEXT_CHUNK; ++c)
+                R[c] = R[c + 1];
+
+            const bool fast = can_fast && !__any(alive && (syms & 0xccccccccu));
+            if (fast) {
+                if (!packed) {
+                    E = t.curr_ed + base;
+                    key = (t.min_ed << 17) | (0xffffu - t.min_pos);
+                    deadf = t.stopped ? 0x80000000u : 0u;
+                    packed = true;
+                }
+                const uint32_t n_left = t.n_cols - base;
+                const bool ends = __any(alive && n_left < 8u);
+#define WAMD_GROUP(RULE, ENDS)                                                                               \
+    group_fast<NW, BLOCK, RULE, ENDS, HIN>(lane_addr, syms, base, lsrep, t.exit_t, n_left, rowmask, sgn, bit16, hin, \
+                                           VP, VN, E, key, deadf)
+                if (rule0 == RULE_M256) {
+                    if (ends)
+                        WAMD_GROUP(RULE_M256, true);
+                    else
+                        WAMD_GROUP(RULE_M256, false);
+                } else if (rule0 == RULE_M128) {
+                    if (ends)
+                        WAMD_GROUP(RULE_M128, true);
+                    else
+                        WAMD_GROUP(RULE_M128, false);
+                } else {
+                    if (ends)
+                        WAMD_GROUP(RULE_M64, true);
+                    else
+                        WAMD_GROUP(RULE_M64, false);
+                }
+#undef WAMD_GROUP
+                continue;
+            }
+
+            // ---- slow group: per-lane bookkeeping, any text symbol ----------------------------
+            if (packed) {
+                if (!t.stopped) {   // lanes that were finished when packing keep their values
+                    t.curr_ed = E - base;
+                    t.min_ed = key >> 17;
+                    t.min_pos = 0xffffu - (key & 0xffffu);
+                    t.stopped = (int32_t)deadf < 0;
+                }
+                packed = false;
+            }
+#pragma unroll 1
+            for (uint32_t u = 0; u < 8; ++u) {
+                const uint32_t col = base + u + 1;
+                const uint32_t c = (syms >> (4 * u)) & 15u;
+                const bool act = !t.stopped && col <= t.n_cols;
+                // a text symbol >= 4 matches only a read holding that very code, which real
+                // data never does (genome: 5/15, reads: 4/6); stay exact anyway
+                const bool exotic = act && c >= 4u && ((t.presence >> c) & 1u);
+                uint32_t eq[NW];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    uint32_t v = phantom_mask<NW>(t.m, w);
+                    if (c < 4u)
+                        v = pm_lds[(w * 4 + c) * BLOCK + tid];
+                    if (exotic) {
+                        const int32_t first = 32 * w - (int32_t)(32u * NW - t.m);
+                        for (int32_t b = 0; b < 32; ++b) {
+                            const int32_t i = first + b;
+                            if (i < 0 || i >= (int32_t)t.m)
+                                continue;
+                            const uint32_t rcode = t.rev ? rc_code(packed_symbol(my_codes, t.m - 1 - (uint32_t)i))
+                                                         : packed_symbol(my_codes, (uint32_t)i);
+                            v |= (uint32_t)(rcode == c) << b;
+                        }
+                    }
+                    eq[w] = v;
+                }
+                uint32_t hp, hn, d0;
+                column_core<NW, HIN>(eq, VP, VN, hp, hn, d0, hin);
+
+                const uint32_t hnb = hn >> 31, hpb = hp >> 31, d0b = d0 >> 31;
+                const uint32_t ced = t.curr_ed + hpb - hnb;
+                const bool lt = ced < t.min_ed;
+                const bool tie = ced == t.min_ed;
+                const bool move = tie && (t.rule == RULE_M256 ? (!d0b || c == t.last_sym) : (t.min_pos + 1 == col));
+                if (act) {
+                    t.curr_ed = ced;
+                    if (lt)
+                        t.min_ed = ced;
+                    if (lt || move)
+                        t.min_pos = col;
+                    // early exit on the iteration index j = col + wn
+                    // (LevMyers256.hpp:232-233, LevMyers128.hpp:125, 219-220)
+                    if (t.rule != RULE_M64 && !hnb && ced + col > t.exit_t)
+                        t.stopped = true;
+                }
+                if (col >= t.n_cols)
+                    t.stopped = true;   // last column of this lane
+            }
+        }
+        if (done)
+            break;
+        // rotate the prefetched chunk in: R[0] already holds the funnel's low dword
+#pragma unroll
+        for (int c = 0; c < TEXT_CHUNK; ++c)
+            R[c + 1] = nibble_swap(NX[c]);
+    }
+
+    if (packed && !t.stopped) {   // t.stopped: as it was when the state was packed
+        t.min_ed = key >> 17;
+        t.min_pos = 0xffffu - (key & 0xffffu);
+    }
+}
+
 #ifndef WAMD_KATTR
 #define WAMD_KATTR
 #endif
+// `only_deferred`: the launch finishes what the banded kernels left (results marked
+// RESULT_DEFERRED); a zero count ends every block at once.  `clamp`: accepted-only mode,
+// distances above k are reported as k + 1.
 template <int NW, int BLOCK>
 __global__ __launch_bounds__(BLOCK) WAMD_KATTR void myers_distance_kernel(
     GenomeView g, ReadsView rv, const wamd_dist_task* __restrict__ tasks, uint32_t n,
     int last_symbol, uint32_t max_text_len, wamd_dist_result* __restrict__ results,
-    uint32_t* __restrict__ flags)
+    uint32_t* __restrict__ flags, const uint32_t* __restrict__ only_deferred, int clamp)
 {
     // [dword][symbol A,C,G,T][lane]
     __shared__ uint32_t pm_lds[NW * 4 * BLOCK];
 
+    if (only_deferred && *only_deferred == 0)
+        return;
     const uint32_t tid = threadIdx.x;
     const uint32_t gid = blockIdx.x * BLOCK + tid;
     bool valid = gid < n;
+    if (valid && only_deferred && results[gid].edit_distance != RESULT_DEFERRED)
+        valid = false;
 
     Lane t{};
     uint32_t read_idx = 0, ref_pos = 0;
@@ -404,172 +587,317 @@ __global__ __launch_bounds__(BLOCK) WAMD_KATTR void myers_distance_kernel(
     }
     if (valid && (t.stopped || t.n_cols == 0)) {
         // finished before the first text column
-        results[gid].edit_distance = t.min_ed;
+        results[gid].edit_distance = (clamp && t.min_ed > t.k) ? t.k + 1u : t.min_ed;
         results[gid].pos = t.min_ed > t.k ? 0u : t.min_pos;
         valid = false;
         t.stopped = true;
     }
 
-    // ---- wave-uniform facts ------------------------------------------------------------------
-    const uint64_t live0 = __ballot(valid);
-    const uint32_t rule0 =
-        __builtin_amdgcn_readfirstlane(__shfl((int)t.rule, live0 ? __ffsll((long long)live0) - 1 : 0));
-    const bool uniform_rule = __all(!valid || t.rule == rule0);
-    // the packed key holds 15 bits of distance + column and 16 bits of column
-    const bool fits = __all(!valid || t.m + t.n_cols < 32000u);
-    const bool can_fast = uniform_rule && fits;
+    run_columns<NW, BLOCK, false>(g, t, valid, VP, VN, pm_lds, tid, rv.codes + rv.code_off[read_idx], ref_pos, 0u, 0u);
 
-    const uint32_t lsrep = t.last_sym * 0x11111111u;
-    const uint32_t rowmask = in_vgpr(3u << (BLOCK == 256 ? 10 : (BLOCK == 128 ? 9 : 8)));
-    const uint32_t sgn = in_vgpr(0x80000000u);
-    const uint32_t bit16 = in_vgpr(0x10000u);
-    // LDS byte address of this lane's slot in row A of dword 0
-    const uint32_t lane_addr =
-        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)pm_lds + tid * 4u;
+    if (valid) {
+        results[gid].edit_distance = (clamp && t.min_ed > t.k) ? t.k + 1u : t.min_ed;
+        results[gid].pos = t.min_ed > t.k ? 0u : t.min_pos;
+    }
+}
+
+// ===========================================================================================
+// Banded kernel (accepted-only mode): the same answers for every candidate the reference
+// accepts (edit_distance <= k: distance and end column with the variant's tie-break), k + 1
+// for the rest - which is all the mapping stages read (mapping_core_sa.cpp:237-241, 289).
+//
+// A candidate can only be accepted through cells on the diagonals -k .. n_cols - m + k of its
+// matrix (a path of cost <= k starts on a diagonal >= 0, ends on one in
+// [-k, n_cols - m], and leaving that range on either side costs more than k to come back).
+// When those fit in 32 NB rows, only a band of 32 NB rows is computed:
+//   * columns 1 .. FS ("sliding"): the frame moves down one row per column (Hyyro's band form:
+//     D0 shifts right instead of HP / HN shifting left), its bottom reaching the read's last
+//     row after column FS.  Cells outside count as infinity, so every value is an upper bound
+//     and exact wherever the true value is <= k.  The value under the frame's bottom-left
+//     corner is known (D[r][0] = r) and is followed down the diagonal by counting D0's top bit;
+//   * columns FS + 1 .. n_cols ("fixed"): the frame stays on the read's last 32 NB rows and the
+//     ordinary recurrence runs there (run_columns with NW = NB), the unknown row above coming
+//     in with a horizontal delta of +1 (an upper bound again).  The score row is the top bit,
+//     so the reference's bookkeeping is the exact kernel's, fed with upper bounds: the first
+//     column that reaches the final minimum and the ties after it are cells of value <= k,
+//     hence the true ones; the early exit may fire sooner but only where the true value could
+//     not come back under k either.
+// pm32 is top-aligned, so the frame of column f + 1 starts at bit 32 words32 - FS + f of a
+// row whatever the read's length: dword index and funnel shift are wave-uniform.  FS is the
+// wave's maximum of n_cols + k - 32 NB, rounded up to a multiple of 8 (a text dword); a lane
+// fits when FS + k + 2 <= m (its accepted end columns then all lie in the fixed phase, one
+// diagonal to spare).  Lanes that do not fit, waves that mix tie-break rules, k >= m and
+// oversized windows are left to the next kernel of the chain (RESULT_DEFERRED).
+// ===========================================================================================
+
+template <int NB>
+__device__ __forceinline__ uint32_t slide_core(const uint32_t (&eq)[NB], uint32_t (&VP)[NB], uint32_t (&VN)[NB])
+{
+    uint32_t x[NB], d0[NB], hp[NB], hn[NB], d0s[NB];
+#pragma unroll
+    for (int w = 0; w < NB; ++w)
+        x[w] = v_and(eq[w], VP[w]);
+    uint32_t carry = 0;
+#pragma unroll
+    for (int w = 0; w < NB; ++w) {
+        uint32_t cout;
+        x[w] = __builtin_addc(x[w], VP[w], carry, &cout);
+        carry = cout;
+    }
+#pragma unroll
+    for (int w = 0; w < NB; ++w)
+        x[w] = v_bitop3<TT_XOR_OR>(x[w], VP[w], eq[w]);
+#pragma unroll
+    for (int w = 0; w < NB; ++w)
+        d0[w] = v_or(x[w], VN[w]);
+#pragma unroll
+    for (int w = 0; w < NB; ++w)
+        hp[w] = v_bitop3<TT_OR_NOR>(VN[w], d0[w], VP[w]);
+#pragma unroll
+    for (int w = 0; w < NB; ++w)
+        hn[w] = v_and(d0[w], VP[w]);
+#pragma unroll
+    for (int w = 0; w < NB; ++w)
+        d0s[w] = w < NB - 1 ? __builtin_amdgcn_alignbit(d0[w < NB - 1 ? w + 1 : w], d0[w], 1) : v_lshr<1>(d0[w]);
+#pragma unroll
+    for (int w = 0; w < NB; ++w)
+        VP[w] = v_bitop3<TT_OR_NOR>(hn[w], d0s[w], hp[w]);   // vertical deltas in the NEXT column's frame
+#pragma unroll
+    for (int w = 0; w < NB; ++w)
+        VN[w] = v_and(d0s[w], hp[w]);
+    return d0[NB - 1];
+}
+
+// pattern-match bits of the frame for symbol U of the group: NB + 1 dwords from row idx on,
+// funnelled by the wave-uniform shift
+template <int NB, int BLOCK, int U>
+__device__ __forceinline__ void slide_load(uint32_t grp_addr, uint32_t syms, uint32_t symsA, uint32_t rowmask,
+                                           uint32_t (&raw)[NB + 1])
+{
+    typedef const __attribute__((address_space(3))) uint32_t* lds_ptr;
+    constexpr int RSH = BLOCK == 256 ? 10 : (BLOCK == 128 ? 9 : 8);
+    const uint32_t srow = U < 5 ? v_lshr<(U < 5 ? 12 + 4 * U - RSH : 0)>(symsA) : v_lshr<(U < 5 ? 0 : 4 * U - RSH)>(syms);
+    const uint32_t addr = v_bitop3<TT_OR_AND>(grp_addr, srow, rowmask);
+#pragma unroll
+    for (int w = 0; w <= NB; ++w)
+        raw[w] = *(lds_ptr)(uintptr_t)(addr + (uint32_t)w * (4u * BLOCK * 4u));
+}
+
+template <int NB, int BLOCK, int U>
+__device__ __forceinline__ void slide_column(uint32_t grp_addr, uint32_t syms, uint32_t symsA, uint32_t rowmask,
+                                             uint32_t s0, uint32_t (&raw)[NB + 1], uint32_t (&VP)[NB],
+                                             uint32_t (&VN)[NB], uint32_t& cnt)
+{
+    uint32_t nxt[NB + 1];
+    if (U < 7)
+        slide_load<NB, BLOCK, (U < 7 ? U + 1 : 0)>(grp_addr, syms, symsA, rowmask, nxt);
+    uint32_t eq[NB];
+#pragma unroll
+    for (int w = 0; w < NB; ++w)
+        eq[w] = __builtin_amdgcn_alignbit(raw[w + 1], raw[w], s0 + (uint32_t)U);
+    const uint32_t d0 = slide_core<NB>(eq, VP, VN);
+    cnt = v_add(cnt, v_lshr<31>(d0));
+    if (U < 7) {
+#pragma unroll
+        for (int w = 0; w <= NB; ++w)
+            raw[w] = nxt[w];
+    }
+}
+
+template <int NB, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void myers_band_kernel(
+    GenomeView g, ReadsView rv, const wamd_dist_task* __restrict__ tasks, uint32_t n, int last_symbol,
+    uint32_t max_text_len, wamd_dist_result* __restrict__ results, uint32_t* __restrict__ flags,
+    const uint32_t* __restrict__ only_deferred, uint32_t* __restrict__ deferred)
+{
+    // [NB rows of ones | the read's words32 dwords | one row of zeros][A,C,G,T][lane]
+    extern __shared__ uint32_t pm_band[];
+    constexpr uint32_t ROW = 4u * BLOCK;   // dwords per vector dword
+
+    if (only_deferred && *only_deferred == 0)
+        return;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t gid = blockIdx.x * BLOCK + tid;
+    bool valid = gid < n;
+    if (valid && only_deferred && results[gid].edit_distance != RESULT_DEFERRED)
+        valid = false;
+
+    Lane t{};
+    uint32_t read_idx = 0, ref_pos = 0;
+    if (valid) {
+        const wamd_dist_task task = tasks[gid];
+        const uint32_t err = decode_task(task, rv, g, max_text_len, 32u * rv.words32, t);
+        read_idx = task.read_idx;
+        ref_pos = task.ref_pos;
+        if (err) {
+            raise_flag(flags, err);
+            results[gid].edit_distance = RESULT_ERROR;
+            results[gid].pos = err;
+            valid = false;
+        }
+    }
+    if (!valid) {
+        t = Lane{};
+        t.m = 1;
+        ref_pos = 0;
+        read_idx = 0;
+    }
+    // no end column can come under k
+    if (valid && t.n_cols + t.k < t.m) {
+        results[gid].edit_distance = t.k + 1u;
+        results[gid].pos = 0;
+        valid = false;
+    }
+
+    // ---- does the lane fit the band, and where does the wave's fixed phase start ----------------
+    const uint32_t fm_own = t.n_cols + t.k > 32u * NB ? t.n_cols + t.k - 32u * NB : 0u;
+    const bool selffit = valid && t.k < t.m && fm_own + t.k + 2u <= t.m && t.m + t.n_cols < 32000u;
+    uint32_t FS = selffit ? fm_own : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        FS = max(FS, (uint32_t)__shfl_xor((int)FS, o));
+    FS = __builtin_amdgcn_readfirstlane((FS + 7u) & ~7u);
+    const uint64_t cand = __ballot(selffit);
+    const uint32_t rule0 = __builtin_amdgcn_readfirstlane(__shfl((int)t.rule, cand ? __ffsll((long long)cand) - 1 : 0));
+    const bool fit = selffit && t.rule == rule0 && FS + t.k + 2u <= t.m;
+    if (valid && !fit) {
+        results[gid].edit_distance = RESULT_DEFERRED;
+        results[gid].pos = 0;
+    }
+    {
+        const uint64_t left = __ballot(valid && !fit);
+        if (left && (tid & 63u) == 0)
+            atomicAdd(deferred, (uint32_t)__popcll(left));
+    }
+    valid = fit;
+    if (!__any(valid))   // wave-uniform; the block has no barriers
+        return;
+
+    // ---- rows -> LDS ----------------------------------------------------------------------------
+    const uint32_t W32 = rv.words32;
+    {
+        const uint32_t slot = valid ? (uint32_t)(t.rev ? rv.slot_rc : rv.slot_direct) : 0;
+        const uint32_t* src = rv.pm32 + ((uint64_t)read_idx * rv.n_orient + slot) * 4 * W32;
+        for (uint32_t d = 0; d < NB + W32 + 1; ++d) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                uint32_t v = d < (uint32_t)NB ? ~0u : 0u;
+                if (valid && d >= (uint32_t)NB && d < NB + W32)
+                    v = src[c * W32 + (d - NB)];
+                pm_band[(d * 4 + c) * BLOCK + tid] = v;
+            }
+        }
+        if (valid) {
+            const uint32_t meta = rv.meta[(uint64_t)read_idx * rv.n_orient + slot];
+            t.presence = meta & 0xffffu;
+            t.last_sym = last_symbol >= 0 ? (uint32_t)last_symbol : ((meta >> 16) & 15u);
+        }
+    }
     const uint8_t* my_codes = rv.codes + rv.code_off[read_idx];
 
-    // ---- text stream: R = nibble-swapped dwords of the current chunk (+1 for the funnel),
-    // NX = raw dwords of the next one, already in flight
-    bool packed = false;   // wave-uniform: which bookkeeping form is current
-    uint32_t E = 0, key = 0, deadf = 0;
-    uint32_t base = 0;     // columns done (wave-uniform)
-
-    const uint32_t shift = (ref_pos & 7u) * 4u;
-    uint32_t didx = ref_pos >> 3;
-    uint32_t R[TEXT_CHUNK + 1], NX[TEXT_CHUNK];
+    // frame of column f (0-based): bit b is read symbol f + Z0 + b; symbols < 0 are phantom rows
+    const int32_t Z0 = (int32_t)t.m - 32 * NB - (int32_t)FS;
+    uint32_t VP[NB], VN[NB];
 #pragma unroll
-    for (int c = 0; c <= TEXT_CHUNK; ++c)
-        R[c] = load_genome_dword(g, didx + c);
-    didx += TEXT_CHUNK + 1;
+    for (int w = 0; w < NB; ++w) {
+        const int32_t ph = -Z0 - 32 * w;   // phantom bits of this dword
+        VP[w] = ph <= 0 ? ~0u : (ph >= 32 ? 0u : ~((1u << ph) - 1u));
+        VN[w] = 0;
+    }
 
-    for (;;) {
-        // next chunk's loads go out before this chunk's columns
+    // ---- sliding phase: columns 1 .. FS ---------------------------------------------------------
+    uint32_t cnt = 0;   // D0 bits seen under the frame's bottom row
+    if (FS) {
+        const uint32_t rowmask = in_vgpr(3u << (BLOCK == 256 ? 10 : (BLOCK == 128 ? 9 : 8)));
+        const uint32_t lane_addr =
+            (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint32_t*)pm_band + tid * 4u;
+        const uint32_t shift = (ref_pos & 7u) * 4u;
+        uint32_t didx = ref_pos >> 3;
+        uint32_t R[TEXT_CHUNK + 1], NX[TEXT_CHUNK];
 #pragma unroll
-        for (int c = 0; c < TEXT_CHUNK; ++c) {
-            const uint32_t idx = didx + c;
-            NX[c] = g.dwords[idx < g.last_dword ? idx : g.last_dword];
-        }
-        didx += TEXT_CHUNK;
-
-        bool done = false;
-        for (int gi = 0; gi < TEXT_CHUNK; ++gi, base += 8) {
-            const bool alive = packed ? (int32_t)deadf >= 0 : !t.stopped;
-            if (!__any(alive)) {
-                done = true;
-                break;
+        for (int c = 0; c <= TEXT_CHUNK; ++c)
+            R[c] = load_genome_dword(g, didx + c);
+        didx += TEXT_CHUNK + 1;
+        for (uint32_t base = 0; base < FS;) {
+#pragma unroll
+            for (int c = 0; c < TEXT_CHUNK; ++c) {
+                const uint32_t idx = didx + c;
+                NX[c] = g.dwords[idx < g.last_dword ? idx : g.last_dword];
             }
-            const uint32_t syms = __builtin_amdgcn_alignbit(R[1], R[0], shift);
+            didx += TEXT_CHUNK;
+            for (int gi = 0; gi < TEXT_CHUNK && base < FS; ++gi, base += 8) {
+                const uint32_t syms = __builtin_amdgcn_alignbit(R[1], R[0], shift);
+#pragma unroll
+                for (int c = 0; c < TEXT_CHUNK; ++c)
+                    R[c] = R[c + 1];
+                // frame start in the LDS rows (NB dwords of ones in front): wave-uniform
+                const uint32_t q = 32u * W32 - FS + base;   // a multiple of 8
+                const uint32_t qi = q >> 5, s0 = q & 31u;
+                if (!__any(valid && (syms & 0xccccccccu))) {
+                    const uint32_t grp_addr = lane_addr + qi * (ROW * 4u);
+                    const uint32_t symsA = syms << 12;
+                    uint32_t raw[NB + 1];
+                    slide_load<NB, BLOCK, 0>(grp_addr, syms, symsA, rowmask, raw);
+                    slide_column<NB, BLOCK, 0>(grp_addr, syms, symsA, rowmask, s0, raw, VP, VN, cnt);
+                    slide_column<NB, BLOCK, 1>(grp_addr, syms, symsA, rowmask, s0, raw, VP, VN, cnt);
+                    slide_column<NB, BLOCK, 2>(grp_addr, syms, symsA, rowmask, s0, raw, VP, VN, cnt);
+                    slide_column<NB, BLOCK, 3>(grp_addr, syms, symsA, rowmask, s0, raw, VP, VN, cnt);
+                    slide_column<NB, BLOCK, 4>(grp_addr, syms, symsA, rowmask, s0, raw, VP, VN, cnt);
+                    slide_column<NB, BLOCK, 5>(grp_addr, syms, symsA, rowmask, s0, raw, VP, VN, cnt);
+                    slide_column<NB, BLOCK, 6>(grp_addr, syms, symsA, rowmask, s0, raw, VP, VN, cnt);
+                    slide_column<NB, BLOCK, 7>(grp_addr, syms, symsA, rowmask, s0, raw, VP, VN, cnt);
+                    continue;
+                }
+                // ---- a text symbol >= 4 somewhere in the wave: spelled out per lane -----------------
+#pragma unroll 1
+                for (uint32_t u = 0; u < 8; ++u) {
+                    const uint32_t f = base + u;
+                    const uint32_t c = (syms >> (4 * u)) & 15u;
+                    const int32_t first = (int32_t)f + Z0;   // read symbol under bit 0
+                    const bool exotic = valid && c >= 4u && ((t.presence >> c) & 1u);
+                    uint32_t eq[NB];
+#pragma unroll
+                    for (int w = 0; w < NB; ++w) {
+                        const uint32_t a0 = pm_band[((qi + w) * 4 + (c & 3u)) * BLOCK + tid];
+                        const uint32_t a1 = pm_band[((qi + w + 1) * 4 + (c & 3u)) * BLOCK + tid];
+                        uint32_t v = __builtin_amdgcn_alignbit(a1, a0, s0 + u);
+                        if (c >= 4u) {
+                            const int32_t ph = -first - 32 * w;   // phantom rows match everything
+                            v = ph <= 0 ? 0u : (ph >= 32 ? ~0u : ((1u << ph) - 1u));
+                            if (exotic) {
+                                for (int32_t b = 0; b < 32; ++b) {
+                                    const int32_t i = first + 32 * w + b;
+                                    if (i < 0 || i >= (int32_t)t.m)
+                                        continue;
+                                    const uint32_t rcode = t.rev ? rc_code(packed_symbol(my_codes, t.m - 1 - (uint32_t)i))
+                                                                 : packed_symbol(my_codes, (uint32_t)i);
+                                    v |= (uint32_t)(rcode == c) << b;
+                                }
+                            }
+                        }
+                        eq[w] = v;
+                    }
+                    cnt += slide_core<NB>(eq, VP, VN) >> 31;
+                }
+            }
 #pragma unroll
             for (int c = 0; c < TEXT_CHUNK; ++c)
-                R[c] = R[c + 1];
-
-            const bool fast = can_fast && !__any(alive && (syms & 0xccccccccu));
-            if (fast) {
-                if (!packed) {
-                    E = t.curr_ed + base;
-                    key = (t.min_ed << 17) | (0xffffu - t.min_pos);
-                    deadf = t.stopped ? 0x80000000u : 0u;
-                    packed = true;
-                }
-                const uint32_t n_left = t.n_cols - base;
-                const bool ends = __any(alive && n_left < 8u);
-#define WAMD_GROUP(RULE, ENDS)                                                                               \
-    group_fast<NW, BLOCK, RULE, ENDS>(lane_addr, syms, base, lsrep, t.exit_t, n_left, rowmask, sgn, bit16, VP, VN, \
-                                      E, key, deadf)
-                if (rule0 == RULE_M256) {
-                    if (ends)
-                        WAMD_GROUP(RULE_M256, true);
-                    else
-                        WAMD_GROUP(RULE_M256, false);
-                } else if (rule0 == RULE_M128) {
-                    if (ends)
-                        WAMD_GROUP(RULE_M128, true);
-                    else
-                        WAMD_GROUP(RULE_M128, false);
-                } else {
-                    if (ends)
-                        WAMD_GROUP(RULE_M64, true);
-                    else
-                        WAMD_GROUP(RULE_M64, false);
-                }
-#undef WAMD_GROUP
-                continue;
-            }
-
-            // ---- slow group: per-lane bookkeeping, any text symbol ----------------------------
-            if (packed) {
-                if (!t.stopped) {   // lanes that were finished when packing keep their values
-                    t.curr_ed = E - base;
-                    t.min_ed = key >> 17;
-                    t.min_pos = 0xffffu - (key & 0xffffu);
-                    t.stopped = (int32_t)deadf < 0;
-                }
-                packed = false;
-            }
-#pragma unroll 1
-            for (uint32_t u = 0; u < 8; ++u) {
-                const uint32_t col = base + u + 1;
-                const uint32_t c = (syms >> (4 * u)) & 15u;
-                const bool act = !t.stopped && col <= t.n_cols;
-                // a text symbol >= 4 matches only a read holding that very code, which real
-                // data never does (genome: 5/15, reads: 4/6); stay exact anyway
-                const bool exotic = act && c >= 4u && ((t.presence >> c) & 1u);
-                uint32_t eq[NW];
-#pragma unroll
-                for (int w = 0; w < NW; ++w) {
-                    uint32_t v = phantom_mask<NW>(t.m, w);
-                    if (c < 4u)
-                        v = pm_lds[(w * 4 + c) * BLOCK + tid];
-                    if (exotic) {
-                        const int32_t first = 32 * w - (int32_t)(32u * NW - t.m);
-                        for (int32_t b = 0; b < 32; ++b) {
-                            const int32_t i = first + b;
-                            if (i < 0 || i >= (int32_t)t.m)
-                                continue;
-                            const uint32_t rcode = t.rev ? rc_code(packed_symbol(my_codes, t.m - 1 - (uint32_t)i))
-                                                         : packed_symbol(my_codes, (uint32_t)i);
-                            v |= (uint32_t)(rcode == c) << b;
-                        }
-                    }
-                    eq[w] = v;
-                }
-                uint32_t hp, hn, d0;
-                column_core<NW>(eq, VP, VN, hp, hn, d0);
-
-                const uint32_t hnb = hn >> 31, hpb = hp >> 31, d0b = d0 >> 31;
-                const uint32_t ced = t.curr_ed + hpb - hnb;
-                const bool lt = ced < t.min_ed;
-                const bool tie = ced == t.min_ed;
-                const bool move = tie && (t.rule == RULE_M256 ? (!d0b || c == t.last_sym) : (t.min_pos + 1 == col));
-                if (act) {
-                    t.curr_ed = ced;
-                    if (lt)
-                        t.min_ed = ced;
-                    if (lt || move)
-                        t.min_pos = col;
-                    // early exit on the iteration index j = col + wn
-                    // (LevMyers256.hpp:232-233, LevMyers128.hpp:125, 219-220)
-                    if (t.rule != RULE_M64 && !hnb && ced + col > t.exit_t)
-                        t.stopped = true;
-                }
-                if (col >= t.n_cols)
-                    t.stopped = true;   // last column of this lane
-            }
+                R[c + 1] = nibble_swap(NX[c]);
         }
-        if (done)
-            break;
-        // rotate the prefetched chunk in: R[0] already holds the funnel's low dword
-#pragma unroll
-        for (int c = 0; c < TEXT_CHUNK; ++c)
-            R[c + 1] = nibble_swap(NX[c]);
     }
 
-    if (packed && !t.stopped) {   // t.stopped: as it was when the state was packed
-        t.min_ed = key >> 17;
-        t.min_pos = 0xffffu - (key & 0xffffu);
-    }
+    // ---- fixed phase ----------------------------------------------------------------------------
+    // bottom cell of column FS's frame (row m - 1) = (m - FS - 1) + FS - cnt; the row below it,
+    // row m, came in through VP's top bit
+    t.min_ed = t.m;
+    t.min_pos = 0;
+    t.curr_ed = FS ? t.m - 1u - cnt + (VP[NB - 1] >> 31) : t.m;
+    t.stopped = !valid;
+    const uint32_t hin = t.m > 32u * NB ? ~0u : 0u;
+    run_columns<NB, BLOCK, true>(g, t, valid, VP, VN, pm_band + W32 * ROW, tid, my_codes, ref_pos, FS, hin);
+
     if (valid) {
-        results[gid].edit_distance = t.min_ed;
+        results[gid].edit_distance = t.min_ed > t.k ? t.k + 1u : t.min_ed;
         results[gid].pos = t.min_ed > t.k ? 0u : t.min_pos;
     }
 }
@@ -577,28 +905,36 @@ __global__ __launch_bounds__(BLOCK) WAMD_KATTR void myers_distance_kernel(
 template <int NW, int BLOCK>
 static int launch_one(const GenomeView& g, const ReadsView& rv, const wamd_dist_task* d_tasks,
                       uint32_t n, int last_symbol, uint32_t max_text_len, wamd_dist_result* d_results,
-                      uint32_t* d_flags, hipStream_t s)
+                      uint32_t* d_flags, const uint32_t* only_deferred, int clamp, hipStream_t s)
 {
     const uint32_t blocks = (n + BLOCK - 1) / BLOCK;
     hipLaunchKernelGGL((myers_distance_kernel<NW, BLOCK>), dim3(blocks), dim3(BLOCK), 0, s, g, rv,
-                       d_tasks, n, last_symbol, max_text_len, d_results, d_flags);
+                       d_tasks, n, last_symbol, max_text_len, d_results, d_flags, only_deferred, clamp);
     WAMD_HIP(hipGetLastError());
     return WAMD_OK;
 }
 
-int launch_distance(wamd_ctx* ctx, const wamd_reads* r, const wamd_dist_task* d_tasks, uint32_t n,
-                    int last_symbol, wamd_dist_result* d_results, hipStream_t s)
+template <int NB>
+static int launch_band(const GenomeView& g, const ReadsView& rv, const wamd_dist_task* d_tasks, uint32_t n,
+                       int last_symbol, uint32_t max_text_len, wamd_dist_result* d_results, uint32_t* d_flags,
+                       const uint32_t* only_deferred, uint32_t* deferred, hipStream_t s)
 {
-    WAMD_HIP(hipSetDevice(ctx->device));
-    if (n == 0)
-        return WAMD_OK;
-    const GenomeView g = genome_view(ctx);
-    const ReadsView rv = r->view();
-    const uint32_t mt = ctx->max_text_len;
-    uint32_t* f = ctx->d_flags;
+    constexpr int BLOCK = 256;
+    const uint32_t blocks = (n + BLOCK - 1) / BLOCK;
+    const size_t lds = (size_t)(NB + rv.words32 + 1) * 4 * BLOCK * sizeof(uint32_t);
+    hipLaunchKernelGGL((myers_band_kernel<NB, BLOCK>), dim3(blocks), dim3(BLOCK), lds, s, g, rv, d_tasks, n,
+                       last_symbol, max_text_len, d_results, d_flags, only_deferred, deferred);
+    WAMD_HIP(hipGetLastError());
+    return WAMD_OK;
+}
+
+static int launch_exact(const GenomeView& g, const ReadsView& rv, const wamd_dist_task* d_tasks, uint32_t n,
+                        int last_symbol, uint32_t mt, wamd_dist_result* d_results, uint32_t* f,
+                        const uint32_t* only_deferred, int clamp, hipStream_t s)
+{
 #define WAMD_DIST_CASE(NW, BLOCK) \
     if (rv.words32 <= NW)         \
-        return launch_one<NW, BLOCK>(g, rv, d_tasks, n, last_symbol, mt, d_results, f, s);
+        return launch_one<NW, BLOCK>(g, rv, d_tasks, n, last_symbol, mt, d_results, f, only_deferred, clamp, s);
     WAMD_DIST_CASE(1, 256)
     WAMD_DIST_CASE(2, 256)
     WAMD_DIST_CASE(3, 256)
@@ -615,6 +951,37 @@ int launch_distance(wamd_ctx* ctx, const wamd_reads* r, const wamd_dist_task* d_
 #undef WAMD_DIST_CASE
     set_error("reads of %u dwords are not supported", rv.words32);
     return WAMD_ERR_TOO_LONG;
+}
+
+int launch_distance(wamd_ctx* ctx, const wamd_reads* r, const wamd_dist_task* d_tasks, uint32_t n,
+                    int last_symbol, wamd_dist_result* d_results, int mode, hipStream_t s)
+{
+    WAMD_HIP(hipSetDevice(ctx->device));
+    if (n == 0)
+        return WAMD_OK;
+    const GenomeView g = genome_view(ctx);
+    const ReadsView rv = r->view();
+    const uint32_t mt = ctx->max_text_len;
+    uint32_t* f = ctx->d_flags;
+    // the LDS rows of the banded kernels must fit a block: (NB + words32 + 1) x 4 KB <= 64 KB
+    if (mode != WAMD_DISTANCE_ACCEPTED_ONLY || rv.words32 <= 2 || rv.words32 > 11)
+        return launch_exact(g, rv, d_tasks, n, last_symbol, mt, d_results, f, nullptr,
+                            mode == WAMD_DISTANCE_ACCEPTED_ONLY, s);
+    // 64-row band, then 96 rows for what did not fit, then whole columns
+    uint32_t* cnt2 = f + 1;
+    uint32_t* cnt3 = f + 2;
+    WAMD_HIP(hipMemsetAsync(cnt2, 0, 2 * sizeof(uint32_t), s));
+    int rc = launch_band<2>(g, rv, d_tasks, n, last_symbol, mt, d_results, f, nullptr, cnt2, s);
+    if (rc != WAMD_OK)
+        return rc;
+    const uint32_t* last = cnt2;
+    if (rv.words32 > 3) {
+        rc = launch_band<3>(g, rv, d_tasks, n, last_symbol, mt, d_results, f, cnt2, cnt3, s);
+        if (rc != WAMD_OK)
+            return rc;
+        last = cnt3;
+    }
+    return launch_exact(g, rv, d_tasks, n, last_symbol, mt, d_results, f, last, 1, s);
 }
 
 } // namespace wamd

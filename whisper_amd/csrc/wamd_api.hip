@@ -284,6 +284,14 @@ int wamd_ctx_set_max_text_len(wamd_ctx* ctx, uint32_t max_text_len)
     return WAMD_OK;
 }
 
+int wamd_ctx_set_distance_mode(wamd_ctx* ctx, int mode)
+{
+    if (!ctx || (mode != WAMD_DISTANCE_EXACT && mode != WAMD_DISTANCE_ACCEPTED_ONLY))
+        return WAMD_ERR_INVALID_ARG;
+    ctx->distance_mode = mode;
+    return WAMD_OK;
+}
+
 int wamd_ctx_set_reference_params(wamd_ctx* ctx, uint32_t ref_size, uint32_t cur_offset)
 {
     if (!ctx)
@@ -447,7 +455,7 @@ int wamd_verify_distance_dev(wamd_ctx* ctx, const wamd_reads* reads, const wamd_
         return rc;
     if (last_symbol < -1 || last_symbol > 15)
         return WAMD_ERR_INVALID_ARG;
-    return launch_distance(ctx, reads, d_tasks, n, last_symbol, d_results,
+    return launch_distance(ctx, reads, d_tasks, n, last_symbol, d_results, ctx->distance_mode,
                            stream ? (hipStream_t)stream : ctx->stream);
 }
 

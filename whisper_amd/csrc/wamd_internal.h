@@ -68,8 +68,9 @@ struct wamd_ctx {
     uint32_t ref_size;
     uint32_t cur_offset;
     uint32_t max_text_len;
+    int distance_mode;          // WAMD_DISTANCE_*
     wamd_scoring scoring;
-    uint32_t* d_flags;          // device error flags
+    uint32_t* d_flags;          // device error flags; [1], [2]: deferred-task counts of the banded kernels
     uint32_t* h_flags;          // pinned mirror
     // staging for the host-pointer entry points (grown on demand)
     void* d_stage;
@@ -115,7 +116,7 @@ int flags_to_status(uint32_t flags);
 int launch_reads_prepare(wamd_ctx* ctx, wamd_reads* r, const uint8_t* d_raw,
                          const uint64_t* d_raw_off, hipStream_t s);
 int launch_distance(wamd_ctx* ctx, const wamd_reads* r, const wamd_dist_task* d_tasks, uint32_t n,
-                    int last_symbol, wamd_dist_result* d_results, hipStream_t s);
+                    int last_symbol, wamd_dist_result* d_results, int mode, hipStream_t s);
 int launch_levdiag(wamd_ctx* ctx, const wamd_reads* r, const wamd_levdiag_task* d_tasks,
                    uint32_t n, uint32_t* d_results, hipStream_t s);
 int launch_align(wamd_ctx* ctx, const wamd_reads* r, const wamd_dist_task* d_tasks, uint32_t n,
