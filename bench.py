@@ -165,6 +165,11 @@ def run_extras(ctx, device, genome_symbols, stream, n_small):
     ms = timed(lambda: ctx.dynamic_programming_dev(reads, d_t, n, d_r, last_symbol=-1))
     out["S5_distance_250bp"] = {"shape": "LevMyers256 distance m=250 k=17 W=284", "tasks": n, "kernel_ms": ms,
                                 "candidates_per_s": n / ms * 1e3}
+    ctx.set_distance_mode(api.DISTANCE_ACCEPTED_ONLY)
+    ms = timed(lambda: ctx.dynamic_programming_dev(reads, d_t, n, d_r, last_symbol=-1))
+    ctx.set_distance_mode(api.DISTANCE_EXACT)
+    out["S5_accepted_only"] = {"shape": "S5 in WAMD_DISTANCE_ACCEPTED_ONLY mode (96-row band)", "tasks": n,
+                               "kernel_ms": ms, "candidates_per_s": n / ms * 1e3}
     reads.free()
     del d_t, d_r
 
@@ -269,6 +274,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary shapes (S2, S4, S5, S8)")
     ap.add_argument("--extras-tasks", type=int, default=1 << 22)
+    ap.add_argument("--distance-mode", choices=("exact", "accepted-only"), default="exact",
+                    help="what the timed step reports for rejected candidates (experiments / profiling; "
+                         "the headline is measured in the default, exact mode)")
     ap.add_argument("--true-frac", type=float, default=0.5,
                     help="fraction of candidates planted at their locus (S1 = 0.5; other values are experiments)")
     args = ap.parse_args()
@@ -296,6 +304,8 @@ def main():
                                                               seed=1234 + rank, true_frac=args.true_frac)
     ctx = api.Context(packed, ref_size=ref_size, cur_offset=0, device=local)   # genome borrowed on device
     ctx.set_max_text_len(M + 2 * K_ERR + 2)   # mapping_core.cpp:158-160
+    if args.distance_mode != "exact":
+        ctx.set_distance_mode(api.DISTANCE_ACCEPTED_ONLY)
     reads = ctx.upload_reads(blob, off, lens, api.READS_NIBBLE, orientations=3)
     d_tasks = torch.from_numpy(tasks.view(np.uint8)).to(device)
     d_results = torch.zeros(n * 2, dtype=torch.int32, device=device)
@@ -375,6 +385,29 @@ def main():
     res = d_results.view(n, 2).cpu().numpy()
     accepted = int((res[:, 0] <= K_ERR).sum())
 
+    # the same step in accepted-only mode (banded kernels): accepted candidates must come back
+    # identical, the others as {k + 1, 0}
+    banded = None
+    if rank == 0 and not args.no_extras and args.distance_mode == "exact":
+        ctx.set_distance_mode(api.DISTANCE_ACCEPTED_ONLY)
+        verify()
+        ctx.synchronize()
+        bev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+        for a, b in bev:
+            a.record(stream)
+            verify()
+            b.record(stream)
+        ctx.synchronize()
+        ctx.set_distance_mode(api.DISTANCE_EXACT)
+        bres = d_results.view(n, 2).cpu().numpy()
+        rej = res[:, 0] > K_ERR
+        same = bool((bres[~rej] == res[~rej]).all() and (bres[rej, 0] == K_ERR + 1).all() and (bres[rej, 1] == 0).all())
+        bms = float(np.mean([a.elapsed_time(b) for a, b in bev]))
+        banded = {"shape": "S1 in WAMD_DISTANCE_ACCEPTED_ONLY mode: 64-row band, %d sliding + %d fixed columns"
+                           % ((N_COLS + K_ERR - 64 + 7) // 8 * 8, N_COLS - (N_COLS + K_ERR - 64 + 7) // 8 * 8),
+                  "tasks": n, "kernel_ms": bms, "candidates_per_s": n / bms * 1e3,
+                  "accepted_identical_rejected_clamped": same}
+
     if rank == 0:
         value = n * world * args.steps / dt
         out = {
@@ -396,6 +429,7 @@ def main():
                             "%d-symbol random genome with N runs, %d%% true candidates with 0..15 edits, "
                             "50%% reverse strand" % (n, args.genome_symbols, round(100 * args.true_frac)),
                 "candidates_per_gpu": n,
+                "distance_mode": args.distance_mode,
                 "accepted_fraction": accepted / n,
                 "parallelism": "bins sharded over %d GPU(s), no data-path collective; "
                                "accepted records gathered to rank 0 over RCCL" % world,
@@ -440,6 +474,7 @@ def main():
             reads = None
             torch.cuda.empty_cache()
             out["extras"] = run_extras(ctx, device, args.genome_symbols, stream, args.extras_tasks)
+            out["extras"]["S1_accepted_only"] = banded
         print(json.dumps(out))
     if dist:
         dist.barrier()

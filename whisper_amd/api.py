@@ -21,6 +21,7 @@ VARIANT_AUTO, VARIANT_M64, VARIANT_M128, VARIANT_M256 = 0, 1, 2, 3
 READS_NIBBLE, READS_ASCII = 0, 1
 FLAG_REV_COMP = 1
 LAST_SYMBOL_FROM_READ = -1
+DISTANCE_EXACT, DISTANCE_ACCEPTED_ONLY = 0, 1
 
 DIST_TASK = np.dtype([("read_idx", "<u4"), ("ref_pos", "<u4"), ("max_distance_in_ref", "<u4"),
                       ("max_ed", "<u2"), ("variant", "u1"), ("flags", "u1")])

@@ -348,7 +348,7 @@ __global__ __launch_bounds__(BLOCK) void align_traceback_kernel(GenomeView g, Re
                 const uint32_t o = (uint32_t)zq & 31u;
                 auto pext = [&](int c, int32_t k) -> uint32_t {
                     const int32_t kc = k < 0 ? 0 : (k >= (int32_t)rv.words32 ? (int32_t)rv.words32 - 1 : k);
-                    const uint32_t v = src[c * rv.words32 + kc];   // 80 B per read and strand: cached after the first touch
+                    const uint32_t v = src[kc * 4 + c];   // 80 B per read and strand: cached after the first touch
                     return k < 0 ? ~0u : (k >= (int32_t)rv.words32 ? 0u : v);
                 };
 #pragma unroll

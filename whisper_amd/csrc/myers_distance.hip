@@ -326,6 +326,34 @@ __device__ __forceinline__ uint32_t decode_task(const wamd_dist_task& task, cons
     return 0;
 }
 
+static_assert(TEXT_CHUNK == 8, "the text stream fetches two 16-byte pieces per chunk");
+// first TEXT_CHUNK + 1 dwords of a lane's text, nibble-swapped
+__device__ __forceinline__ void load_text_first(const GenomeView& g, uint32_t didx, uint32_t (&R)[TEXT_CHUNK + 1])
+{
+    uint32_t a[4], b[4];
+    load_genome_raw4(g, didx, a);
+    load_genome_raw4(g, didx + 4, b);
+    const uint32_t last = g.dwords[didx + 8 < g.last_dword ? didx + 8 : g.last_dword];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        R[c] = nibble_swap(a[c]);
+        R[4 + c] = nibble_swap(b[c]);
+    }
+    R[8] = nibble_swap(last);
+}
+// the next TEXT_CHUNK raw dwords
+__device__ __forceinline__ void load_text_chunk(const GenomeView& g, uint32_t didx, uint32_t (&NX)[TEXT_CHUNK])
+{
+    uint32_t a[4], b[4];
+    load_genome_raw4(g, didx, a);
+    load_genome_raw4(g, didx + 4, b);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        NX[c] = a[c];
+        NX[4 + c] = b[c];
+    }
+}
+
 // ---- the column loop: columns base0 + 1 .. n_cols of every lane, bookkeeping in `t` -----------
 // pm_lds: this block's pattern-match rows [NW dwords][A,C,G,T][BLOCK lanes] (the banded kernel
 // passes the top NW dwords of longer vectors); VP / VN: the state before column base0 + 1;
@@ -363,18 +391,13 @@ __device__ __forceinline__ void run_columns(const GenomeView& g, Lane& t, const 
     const uint32_t shift = (ref_pos & 7u) * 4u;
     uint32_t didx = (ref_pos >> 3) + (base0 >> 3);
     uint32_t R[TEXT_CHUNK + 1], NX[TEXT_CHUNK];
-#pragma unroll
-    for (int c = 0; c <= TEXT_CHUNK; ++c)
-        R[c] = load_genome_dword(g, didx + c);
+    load_text_first(g, didx, R);
     didx += TEXT_CHUNK + 1;
 
     for (;;) {
-        // next chunk's loads go out before this chunk's columns
-#pragma unroll
-        for (int c = 0; c < TEXT_CHUNK; ++c) {
-            const uint32_t idx = didx + c;
-            NX[c] = g.dwords[idx < g.last_dword ? idx : g.last_dword];
-        }
+        // next chunk's loads go out before this chunk's columns - when a lane has columns there
+        if (__any(valid && t.n_cols > base + 8u * TEXT_CHUNK))
+            load_text_chunk(g, didx, NX);
         didx += TEXT_CHUNK;
 
         bool done = false;
@@ -545,16 +568,16 @@ __global__ __launch_bounds__(BLOCK) WAMD_KATTR void myers_distance_kernel(
     {
         const uint32_t slot = valid ? (uint32_t)(t.rev ? rv.slot_rc : rv.slot_direct) : 0;
         const uint32_t pad = NW - rv.words32;   // launcher: NW >= words32
-        const uint32_t* src = rv.pm32 + ((uint64_t)read_idx * rv.n_orient + slot) * 4 * rv.words32;
+        const uint4* src = reinterpret_cast<const uint4*>(rv.pm32) + ((uint64_t)read_idx * rv.n_orient + slot) * rv.words32;
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                uint32_t v = ~0u;   // dwords below the batch's own vectors: phantom rows
-                if (valid && (uint32_t)j >= pad)
-                    v = src[c * rv.words32 + ((uint32_t)j - pad)];
-                pm_lds[(j * 4 + c) * BLOCK + tid] = v;
-            }
+            uint4 v = make_uint4(~0u, ~0u, ~0u, ~0u);   // dwords below the batch's own vectors: phantom rows
+            if (valid && (uint32_t)j >= pad)
+                v = src[(uint32_t)j - pad];              // A, C, G, T rows of this dword: one 16-byte load
+            pm_lds[(j * 4 + 0) * BLOCK + tid] = v.x;
+            pm_lds[(j * 4 + 1) * BLOCK + tid] = v.y;
+            pm_lds[(j * 4 + 2) * BLOCK + tid] = v.z;
+            pm_lds[(j * 4 + 3) * BLOCK + tid] = v.w;
             VP[j] = ~phantom_mask<NW>(t.m, j);
             VN[j] = 0;
         }
@@ -710,7 +733,7 @@ __global__ __launch_bounds__(BLOCK) void myers_band_kernel(
     uint32_t max_text_len, wamd_dist_result* __restrict__ results, uint32_t* __restrict__ flags,
     const uint32_t* __restrict__ only_deferred, uint32_t* __restrict__ deferred)
 {
-    // [NB rows of ones | the read's words32 dwords | one row of zeros][A,C,G,T][lane]
+    // [NB rows of ones | the read's words32 dwords][A,C,G,T][lane]
     extern __shared__ uint32_t pm_band[];
     constexpr uint32_t ROW = 4u * BLOCK;   // dwords per vector dword
 
@@ -777,15 +800,15 @@ __global__ __launch_bounds__(BLOCK) void myers_band_kernel(
     const uint32_t W32 = rv.words32;
     {
         const uint32_t slot = valid ? (uint32_t)(t.rev ? rv.slot_rc : rv.slot_direct) : 0;
-        const uint32_t* src = rv.pm32 + ((uint64_t)read_idx * rv.n_orient + slot) * 4 * W32;
-        for (uint32_t d = 0; d < NB + W32 + 1; ++d) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                uint32_t v = d < (uint32_t)NB ? ~0u : 0u;
-                if (valid && d >= (uint32_t)NB && d < NB + W32)
-                    v = src[c * W32 + (d - NB)];
-                pm_band[(d * 4 + c) * BLOCK + tid] = v;
-            }
+        const uint4* src = reinterpret_cast<const uint4*>(rv.pm32) + ((uint64_t)read_idx * rv.n_orient + slot) * W32;
+        for (uint32_t d = 0; d < NB + W32; ++d) {
+            uint4 v = make_uint4(~0u, ~0u, ~0u, ~0u);
+            if (valid && d >= (uint32_t)NB)
+                v = src[d - NB];
+            pm_band[(d * 4 + 0) * BLOCK + tid] = v.x;
+            pm_band[(d * 4 + 1) * BLOCK + tid] = v.y;
+            pm_band[(d * 4 + 2) * BLOCK + tid] = v.z;
+            pm_band[(d * 4 + 3) * BLOCK + tid] = v.w;
         }
         if (valid) {
             const uint32_t meta = rv.meta[(uint64_t)read_idx * rv.n_orient + slot];
@@ -814,16 +837,11 @@ __global__ __launch_bounds__(BLOCK) void myers_band_kernel(
         const uint32_t shift = (ref_pos & 7u) * 4u;
         uint32_t didx = ref_pos >> 3;
         uint32_t R[TEXT_CHUNK + 1], NX[TEXT_CHUNK];
-#pragma unroll
-        for (int c = 0; c <= TEXT_CHUNK; ++c)
-            R[c] = load_genome_dword(g, didx + c);
+        load_text_first(g, didx, R);
         didx += TEXT_CHUNK + 1;
         for (uint32_t base = 0; base < FS;) {
-#pragma unroll
-            for (int c = 0; c < TEXT_CHUNK; ++c) {
-                const uint32_t idx = didx + c;
-                NX[c] = g.dwords[idx < g.last_dword ? idx : g.last_dword];
-            }
+            if (base + 8u * TEXT_CHUNK < FS)   // another chunk of sliding columns follows
+                load_text_chunk(g, didx, NX);
             didx += TEXT_CHUNK;
             for (int gi = 0; gi < TEXT_CHUNK && base < FS; ++gi, base += 8) {
                 const uint32_t syms = __builtin_amdgcn_alignbit(R[1], R[0], shift);
@@ -919,9 +937,12 @@ static int launch_band(const GenomeView& g, const ReadsView& rv, const wamd_dist
                        int last_symbol, uint32_t max_text_len, wamd_dist_result* d_results, uint32_t* d_flags,
                        const uint32_t* only_deferred, uint32_t* deferred, hipStream_t s)
 {
-    constexpr int BLOCK = 256;
+#ifndef WAMD_BAND_BLOCK
+#define WAMD_BAND_BLOCK 128
+#endif
+    constexpr int BLOCK = WAMD_BAND_BLOCK;   // small blocks: the LDS rows are what limits the waves per CU
     const uint32_t blocks = (n + BLOCK - 1) / BLOCK;
-    const size_t lds = (size_t)(NB + rv.words32 + 1) * 4 * BLOCK * sizeof(uint32_t);
+    const size_t lds = (size_t)(NB + rv.words32) * 4 * BLOCK * sizeof(uint32_t);
     hipLaunchKernelGGL((myers_band_kernel<NB, BLOCK>), dim3(blocks), dim3(BLOCK), lds, s, g, rv, d_tasks, n,
                        last_symbol, max_text_len, d_results, d_flags, only_deferred, deferred);
     WAMD_HIP(hipGetLastError());
@@ -963,8 +984,8 @@ int launch_distance(wamd_ctx* ctx, const wamd_reads* r, const wamd_dist_task* d_
     const ReadsView rv = r->view();
     const uint32_t mt = ctx->max_text_len;
     uint32_t* f = ctx->d_flags;
-    // the LDS rows of the banded kernels must fit a block: (NB + words32 + 1) x 4 KB <= 64 KB
-    if (mode != WAMD_DISTANCE_ACCEPTED_ONLY || rv.words32 <= 2 || rv.words32 > 11)
+    // the LDS rows of the banded kernels must fit a block: (NB + words32) x 2 KB <= 64 KB
+    if (mode != WAMD_DISTANCE_ACCEPTED_ONLY || rv.words32 <= 2 || rv.words32 > 28)
         return launch_exact(g, rv, d_tasks, n, last_symbol, mt, d_results, f, nullptr,
                             mode == WAMD_DISTANCE_ACCEPTED_ONLY, s);
     // 64-row band, then 96 rows for what did not fit, then whole columns

@@ -154,9 +154,9 @@ __global__ __launch_bounds__(256) void pattern_vectors32_kernel(ReadsView rv, ui
             row[3] |= (i < 0 || c == 3) ? bit : 0;
         }
     }
-    uint32_t* dst = pm32 + ((uint64_t)(read * (uint64_t)rv.n_orient + slot) * 4) * rv.words32 + j;
-    for (int c = 0; c < 4; ++c)
-        dst[(uint64_t)c * rv.words32] = row[c];
+    // [dword][A,C,G,T]: the verification kernels fetch a dword of all four rows with one 16-byte load
+    uint4* dst = reinterpret_cast<uint4*>(pm32) + (uint64_t)(read * (uint64_t)rv.n_orient + slot) * rv.words32 + j;
+    *dst = make_uint4(row[0], row[1], row[2], row[3]);
 }
 
 int launch_reads_prepare(wamd_ctx* ctx, wamd_reads* r, const uint8_t* d_raw,
