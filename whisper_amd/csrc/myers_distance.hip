@@ -691,9 +691,10 @@ __device__ __forceinline__ uint32_t slide_core(const uint32_t (&eq)[NB], uint32_
     return d0[NB - 1];
 }
 
-// pattern-match bits of the frame for symbol U of the group: NB + 1 dwords from row idx on,
-// funnelled by the wave-uniform shift
-template <int NB, int BLOCK, int U>
+// pattern-match bits of the frame for symbol U of the group: NB + 1 dwords, funnelled by the
+// wave-uniform shift.  The first Z of them lie below the vector's dword 0 - phantom rows, all
+// ones - and are not fetched; the others come from rows 0.. of grp_addr.
+template <int NB, int BLOCK, int U, int Z>
 __device__ __forceinline__ void slide_load(uint32_t grp_addr, uint32_t syms, uint32_t symsA, uint32_t rowmask,
                                            uint32_t (&raw)[NB + 1])
 {
@@ -703,21 +704,21 @@ __device__ __forceinline__ void slide_load(uint32_t grp_addr, uint32_t syms, uin
     const uint32_t addr = v_bitop3<TT_OR_AND>(grp_addr, srow, rowmask);
 #pragma unroll
     for (int w = 0; w <= NB; ++w)
-        raw[w] = *(lds_ptr)(uintptr_t)(addr + (uint32_t)w * (4u * BLOCK * 4u));
+        raw[w] = w < Z ? ~0u : *(lds_ptr)(uintptr_t)(addr + (uint32_t)(w < Z ? 0 : w - Z) * (4u * BLOCK * 4u));
 }
 
-template <int NB, int BLOCK, int U>
+template <int NB, int BLOCK, int U, int Z>
 __device__ __forceinline__ void slide_column(uint32_t grp_addr, uint32_t syms, uint32_t symsA, uint32_t rowmask,
                                              uint32_t s0, uint32_t (&raw)[NB + 1], uint32_t (&VP)[NB],
                                              uint32_t (&VN)[NB], uint32_t& cnt)
 {
     uint32_t nxt[NB + 1];
     if (U < 7)
-        slide_load<NB, BLOCK, (U < 7 ? U + 1 : 0)>(grp_addr, syms, symsA, rowmask, nxt);
+        slide_load<NB, BLOCK, (U < 7 ? U + 1 : 0), Z>(grp_addr, syms, symsA, rowmask, nxt);
     uint32_t eq[NB];
 #pragma unroll
     for (int w = 0; w < NB; ++w)
-        eq[w] = __builtin_amdgcn_alignbit(raw[w + 1], raw[w], s0 + (uint32_t)U);
+        eq[w] = w + 1 < Z ? ~0u : __builtin_amdgcn_alignbit(raw[w + 1], raw[w], s0 + (uint32_t)U);
     const uint32_t d0 = slide_core<NB>(eq, VP, VN);
     cnt = v_add(cnt, v_lshr<31>(d0));
     if (U < 7) {
@@ -727,13 +728,30 @@ __device__ __forceinline__ void slide_column(uint32_t grp_addr, uint32_t syms, u
     }
 }
 
+template <int NB, int BLOCK, int Z>
+__device__ __forceinline__ void slide_group(uint32_t grp_addr, uint32_t syms, uint32_t rowmask, uint32_t s0,
+                                            uint32_t (&VP)[NB], uint32_t (&VN)[NB], uint32_t& cnt)
+{
+    const uint32_t symsA = syms << 12;
+    uint32_t raw[NB + 1];
+    slide_load<NB, BLOCK, 0, Z>(grp_addr, syms, symsA, rowmask, raw);
+    slide_column<NB, BLOCK, 0, Z>(grp_addr, syms, symsA, rowmask, s0, raw, VP, VN, cnt);
+    slide_column<NB, BLOCK, 1, Z>(grp_addr, syms, symsA, rowmask, s0, raw, VP, VN, cnt);
+    slide_column<NB, BLOCK, 2, Z>(grp_addr, syms, symsA, rowmask, s0, raw, VP, VN, cnt);
+    slide_column<NB, BLOCK, 3, Z>(grp_addr, syms, symsA, rowmask, s0, raw, VP, VN, cnt);
+    slide_column<NB, BLOCK, 4, Z>(grp_addr, syms, symsA, rowmask, s0, raw, VP, VN, cnt);
+    slide_column<NB, BLOCK, 5, Z>(grp_addr, syms, symsA, rowmask, s0, raw, VP, VN, cnt);
+    slide_column<NB, BLOCK, 6, Z>(grp_addr, syms, symsA, rowmask, s0, raw, VP, VN, cnt);
+    slide_column<NB, BLOCK, 7, Z>(grp_addr, syms, symsA, rowmask, s0, raw, VP, VN, cnt);
+}
+
 template <int NB, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void myers_band_kernel(
     GenomeView g, ReadsView rv, const wamd_dist_task* __restrict__ tasks, uint32_t n, int last_symbol,
     uint32_t max_text_len, wamd_dist_result* __restrict__ results, uint32_t* __restrict__ flags,
     const uint32_t* __restrict__ only_deferred, uint32_t* __restrict__ deferred)
 {
-    // [NB rows of ones | the read's words32 dwords][A,C,G,T][lane]
+    // [the read's words32 dwords][A,C,G,T][lane], as in the exact kernel
     extern __shared__ uint32_t pm_band[];
     constexpr uint32_t ROW = 4u * BLOCK;   // dwords per vector dword
 
@@ -788,9 +806,11 @@ __global__ __launch_bounds__(BLOCK) void myers_band_kernel(
         results[gid].pos = 0;
     }
     {
+        // the next kernel only asks "any?": one flag, written by the waves that still read 0
+        // (an atomic per wave on one address would serialise the whole launch)
         const uint64_t left = __ballot(valid && !fit);
-        if (left && (tid & 63u) == 0)
-            atomicAdd(deferred, (uint32_t)__popcll(left));
+        if (left && (tid & 63u) == 0 && *reinterpret_cast<volatile uint32_t*>(deferred) == 0)
+            *reinterpret_cast<volatile uint32_t*>(deferred) = 1u;
     }
     valid = fit;
     if (!__any(valid))   // wave-uniform; the block has no barriers
@@ -801,10 +821,10 @@ __global__ __launch_bounds__(BLOCK) void myers_band_kernel(
     {
         const uint32_t slot = valid ? (uint32_t)(t.rev ? rv.slot_rc : rv.slot_direct) : 0;
         const uint4* src = reinterpret_cast<const uint4*>(rv.pm32) + ((uint64_t)read_idx * rv.n_orient + slot) * W32;
-        for (uint32_t d = 0; d < NB + W32; ++d) {
+        for (uint32_t d = 0; d < W32; ++d) {
             uint4 v = make_uint4(~0u, ~0u, ~0u, ~0u);
-            if (valid && d >= (uint32_t)NB)
-                v = src[d - NB];
+            if (valid)
+                v = src[d];
             pm_band[(d * 4 + 0) * BLOCK + tid] = v.x;
             pm_band[(d * 4 + 1) * BLOCK + tid] = v.y;
             pm_band[(d * 4 + 2) * BLOCK + tid] = v.z;
@@ -848,22 +868,22 @@ __global__ __launch_bounds__(BLOCK) void myers_band_kernel(
 #pragma unroll
                 for (int c = 0; c < TEXT_CHUNK; ++c)
                     R[c] = R[c + 1];
-                // frame start in the LDS rows (NB dwords of ones in front): wave-uniform
-                const uint32_t q = 32u * W32 - FS + base;   // a multiple of 8
-                const uint32_t qi = q >> 5, s0 = q & 31u;
+                // frame start as a bit offset into the vector (negative: still among the phantom rows
+                // below its dword 0): wave-uniform, a multiple of 8
+                const int32_t q = (int32_t)(32u * (W32 - NB)) - (int32_t)FS + (int32_t)base;
+                const int32_t qi = q >> 5;
+                const uint32_t s0 = (uint32_t)q & 31u;
                 if (!__any(valid && (syms & 0xccccccccu))) {
-                    const uint32_t grp_addr = lane_addr + qi * (ROW * 4u);
-                    const uint32_t symsA = syms << 12;
-                    uint32_t raw[NB + 1];
-                    slide_load<NB, BLOCK, 0>(grp_addr, syms, symsA, rowmask, raw);
-                    slide_column<NB, BLOCK, 0>(grp_addr, syms, symsA, rowmask, s0, raw, VP, VN, cnt);
-                    slide_column<NB, BLOCK, 1>(grp_addr, syms, symsA, rowmask, s0, raw, VP, VN, cnt);
-                    slide_column<NB, BLOCK, 2>(grp_addr, syms, symsA, rowmask, s0, raw, VP, VN, cnt);
-                    slide_column<NB, BLOCK, 3>(grp_addr, syms, symsA, rowmask, s0, raw, VP, VN, cnt);
-                    slide_column<NB, BLOCK, 4>(grp_addr, syms, symsA, rowmask, s0, raw, VP, VN, cnt);
-                    slide_column<NB, BLOCK, 5>(grp_addr, syms, symsA, rowmask, s0, raw, VP, VN, cnt);
-                    slide_column<NB, BLOCK, 6>(grp_addr, syms, symsA, rowmask, s0, raw, VP, VN, cnt);
-                    slide_column<NB, BLOCK, 7>(grp_addr, syms, symsA, rowmask, s0, raw, VP, VN, cnt);
+                    const uint32_t grp_addr = lane_addr + (uint32_t)(qi < 0 ? 0 : qi) * (ROW * 4u);
+                    const int z = qi < 0 ? -qi : 0;   // dwords of the frame that lie below dword 0
+                    if (z == 0)
+                        slide_group<NB, BLOCK, 0>(grp_addr, syms, rowmask, s0, VP, VN, cnt);
+                    else if (z == 1)
+                        slide_group<NB, BLOCK, 1>(grp_addr, syms, rowmask, s0, VP, VN, cnt);
+                    else if (z == 2 || NB < 3)
+                        slide_group<NB, BLOCK, 2>(grp_addr, syms, rowmask, s0, VP, VN, cnt);
+                    else
+                        slide_group<NB, BLOCK, (NB < 3 ? 2 : 3)>(grp_addr, syms, rowmask, s0, VP, VN, cnt);
                     continue;
                 }
                 // ---- a text symbol >= 4 somewhere in the wave: spelled out per lane -----------------
@@ -876,8 +896,9 @@ __global__ __launch_bounds__(BLOCK) void myers_band_kernel(
                     uint32_t eq[NB];
 #pragma unroll
                     for (int w = 0; w < NB; ++w) {
-                        const uint32_t a0 = pm_band[((qi + w) * 4 + (c & 3u)) * BLOCK + tid];
-                        const uint32_t a1 = pm_band[((qi + w + 1) * 4 + (c & 3u)) * BLOCK + tid];
+                        const int32_t r0 = qi + w, r1 = qi + w + 1;
+                        const uint32_t a0 = r0 < 0 ? ~0u : pm_band[((uint32_t)r0 * 4 + (c & 3u)) * BLOCK + tid];
+                        const uint32_t a1 = r1 < 0 ? ~0u : pm_band[((uint32_t)r1 * 4 + (c & 3u)) * BLOCK + tid];
                         uint32_t v = __builtin_amdgcn_alignbit(a1, a0, s0 + u);
                         if (c >= 4u) {
                             const int32_t ph = -first - 32 * w;   // phantom rows match everything
@@ -912,7 +933,7 @@ __global__ __launch_bounds__(BLOCK) void myers_band_kernel(
     t.curr_ed = FS ? t.m - 1u - cnt + (VP[NB - 1] >> 31) : t.m;
     t.stopped = !valid;
     const uint32_t hin = t.m > 32u * NB ? ~0u : 0u;
-    run_columns<NB, BLOCK, true>(g, t, valid, VP, VN, pm_band + W32 * ROW, tid, my_codes, ref_pos, FS, hin);
+    run_columns<NB, BLOCK, true>(g, t, valid, VP, VN, pm_band + (W32 - NB) * ROW, tid, my_codes, ref_pos, FS, hin);
 
     if (valid) {
         results[gid].edit_distance = t.min_ed > t.k ? t.k + 1u : t.min_ed;
@@ -942,7 +963,7 @@ static int launch_band(const GenomeView& g, const ReadsView& rv, const wamd_dist
 #endif
     constexpr int BLOCK = WAMD_BAND_BLOCK;   // small blocks: the LDS rows are what limits the waves per CU
     const uint32_t blocks = (n + BLOCK - 1) / BLOCK;
-    const size_t lds = (size_t)(NB + rv.words32) * 4 * BLOCK * sizeof(uint32_t);
+    const size_t lds = (size_t)rv.words32 * 4 * BLOCK * sizeof(uint32_t);
     hipLaunchKernelGGL((myers_band_kernel<NB, BLOCK>), dim3(blocks), dim3(BLOCK), lds, s, g, rv, d_tasks, n,
                        last_symbol, max_text_len, d_results, d_flags, only_deferred, deferred);
     WAMD_HIP(hipGetLastError());
@@ -984,8 +1005,8 @@ int launch_distance(wamd_ctx* ctx, const wamd_reads* r, const wamd_dist_task* d_
     const ReadsView rv = r->view();
     const uint32_t mt = ctx->max_text_len;
     uint32_t* f = ctx->d_flags;
-    // the LDS rows of the banded kernels must fit a block: (NB + words32) x 2 KB <= 64 KB
-    if (mode != WAMD_DISTANCE_ACCEPTED_ONLY || rv.words32 <= 2 || rv.words32 > 28)
+    // the LDS rows of the banded kernels must fit a block: words32 x 2 KB <= 64 KB
+    if (mode != WAMD_DISTANCE_ACCEPTED_ONLY || rv.words32 <= 2 || rv.words32 > 32)
         return launch_exact(g, rv, d_tasks, n, last_symbol, mt, d_results, f, nullptr,
                             mode == WAMD_DISTANCE_ACCEPTED_ONLY, s);
     // 64-row band, then 96 rows for what did not fit, then whole columns
