@@ -48,8 +48,9 @@ __device__ __forceinline__ uint32_t range_flags(int32_t lo, int32_t hi, int32_t 
 
 // Adds to cnt the pairs starting in [lo1, hi1) or [lo2, hi2) (symbol indices into `seq`,
 // a packed 4-bit sequence read as dwords 0 .. last_dw).
-template <class Load>
-__device__ __forceinline__ void count_pairs(Load load, int32_t lo1, int32_t hi1, int32_t lo2, int32_t hi2,
+// load(d): dword d; load4(d, out): dwords d .. d + 3 with one 16-byte load.
+template <class Load, class Load4>
+__device__ __forceinline__ void count_pairs(Load load, Load4 load4, int32_t lo1, int32_t hi1, int32_t lo2, int32_t hi2,
                                             uint32_t (&cnt)[16])
 {
     const bool r1 = lo1 < hi1, r2 = lo2 < hi2;   // the caller guarantees at least one
@@ -57,12 +58,10 @@ __device__ __forceinline__ void count_pairs(Load load, int32_t lo1, int32_t hi1,
     const int32_t hi = r1 && r2 ? max(hi1, hi2) : (r1 ? hi1 : hi2);
     const int32_t first = lo >> 3, last = (hi - 1) >> 3;
     Classes cur = classify(load(first));
-    // four dwords per round trip: the loads of a batch are independent of each other
+    // four dwords per round trip, fetched by one 16-byte load
     for (int32_t d0 = first; d0 <= last; d0 += 4) {
         uint32_t raw[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            raw[q] = load(d0 + 1 + q);
+        load4(d0 + 1, raw);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int32_t d = d0 + q;
@@ -128,14 +127,28 @@ __global__ __launch_bounds__(256) void cf_filter_kernel(GenomeView g, ReadsView 
             const int32_t w0 = (int32_t)(left_end & 7u);   // count from the dword the window starts in
             const uint32_t d0 = left_end >> 3;
             auto load = [&](int32_t d) -> uint32_t { return load_genome_dword(g, d0 + (uint32_t)d); };
-            count_pairs(load, w0 + p_lo1, w0 + p_hi1, w0 + p_lo2, w0 + p_hi2, cg);
+            auto load4 = [&](int32_t d, uint32_t (&out)[4]) {
+                load_genome_raw4(g, d0 + (uint32_t)d, out);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    out[q] = nibble_swap(out[q]);
+            };
+            count_pairs(load, load4, w0 + p_lo1, w0 + p_hi1, w0 + p_lo2, w0 + p_hi2, cg);
         }
         const uint32_t* codes = reinterpret_cast<const uint32_t*>(rv.codes + rv.code_off[t.read_idx]);
         const int32_t last_dw = (int32_t)((m + 7) / 8) - 1;
         auto load = [&](int32_t d) -> uint32_t { return d <= last_dw ? nibble_swap(codes[d]) : 0xffffffffu; };
+        // the codes buffer has 64 bytes of slack behind the last read
+        auto load4 = [&](int32_t d, uint32_t (&out)[4]) {
+            const wamd_u32x4 v = d <= last_dw ? *reinterpret_cast<const wamd_u32x4_a4*>(codes + d) : wamd_u32x4{0, 0, 0, 0};
+            const uint32_t b[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                out[q] = d + q <= last_dw ? nibble_swap(b[q]) : 0xffffffffu;
+        };
         if (!(t.flags & WAMD_TASK_FLAG_REV_COMP)) {
             const int32_t w0 = (int32_t)t.read_offset;
-            count_pairs(load, w0 + p_lo1, w0 + p_hi1, w0 + p_lo2, w0 + p_hi2, cr);
+            count_pairs(load, load4, w0 + p_lo1, w0 + p_hi1, w0 + p_lo2, w0 + p_hi2, cr);
         } else {
             // oriented pair start i sits at stored pair start m - 2 - i
             const int32_t e = (int32_t)m - 1 - (int32_t)t.read_offset;   // one past the stored start of oriented pair 0
@@ -143,7 +156,7 @@ __global__ __launch_bounds__(256) void cf_filter_kernel(GenomeView g, ReadsView 
 #pragma unroll
             for (int i = 0; i < 16; ++i)
                 tmp[i] = 0;
-            count_pairs(load, e - p_hi1, e - p_lo1, e - p_hi2, e - p_lo2, tmp);
+            count_pairs(load, load4, e - p_hi1, e - p_lo1, e - p_hi2, e - p_lo2, tmp);
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll

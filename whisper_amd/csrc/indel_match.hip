@@ -206,21 +206,41 @@ __global__ __launch_bounds__(64) void indel_match_kernel(const uint8_t* __restri
         const uint32_t n_gd = (text_size + 2 + 7) / 8 + 1;
         const uint32_t gk = (uint32_t)(s.g0 >> 3), gsh = 4u * ((uint32_t)s.g0 & 7u);
         const uint32_t last_gd = (uint32_t)((genome_symbols - 1) >> 3);
+        // 16-byte loads: a wave's load costs the 64 cache lines it touches, whatever its width
         uint32_t lo = nibble_swap(gd[gk]);
-        for (uint32_t d = 0; d < n_gd; ++d) {
+        for (uint32_t d = 0; d < n_gd; d += 4) {
             const uint32_t k = gk + d + 1;
-            const uint32_t hi = nibble_swap(gd[k < last_gd ? k : last_gd]);
-            lg[d * 64] = __builtin_amdgcn_alignbit(hi, lo, gsh);
-            lo = hi;
+            uint32_t b[4];
+            if (k + 3u <= last_gd) {
+                const wamd_u32x4 v = *reinterpret_cast<const wamd_u32x4_a4*>(gd + k);
+                b[0] = v.x, b[1] = v.y, b[2] = v.z, b[3] = v.w;
+            } else {
+#pragma unroll
+                for (uint32_t c = 0; c < 4; ++c)
+                    b[c] = gd[k + c < last_gd ? k + c : last_gd];
+            }
+#pragma unroll
+            for (uint32_t c = 0; c < 4; ++c) {
+                if (d + c < n_gd) {
+                    const uint32_t hi = nibble_swap(b[c]);
+                    lg[(d + c) * 64] = __builtin_amdgcn_alignbit(hi, lo, gsh);
+                    lo = hi;
+                }
+            }
         }
         // oriented read; nibbles past its end are 15
         const uint32_t* cd = reinterpret_cast<const uint32_t*>(s.codes);
         const uint32_t n_qd = (query_len + 7) / 8;
+        uint32_t fwd[4] = {0, 0, 0, 0};
         for (uint32_t d = 0; d <= n_qd; ++d) {
             uint32_t w = 0xffffffffu;
             if (d < n_qd) {
                 if (!s.rev) {
-                    w = nibble_swap(cd[d]);
+                    if ((d & 3u) == 0) {   // the codes buffer has 64 bytes of slack behind the last read
+                        const wamd_u32x4 v = *reinterpret_cast<const wamd_u32x4_a4*>(cd + d);
+                        fwd[0] = v.x, fwd[1] = v.y, fwd[2] = v.z, fwd[3] = v.w;
+                    }
+                    w = nibble_swap((d & 3u) == 0 ? fwd[0] : ((d & 3u) == 1 ? fwd[1] : ((d & 3u) == 2 ? fwd[2] : fwd[3])));
                 } else {   // oriented symbol p = rc(stored symbol m - 1 - p)
                     w = 0;
                     for (uint32_t z = 0; z < 8; ++z) {

@@ -159,26 +159,40 @@ __global__ __launch_bounds__(BLOCK) void levdiag_kernel(GenomeView g, ReadsView 
     uint32_t* pat = pat_lds + tid;
     uint32_t* gen = gen_lds + tid;
     {
+        // 16-byte loads: what a wave's load costs is the 64 cache lines it touches, not its width
+        // (the codes buffer has 64 bytes of slack behind the last read)
         const uint32_t* src = reinterpret_cast<const uint32_t*>(rv.codes + rv.code_off[read_idx]);
         const uint32_t pd = valid ? (m + 7) / 8 : 0;
         pat[0] = 0;
-#pragma unroll 4
-        for (int j = 1; j < PW; ++j)
-            pat[j * BLOCK] = (uint32_t)(j - 1) < pd ? nibble_swap(src[j - 1]) : 0xffffffffu;
+#pragma unroll
+        for (int j4 = 0; j4 < PW - 1; j4 += 4) {
+            wamd_u32x4 v = {0, 0, 0, 0};
+            if ((uint32_t)j4 < pd)
+                v = *reinterpret_cast<const wamd_u32x4_a4*>(src + j4);
+            const uint32_t b[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (j4 + c + 1 < PW)
+                    pat[(j4 + c + 1) * BLOCK] = (uint32_t)(j4 + c) < pd ? nibble_swap(b[c]) : 0xffffffffu;
+        }
         const uint32_t shift = (g0 & 7u) * 4u;
         const uint32_t d0 = g0 >> 3;
         const uint32_t gd = valid ? (m + 2 * k + 1 + 7) / 8 : 0;
         gen[0] = 0;
         uint32_t lo = load_genome_dword(g, d0);
-#pragma unroll 4
-        for (int j = 1; j < GW; ++j) {
-            uint32_t v = 0;
-            if ((uint32_t)(j - 1) < gd) {
-                const uint32_t hi = load_genome_dword(g, d0 + (uint32_t)j);
-                v = __builtin_amdgcn_alignbit(hi, lo, shift);
-                lo = hi;
+#pragma unroll
+        for (int j4 = 0; j4 < GW - 1; j4 += 4) {
+            uint32_t b[4] = {0, 0, 0, 0};
+            if ((uint32_t)j4 < gd)
+                load_genome_raw4(g, d0 + 1u + (uint32_t)j4, b);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (j4 + c + 1 < GW) {
+                    const uint32_t hi = nibble_swap(b[c]);
+                    gen[(j4 + c + 1) * BLOCK] = (uint32_t)(j4 + c) < gd ? __builtin_amdgcn_alignbit(hi, lo, shift) : 0u;
+                    lo = hi;
+                }
             }
-            gen[j * BLOCK] = v;
         }
     }
 

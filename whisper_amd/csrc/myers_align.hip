@@ -346,19 +346,27 @@ __global__ __launch_bounds__(BLOCK) void align_traceback_kernel(GenomeView g, Re
                 const int32_t zq = Zf + (int32_t)(32u * rv.words32 - m);   // bit of the pm32 row under x = 0
                 const int32_t k0 = zq >> 5;                                // floor
                 const uint32_t o = (uint32_t)zq & 31u;
-                auto pext = [&](int c, int32_t k) -> uint32_t {
+                // dword k of all four rows: one 16-byte load (pm32 is dword-major)
+                auto pext4 = [&](int32_t k, uint32_t (&out)[4]) {
                     const int32_t kc = k < 0 ? 0 : (k >= (int32_t)rv.words32 ? (int32_t)rv.words32 - 1 : k);
-                    const uint32_t v = src[kc * 4 + c];   // 80 B per read and strand: cached after the first touch
-                    return k < 0 ? ~0u : (k >= (int32_t)rv.words32 ? 0u : v);
+                    const uint4 v = reinterpret_cast<const uint4*>(src)[kc];
+                    const uint32_t fill = k < 0 ? ~0u : 0u;
+                    const bool inside = k >= 0 && k < (int32_t)rv.words32;
+                    out[0] = inside ? v.x : fill;
+                    out[1] = inside ? v.y : fill;
+                    out[2] = inside ? v.z : fill;
+                    out[3] = inside ? v.w : fill;
                 };
+                uint32_t lo[4];
+                pext4(k0, lo);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    uint32_t lo = pext(c, k0);
+                for (int d = 0; d < SD; ++d) {
+                    uint32_t hi[4];
+                    pext4(k0 + d + 1, hi);
 #pragma unroll
-                    for (int d = 0; d < SD; ++d) {
-                        const uint32_t hi = pext(c, k0 + d + 1);
-                        S[(c * SD + d) * BLOCK] = valid ? __builtin_amdgcn_alignbit(hi, lo, o) : 0u;
-                        lo = hi;
+                    for (int c = 0; c < 4; ++c) {
+                        S[(c * SD + d) * BLOCK] = valid ? __builtin_amdgcn_alignbit(hi[c], lo[c], o) : 0u;
+                        lo[c] = hi[c];
                     }
                 }
             }
