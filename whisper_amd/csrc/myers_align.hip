@@ -256,12 +256,21 @@ __global__ __launch_bounds__(BLOCK) void align_traceback_kernel(GenomeView g, Re
         auto low_ones = [](int32_t nbits) -> uint64_t {   // ones in bits 0 .. nbits-1
             return nbits <= 0 ? 0ull : (nbits >= 64 ? ~0ull : ((1ull << nbits) - 1ull));
         };
-        // genome symbols under iterations fb .. fb + 7 (fb a multiple of 8)
-        auto band_syms = [&](uint32_t fb) -> uint32_t {
-            int64_t x = (int64_t)ref_pos + (int64_t)s_col - 1 - (int64_t)(F - n_cols) + (int64_t)fb;
-            x = x < 0 ? 0 : x;   // iterations before the lane's first column: any symbol will do
-            const uint32_t d0 = load_genome_dword(g, (uint32_t)(x >> 3)), d1 = load_genome_dword(g, (uint32_t)(x >> 3) + 1);
-            return __builtin_amdgcn_alignbit(d1, d0, 4u * ((uint32_t)x & 7u));
+        // Genome symbols under iterations fb .. fb + 7 (fb a multiple of 8) are the funnel of text
+        // dwords tx_i0 + fb / 8 and the next one.  Iterations before the lane's first column may lie
+        // before the genome's first symbol: any symbol will do there (dwords < 0 read as 0).
+        const int64_t tx0 = (int64_t)ref_pos + (int64_t)s_col - 1 - (int64_t)(F - n_cols);
+        const int32_t tx_i0 = (int32_t)(tx0 >> 3);
+        const uint32_t tx_sh = 4u * ((uint32_t)tx0 & 7u);
+        auto text_dword = [&](int32_t i) -> uint32_t { return i < 0 ? 0u : load_genome_dword(g, (uint32_t)i); };
+        auto text_raw4 = [&](int32_t i, uint32_t (&out)[4]) {   // raw dwords i .. i + 3
+            if (i >= 0) {
+                load_genome_raw4(g, (uint32_t)i, out);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    out[c] = i + c < 0 ? 0u : g.dwords[(uint32_t)(i + c) < g.last_dword ? (uint32_t)(i + c) : g.last_dword];
+            }
         };
         // one banded column: updates VPb / VNb, returns the four decision windows of the column
         auto band_col = [&](uint32_t f, uint32_t c, uint32_t (&win)[4]) {
@@ -372,15 +381,26 @@ __global__ __launch_bounds__(BLOCK) void align_traceback_kernel(GenomeView g, Re
             }
             VPb = ~low_ones(-(Zf + (int32_t)delay));   // column s_col - 1: D = row, phantom rows flat
             VNb = 0;
-            for (uint32_t fb = 0; fb < F; fb += 8) {
-                uint64_t* ck = mat + ((uint64_t)(fb / 8) * 2) * BLOCK + tid;
-                ck[0] = VPb;
-                ck[BLOCK] = VNb;
-                const uint32_t syms = band_syms(fb);
+            uint32_t t_lo = text_dword(tx_i0);
+            for (uint32_t fb4 = 0; fb4 < F; fb4 += 32) {   // four text dwords per 16-byte load
+                uint32_t raw[4];
+                text_raw4(tx_i0 + 1 + (int32_t)(fb4 >> 3), raw);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    uint32_t win[4];
-                    band_col(fb + u, (syms >> (4 * u)) & 15u, win);
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t fb = fb4 + 8u * q;
+                    if (fb < F) {
+                        uint64_t* ck = mat + ((uint64_t)(fb / 8) * 2) * BLOCK + tid;
+                        ck[0] = VPb;
+                        ck[BLOCK] = VNb;
+                        const uint32_t t_hi = nibble_swap(raw[q]);
+                        const uint32_t syms = __builtin_amdgcn_alignbit(t_hi, t_lo, tx_sh);
+                        t_lo = t_hi;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            uint32_t win[4];
+                            band_col(fb + u, (syms >> (4 * u)) & 15u, win);
+                        }
+                    }
                 }
             }
         } else {
@@ -601,15 +621,31 @@ __global__ __launch_bounds__(BLOCK) void align_traceback_kernel(GenomeView g, Re
         int32_t gd_n = valid ? (int32_t)((((int64_t)ref_pos + end_pos - 1) >> 3) - g_origin + 1) : 1;
         gd_n = gd_n > GD ? GD : (gd_n < 1 ? 1 : gd_n);
         if constexpr (PHASE != 1) {
+            // 16-byte loads (a wave's load costs the 64 cache lines it touches, whatever its width);
+            // the codes buffer has 64 bytes of slack behind the last read
             const uint32_t* src = reinterpret_cast<const uint32_t*>(my_codes);
-#pragma unroll 4
-            for (int d = 0; d < RD; ++d)
-                if (d < rd_n)
-                    st_read[d * BLOCK] = nibble_swap(src[d]);
-#pragma unroll 4
-            for (int d = 0; d < GD; ++d)
-                if (d < gd_n)
-                    st_gen[d * BLOCK] = load_genome_dword(g, (uint32_t)(g_origin + d));
+#pragma unroll
+            for (int d4 = 0; d4 < RD; d4 += 4) {
+                if (d4 < rd_n) {
+                    const wamd_u32x4 v = *reinterpret_cast<const wamd_u32x4_a4*>(src + d4);
+                    const uint32_t b[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (d4 + c < RD && d4 + c < rd_n)
+                            st_read[(d4 + c) * BLOCK] = nibble_swap(b[c]);
+                }
+            }
+#pragma unroll
+            for (int d4 = 0; d4 < GD; d4 += 4) {
+                if (d4 < gd_n) {
+                    uint32_t b[4];
+                    load_genome_raw4(g, (uint32_t)(g_origin + d4), b);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (d4 + c < GD && d4 + c < gd_n)
+                            st_gen[(d4 + c) * BLOCK] = nibble_swap(b[c]);
+                }
+            }
         }
         // symbol s of a staged sequence (branch-free: the walk fetches both symbols every step)
         auto staged_sym = [&](const uint32_t* base, uint32_t origin_dw, int32_t n_dw, uint32_t idx) -> uint32_t {
@@ -711,14 +747,20 @@ __global__ __launch_bounds__(BLOCK) void align_traceback_kernel(GenomeView g, Re
                 };
                 uint64_t nvp, nvn;
                 ck_load(0, nvp, nvn);
-                uint32_t nsyms = band_syms(F - 8);
+                // text dwords right to left: the low dword of a group is the high one of the next
+                uint32_t t_lo = text_dword(tx_i0 + (int32_t)n_chunks - 1);
+                uint32_t nsyms = __builtin_amdgcn_alignbit(text_dword(tx_i0 + (int32_t)n_chunks), t_lo, tx_sh);
                 for (uint32_t q = 0; q < n_chunks && __any(read_pos && pos); ++q) {
                     const uint32_t fb = F - 8 * (q + 1);
                     VPb = nvp;
                     VNb = nvn;
                     const uint32_t syms = nsyms;
                     ck_load(q + 1, nvp, nvn);
-                    nsyms = band_syms(fb >= 8 ? fb - 8 : 0u);
+                    {
+                        const uint32_t t_hi = t_lo;
+                        t_lo = text_dword(tx_i0 + (int32_t)(fb >> 3) - 1);
+                        nsyms = __builtin_amdgcn_alignbit(t_hi, t_lo, tx_sh);
+                    }
                     uint32_t D[8][4];
 #pragma unroll
                     for (int u = 0; u < 8; ++u)
