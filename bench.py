@@ -388,7 +388,7 @@ def main():
     # the same step in accepted-only mode (banded kernels): accepted candidates must come back
     # identical, the others as {k + 1, 0}
     banded = None
-    if rank == 0 and not args.no_extras and args.distance_mode == "exact":
+    if rank == 0 and world == 1 and not args.no_extras and args.distance_mode == "exact":
         ctx.set_distance_mode(api.DISTANCE_ACCEPTED_ONLY)
         verify()
         ctx.synchronize()
@@ -407,6 +407,12 @@ def main():
                            % ((N_COLS + K_ERR - 64 + 7) // 8 * 8, N_COLS - (N_COLS + K_ERR - 64 + 7) // 8 * 8),
                   "tasks": n, "kernel_ms": bms, "candidates_per_s": n / bms * 1e3,
                   "accepted_identical_rejected_clamped": same}
+        # algorithmic VALU work of the banded kernel: 2 dwords x 9 + 6 per sliding column,
+        # 2 x 10 + 24 per fixed column
+        fs = (N_COLS + K_ERR - 64 + 7) // 8 * 8
+        b_ops = n * (fs * 24 + (N_COLS - fs) * 44) / (bms * 1e-3)
+        banded["roofline"] = {"bound": "valu", "achieved": b_ops / 1e12, "peak": PEAK_VALU_LANEOPS / 1e12,
+                              "unit": "T lane-op/s (32-bit integer VALU)", "frac": b_ops / PEAK_VALU_LANEOPS}
 
     if rank == 0:
         value = n * world * args.steps / dt

@@ -444,3 +444,57 @@ def test_emit_lev_records(ctx, oracle):
     np.testing.assert_array_equal(rec[:, :4].copy().view("<u4")[:, 0], tasks["read_idx"][ok])
     np.testing.assert_array_equal(rec[:, 4:9], wire[:, :5])
     assert (rec[:, 9:] == 0).all()
+
+
+def test_windows_at_the_genome_ends(oracle):
+    """Windows that start in the genome's first dword or end in its last one (a genome without
+    the N borders): distance in both modes and align; the clamped loads at either end and the
+    first group of the band must see the right symbols."""
+    import torch
+    from whisper_amd import synth
+    g = torch.Generator().manual_seed(5)
+    G = 4096 + 6
+    codes = torch.randint(0, 4, (G,), generator=g, dtype=torch.uint8)
+    packed = synth.pack_nibbles(codes).numpy()
+    m, k = 150, 12
+    starts = list(range(0, 20)) + list(range(G - m - 2 * k - 1 - 20, G - m - 2 * k - 1))
+    reads_codes, tasks = [], []
+    for rep in range(8):
+        for i, s0 in enumerate(starts):
+            W = m + 2 * k
+            p = s0 + int(torch.randint(0, 2 * k, (1,), generator=g))
+            p = min(p, G - m)
+            r = codes[p:p + m].clone()
+            for _ in range(int(torch.randint(0, 6, (1,), generator=g))):
+                x = int(torch.randint(0, m, (1,), generator=g))
+                r[x] = (int(r[x]) + 1) & 3
+            reads_codes.append(r)
+            tasks.append((len(tasks), s0, W, k, 0, 0))
+    tasks = np.array(tasks, api.DIST_TASK)
+    c = api.Context(packed, ref_size=G, cur_offset=0)
+    try:
+        for enc in (0, 1):
+            blob, off, lens = common.mixed_reads(reads_codes, enc)
+            last = 0 if enc else -1
+            rc, want = oracle.distance(packed, blob, off, lens, enc, tasks, last)
+            assert rc == 0 and (want["edit_distance"] <= k).sum() > 100
+            reads = c.upload_reads(blob, off, lens, enc)
+            np.testing.assert_array_equal(c.dynamic_programming(reads, tasks, last), want)
+            c.set_distance_mode(api.DISTANCE_ACCEPTED_ONLY)
+            got = c.dynamic_programming(reads, tasks, last)
+            c.set_distance_mode(api.DISTANCE_EXACT)
+            rej = want["edit_distance"] > k
+            np.testing.assert_array_equal(got[~rej], want[~rej])
+            assert (got["edit_distance"][rej] == k + 1).all() and (got["pos"][rej] == 0).all()
+            if enc:
+                rc, wa, wcig = oracle.align(packed, blob, off, lens, 1, tasks, 0, 1, cigar_stride=512)
+                assert rc == 0
+                ga, gcig = c.align(reads, tasks, 0, 1, cigar_stride=512)
+                for f in wa.dtype.names:
+                    np.testing.assert_array_equal(ga[f], wa[f], err_msg=f)
+                for i in np.nonzero(wa["ok"])[0]:
+                    n = wa["cigar_len"][i]
+                    assert bytes(gcig[i, :n + 1]) == bytes(wcig[i, :n + 1]), i
+            reads.free()
+    finally:
+        c.destroy()
