@@ -169,3 +169,36 @@ def test_mode_switch_and_errors(ctx, oracle):
     with pytest.raises(api.WamdError):
         ctx.set_distance_mode(7)
     reads.free()
+
+
+def test_accepted_only_on_several_streams(ctx, oracle):
+    """Launches on different streams of one context overlap: each stream has its own pair of
+    deferral flags, so a batch that defers everything (rescue windows) next to one that defers
+    nothing must not disturb it.  More streams than flag pairs fall back to the flag-less chain."""
+    dev = torch.device("cuda", 0)
+    shapes = [(150, 12, None), (150, 26, 660), (250, 17, None)]
+    work = []
+    for i, (m, k, W) in enumerate(shapes):
+        codes, packed, (blob, off, lens), tasks = common.distance_workload(m, k, 20000, seed=900 + i, W=W)
+        rc, want = oracle.distance(packed, blob, off, lens, 0, tasks, -1)
+        assert rc == 0
+        reads = ctx.upload_reads(blob, off, lens, 0)
+        d_t = torch.from_numpy(tasks.view(np.uint8)).to(dev)
+        work.append((reads, d_t, len(tasks), clamp(want, tasks["max_ed"])))
+    streams = [torch.cuda.Stream(device=dev) for _ in range(20)]
+    outs = []
+    for rep in range(2):
+        for si, st in enumerate(streams):
+            reads, d_t, n, want = work[si % len(work)]
+            outs.append((torch.full((n * 2,), -1, dtype=torch.int32, device=dev), want, st, work[si % len(work)]))
+    torch.cuda.synchronize()   # the fills above run on torch's stream
+    for d_r, want, st, (reads, d_t, n, _) in outs:
+        ctx.dynamic_programming_dev(reads, d_t, n, d_r, last_symbol=-1, stream=st.cuda_stream)
+    torch.cuda.synchronize()
+    assert ctx.take_flags() == 0
+    for d_r, want, _, _ in outs:
+        got = d_r.cpu().numpy().view(np.uint32).reshape(-1, 2)
+        np.testing.assert_array_equal(got[:, 0], want["edit_distance"])
+        np.testing.assert_array_equal(got[:, 1], want["pos"])
+    for reads, _, _, _ in work:
+        reads.free()

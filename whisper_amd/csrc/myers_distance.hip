@@ -522,14 +522,15 @@ __device__ __forceinline__ void run_columns(const GenomeView& g, Lane& t, const 
 #ifndef WAMD_KATTR
 #define WAMD_KATTR
 #endif
-// `only_deferred`: the launch finishes what the banded kernels left (results marked
-// RESULT_DEFERRED); a zero count ends every block at once.  `clamp`: accepted-only mode,
-// distances above k are reported as k + 1.
+// `chained`: the launch finishes what the banded kernels left (results marked RESULT_DEFERRED);
+// `only_deferred`, when given, is the flag the previous kernel of the chain raised if it left
+// anything: zero ends every block at once.  `clamp`: accepted-only mode, distances above k are
+// reported as k + 1.
 template <int NW, int BLOCK>
 __global__ __launch_bounds__(BLOCK) WAMD_KATTR void myers_distance_kernel(
     GenomeView g, ReadsView rv, const wamd_dist_task* __restrict__ tasks, uint32_t n,
     int last_symbol, uint32_t max_text_len, wamd_dist_result* __restrict__ results,
-    uint32_t* __restrict__ flags, const uint32_t* __restrict__ only_deferred, int clamp)
+    uint32_t* __restrict__ flags, int chained, const uint32_t* __restrict__ only_deferred, int clamp)
 {
     // [dword][symbol A,C,G,T][lane]
     __shared__ uint32_t pm_lds[NW * 4 * BLOCK];
@@ -539,8 +540,10 @@ __global__ __launch_bounds__(BLOCK) WAMD_KATTR void myers_distance_kernel(
     const uint32_t tid = threadIdx.x;
     const uint32_t gid = blockIdx.x * BLOCK + tid;
     bool valid = gid < n;
-    if (valid && only_deferred && results[gid].edit_distance != RESULT_DEFERRED)
+    if (valid && chained && results[gid].edit_distance != RESULT_DEFERRED)
         valid = false;
+    if (chained && !__any(valid))   // wave-uniform; the block has no barriers
+        return;
 
     Lane t{};
     uint32_t read_idx = 0, ref_pos = 0;
@@ -749,7 +752,7 @@ template <int NB, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void myers_band_kernel(
     GenomeView g, ReadsView rv, const wamd_dist_task* __restrict__ tasks, uint32_t n, int last_symbol,
     uint32_t max_text_len, wamd_dist_result* __restrict__ results, uint32_t* __restrict__ flags,
-    const uint32_t* __restrict__ only_deferred, uint32_t* __restrict__ deferred)
+    int chained, const uint32_t* __restrict__ only_deferred, uint32_t* __restrict__ deferred)
 {
     // [the read's words32 dwords][A,C,G,T][lane], as in the exact kernel
     extern __shared__ uint32_t pm_band[];
@@ -760,8 +763,10 @@ __global__ __launch_bounds__(BLOCK) void myers_band_kernel(
     const uint32_t tid = threadIdx.x;
     const uint32_t gid = blockIdx.x * BLOCK + tid;
     bool valid = gid < n;
-    if (valid && only_deferred && results[gid].edit_distance != RESULT_DEFERRED)
+    if (valid && chained && results[gid].edit_distance != RESULT_DEFERRED)
         valid = false;
+    if (chained && !__any(valid))
+        return;
 
     Lane t{};
     uint32_t read_idx = 0, ref_pos = 0;
@@ -809,7 +814,7 @@ __global__ __launch_bounds__(BLOCK) void myers_band_kernel(
         // the next kernel only asks "any?": one flag, written by the waves that still read 0
         // (an atomic per wave on one address would serialise the whole launch)
         const uint64_t left = __ballot(valid && !fit);
-        if (left && (tid & 63u) == 0 && *reinterpret_cast<volatile uint32_t*>(deferred) == 0)
+        if (deferred && left && (tid & 63u) == 0 && *reinterpret_cast<volatile uint32_t*>(deferred) == 0)
             *reinterpret_cast<volatile uint32_t*>(deferred) = 1u;
     }
     valid = fit;
@@ -944,11 +949,11 @@ __global__ __launch_bounds__(BLOCK) void myers_band_kernel(
 template <int NW, int BLOCK>
 static int launch_one(const GenomeView& g, const ReadsView& rv, const wamd_dist_task* d_tasks,
                       uint32_t n, int last_symbol, uint32_t max_text_len, wamd_dist_result* d_results,
-                      uint32_t* d_flags, const uint32_t* only_deferred, int clamp, hipStream_t s)
+                      uint32_t* d_flags, int chained, const uint32_t* only_deferred, int clamp, hipStream_t s)
 {
     const uint32_t blocks = (n + BLOCK - 1) / BLOCK;
     hipLaunchKernelGGL((myers_distance_kernel<NW, BLOCK>), dim3(blocks), dim3(BLOCK), 0, s, g, rv,
-                       d_tasks, n, last_symbol, max_text_len, d_results, d_flags, only_deferred, clamp);
+                       d_tasks, n, last_symbol, max_text_len, d_results, d_flags, chained, only_deferred, clamp);
     WAMD_HIP(hipGetLastError());
     return WAMD_OK;
 }
@@ -956,7 +961,7 @@ static int launch_one(const GenomeView& g, const ReadsView& rv, const wamd_dist_
 template <int NB>
 static int launch_band(const GenomeView& g, const ReadsView& rv, const wamd_dist_task* d_tasks, uint32_t n,
                        int last_symbol, uint32_t max_text_len, wamd_dist_result* d_results, uint32_t* d_flags,
-                       const uint32_t* only_deferred, uint32_t* deferred, hipStream_t s)
+                       int chained, const uint32_t* only_deferred, uint32_t* deferred, hipStream_t s)
 {
 #ifndef WAMD_BAND_BLOCK
 #define WAMD_BAND_BLOCK 128
@@ -965,18 +970,18 @@ static int launch_band(const GenomeView& g, const ReadsView& rv, const wamd_dist
     const uint32_t blocks = (n + BLOCK - 1) / BLOCK;
     const size_t lds = (size_t)rv.words32 * 4 * BLOCK * sizeof(uint32_t);
     hipLaunchKernelGGL((myers_band_kernel<NB, BLOCK>), dim3(blocks), dim3(BLOCK), lds, s, g, rv, d_tasks, n,
-                       last_symbol, max_text_len, d_results, d_flags, only_deferred, deferred);
+                       last_symbol, max_text_len, d_results, d_flags, chained, only_deferred, deferred);
     WAMD_HIP(hipGetLastError());
     return WAMD_OK;
 }
 
 static int launch_exact(const GenomeView& g, const ReadsView& rv, const wamd_dist_task* d_tasks, uint32_t n,
-                        int last_symbol, uint32_t mt, wamd_dist_result* d_results, uint32_t* f,
+                        int last_symbol, uint32_t mt, wamd_dist_result* d_results, uint32_t* f, int chained,
                         const uint32_t* only_deferred, int clamp, hipStream_t s)
 {
 #define WAMD_DIST_CASE(NW, BLOCK) \
     if (rv.words32 <= NW)         \
-        return launch_one<NW, BLOCK>(g, rv, d_tasks, n, last_symbol, mt, d_results, f, only_deferred, clamp, s);
+        return launch_one<NW, BLOCK>(g, rv, d_tasks, n, last_symbol, mt, d_results, f, chained, only_deferred, clamp, s);
     WAMD_DIST_CASE(1, 256)
     WAMD_DIST_CASE(2, 256)
     WAMD_DIST_CASE(3, 256)
@@ -995,6 +1000,25 @@ static int launch_exact(const GenomeView& g, const ReadsView& rv, const wamd_dis
     return WAMD_ERR_TOO_LONG;
 }
 
+// The pair of "something was deferred" flags of a stream: a stream keeps the pair it was given at
+// its first accepted-only launch (launches on one stream are ordered, so they may share it).
+// nullptr once BAND_SLOTS streams have been seen: the chain then runs without the early-out.
+static uint32_t* band_flags(wamd_ctx* ctx, hipStream_t s)
+{
+    while (__sync_lock_test_and_set(&ctx->band_lock, 1)) {
+    }
+    int slot = -1;
+    for (int i = 0; i < ctx->band_streams; ++i)
+        if (ctx->band_stream[i] == (void*)s)
+            slot = i;
+    if (slot < 0 && ctx->band_streams < BAND_SLOTS) {
+        slot = ctx->band_streams++;
+        ctx->band_stream[slot] = (void*)s;
+    }
+    __sync_lock_release(&ctx->band_lock);
+    return slot < 0 ? nullptr : ctx->d_flags + 4 + 2 * slot;
+}
+
 int launch_distance(wamd_ctx* ctx, const wamd_reads* r, const wamd_dist_task* d_tasks, uint32_t n,
                     int last_symbol, wamd_dist_result* d_results, int mode, hipStream_t s)
 {
@@ -1007,23 +1031,24 @@ int launch_distance(wamd_ctx* ctx, const wamd_reads* r, const wamd_dist_task* d_
     uint32_t* f = ctx->d_flags;
     // the LDS rows of the banded kernels must fit a block: words32 x 2 KB <= 64 KB
     if (mode != WAMD_DISTANCE_ACCEPTED_ONLY || rv.words32 <= 2 || rv.words32 > 32)
-        return launch_exact(g, rv, d_tasks, n, last_symbol, mt, d_results, f, nullptr,
+        return launch_exact(g, rv, d_tasks, n, last_symbol, mt, d_results, f, 0, nullptr,
                             mode == WAMD_DISTANCE_ACCEPTED_ONLY, s);
     // 64-row band, then 96 rows for what did not fit, then whole columns
-    uint32_t* cnt2 = f + 1;
-    uint32_t* cnt3 = f + 2;
-    WAMD_HIP(hipMemsetAsync(cnt2, 0, 2 * sizeof(uint32_t), s));
-    int rc = launch_band<2>(g, rv, d_tasks, n, last_symbol, mt, d_results, f, nullptr, cnt2, s);
+    uint32_t* cnt2 = band_flags(ctx, s);
+    uint32_t* cnt3 = cnt2 ? cnt2 + 1 : nullptr;
+    if (cnt2)
+        WAMD_HIP(hipMemsetAsync(cnt2, 0, 2 * sizeof(uint32_t), s));
+    int rc = launch_band<2>(g, rv, d_tasks, n, last_symbol, mt, d_results, f, 0, nullptr, cnt2, s);
     if (rc != WAMD_OK)
         return rc;
     const uint32_t* last = cnt2;
     if (rv.words32 > 3) {
-        rc = launch_band<3>(g, rv, d_tasks, n, last_symbol, mt, d_results, f, cnt2, cnt3, s);
+        rc = launch_band<3>(g, rv, d_tasks, n, last_symbol, mt, d_results, f, 1, cnt2, cnt3, s);
         if (rc != WAMD_OK)
             return rc;
         last = cnt3;
     }
-    return launch_exact(g, rv, d_tasks, n, last_symbol, mt, d_results, f, last, 1, s);
+    return launch_exact(g, rv, d_tasks, n, last_symbol, mt, d_results, f, 1, last, 1, s);
 }
 
 } // namespace wamd

@@ -217,9 +217,9 @@ static int ctx_create_common(int device, const uint8_t* genome, bool on_device, 
                 break;
             }
         }
-        if ((e = hipMalloc(&c->d_flags, 4 * sizeof(uint32_t))) != hipSuccess ||
+        if ((e = hipMalloc(&c->d_flags, (4 + 2 * BAND_SLOTS) * sizeof(uint32_t))) != hipSuccess ||
             (e = hipHostMalloc(&c->h_flags, sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess ||
-            (e = hipMemsetAsync(c->d_flags, 0, 4 * sizeof(uint32_t), c->stream)) != hipSuccess ||
+            (e = hipMemsetAsync(c->d_flags, 0, (4 + 2 * BAND_SLOTS) * sizeof(uint32_t), c->stream)) != hipSuccess ||
             (e = hipStreamSynchronize(c->stream)) != hipSuccess) {
             rc = hip_fail(e, "context buffers", __FILE__, __LINE__);
             break;

@@ -21,6 +21,7 @@ enum : uint32_t {
     FLAG_CIGAR = 1u << 6,      // cigar_stride too small for a task
 };
 constexpr uint32_t RESULT_ERROR = 0xFFFFFFFFu;
+constexpr int BAND_SLOTS = 16;
 
 // ---- device view of a reads batch ------------------------------------------------
 // codes : canonical 4-bit codes of every read in DIRECT orientation, two per byte,
@@ -71,7 +72,11 @@ struct wamd_ctx {
     uint32_t max_text_len;
     int distance_mode;          // WAMD_DISTANCE_*
     wamd_scoring scoring;
-    uint32_t* d_flags;          // device error flags; [1], [2]: deferred-task counts of the banded kernels
+    uint32_t* d_flags;          // device error flags; behind them BAND_SLOTS pairs of "something was
+                                // deferred" words of the banded distance chain, one pair per stream
+    void* band_stream[16];      // which stream owns which pair (assigned at its first launch)
+    int band_streams;
+    int band_lock;
     uint32_t* h_flags;          // pinned mirror
     // staging for the host-pointer entry points (grown on demand)
     void* d_stage;
