@@ -883,13 +883,47 @@ __global__ __launch_bounds__(BLOCK) void align_traceback_kernel(GenomeView g, Re
             raise_flag(ap.flags, FLAG_CIGAR);
             valid = false;
         }
+        // Bytes gather in `acc`, dwords in a 16-byte buffer that goes out with one store: every lane
+        // writes its own slot, so a wave's store costs the 64 lines it touches whatever its width.
+        uint32_t qb0 = 0, qb1 = 0, qb2 = 0, qb3 = 0;
         auto emit = [&](uint32_t byte) {
             acc |= byte << (8 * (cur & 3u));
             ++cur;
             if ((cur & 3u) == 0) {
-                *reinterpret_cast<uint32_t*>(slot + cur - 4) = acc;
+                const uint32_t qi = ((cur >> 2) - 1u) & 3u;
+                qb0 = qi == 0 ? acc : qb0;
+                qb1 = qi == 1 ? acc : qb1;
+                qb2 = qi == 2 ? acc : qb2;
+                qb3 = qi == 3 ? acc : qb3;
                 acc = 0;
+                if (qi == 3) {
+                    wamd_u32x4 v = {qb0, qb1, qb2, qb3};
+                    *reinterpret_cast<wamd_u32x4_a4*>(slot + cur - 16) = v;
+                }
             }
+        };
+        // memory holds every byte emitted so far (the refinement patches bytes in place)
+        auto flush_partial = [&]() {
+            const uint32_t blk = cur & ~15u, full = (cur & 15u) >> 2;
+            if (full > 0)
+                *reinterpret_cast<uint32_t*>(slot + blk) = qb0;
+            if (full > 1)
+                *reinterpret_cast<uint32_t*>(slot + blk + 4) = qb1;
+            if (full > 2)
+                *reinterpret_cast<uint32_t*>(slot + blk + 8) = qb2;
+            for (uint32_t q = cur & ~3u; q < cur; ++q)
+                slot[q] = (uint8_t)(acc >> (8 * (q & 3u)));
+        };
+        // the buffer and `acc` as memory holds them at position `cur`
+        auto reload_partial = [&]() {
+            const uint32_t blk = cur & ~15u, full = (cur & 15u) >> 2;
+            qb0 = full > 0 ? *reinterpret_cast<const uint32_t*>(slot + blk) : 0u;
+            qb1 = full > 1 ? *reinterpret_cast<const uint32_t*>(slot + blk + 4) : 0u;
+            qb2 = full > 2 ? *reinterpret_cast<const uint32_t*>(slot + blk + 8) : 0u;
+            qb3 = 0;
+            acc = 0;
+            for (uint32_t q = cur & ~3u; q < cur; ++q)
+                acc |= (uint32_t)slot[q] << (8 * (q & 3u));
         };
         NibStream rf, gf;
         rf.init(st_read, BLOCK, 0, rd_n, rev ? (int64_t)m - 1 : 0);
@@ -935,17 +969,14 @@ __global__ __launch_bounds__(BLOCK) void align_traceback_kernel(GenomeView g, Re
                     // the current match has just pushed its own reference symbol
                     if (hist == pat_a || hist == pat_b) {
                         refined = 1;
-                        // make memory hold every byte emitted so far
-                        for (uint32_t q = cur & ~3u; q < cur; ++q)
-                            slot[q] = (uint8_t)(acc >> (8 * (q & 3u)));
+                        flush_partial();
                         const uint32_t q0 = cur - 6;   // "^x..#y" / "#y..^x"
                         slot[q0 + 0] = (uint8_t)decode((ref_hist >> 12) & 15u);
                         slot[q0 + 1] = (uint8_t)decode((ref_hist >> 8) & 15u);
                         slot[q0 + 2] = (uint8_t)decode((ref_hist >> 4) & 15u);
+                        __threadfence_block();   // the patched bytes are read back just below
                         cur = q0 + 3;
-                        acc = 0;
-                        for (uint32_t q = cur & ~3u; q < cur; ++q)
-                            acc |= (uint32_t)slot[q] << (8 * (q & 3u));
+                        reload_partial();
                         ++events;
                         score += 3 * ap.sc.mismatch;
                         score -= ap.sc.gap_ins_open + ap.sc.gap_del_open;
@@ -960,8 +991,17 @@ __global__ __launch_bounds__(BLOCK) void align_traceback_kernel(GenomeView g, Re
         if (valid) {
             const uint32_t len = cur;
             emit(0);
-            if (cur & 3u)
-                *reinterpret_cast<uint32_t*>(slot + (cur & ~3u)) = acc;
+            {   // what the buffer still holds: its full dwords and the one being filled
+                const uint32_t blk = cur & ~15u, full = (cur & 15u) >> 2;
+                if (full > 0)
+                    *reinterpret_cast<uint32_t*>(slot + blk) = qb0;
+                if (full > 1)
+                    *reinterpret_cast<uint32_t*>(slot + blk + 4) = qb1;
+                if (full > 2)
+                    *reinterpret_cast<uint32_t*>(slot + blk + 8) = qb2;
+                if (cur & 3u)
+                    *reinterpret_cast<uint32_t*>(slot + (cur & ~3u)) = acc;
+            }
             wamd_align_result r;
             r.affine_score = score;
             r.ok = 1;
