@@ -74,7 +74,7 @@ struct NibStream {
 
 // ---- pass 2a: sort accepted tasks into classes by band width ------------------------
 // class 0: 2ed+3 <= 32 rows, class 1: <= 64 rows, class 2: <= 128 rows, class 3: whole columns
-__global__ __launch_bounds__(256) void align_classify_kernel(
+__global__ __launch_bounds__(1024) void align_classify_kernel(
     ReadsView rv, const wamd_dist_task* __restrict__ tasks, const wamd_dist_result* __restrict__ dist,
     uint32_t n, wamd_align_result* __restrict__ results, uint8_t* __restrict__ cigars,
     uint32_t cigar_stride, uint32_t* __restrict__ lists, uint32_t* __restrict__ counters)
@@ -105,20 +105,33 @@ __global__ __launch_bounds__(256) void align_classify_kernel(
             cls = rows <= 32 ? 0u : (rows <= 64 ? 1u : (rows <= 128 ? 2u : 3u));
         }
     }
-    // one atomic per wave and class, slots handed out by lane rank
+    // one atomic per block and class (same-address atomics serialise: per wave they were most of
+    // this kernel's time); inside the block slots go by wave, inside the wave by lane rank
+    __shared__ uint32_t wave_cnt[16][4];
+    __shared__ uint32_t block_base[4];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint32_t rank = 0;
 #pragma unroll
     for (uint32_t c = 0; c < 4; ++c) {
         const uint64_t mask = __ballot(cls == c);
-        if (!mask)
-            continue;
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
-        uint32_t first = 0;
-        if (cls == c && rank == 0)
-            first = atomicAdd(counters + c, (uint32_t)__popcll(mask));
-        first = __shfl((int)first, __ffsll((long long)mask) - 1);
         if (cls == c)
-            lists[(uint64_t)c * n + first + rank] = gid;
+            rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+        if (lane == 0)
+            wave_cnt[wave][c] = (uint32_t)__popcll(mask);
     }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) {
+            const uint32_t v = wave_cnt[w][threadIdx.x];
+            wave_cnt[w][threadIdx.x] = total;   // exclusive prefix over the block's waves
+            total += v;
+        }
+        block_base[threadIdx.x] = total ? atomicAdd(counters + threadIdx.x, total) : 0u;
+    }
+    __syncthreads();
+    if (cls < 4)
+        lists[(uint64_t)cls * n + block_base[cls] + wave_cnt[wave][cls] + rank] = gid;
 }
 
 template <int NW, int WW>
@@ -1135,7 +1148,7 @@ int launch_align(wamd_ctx* ctx, const wamd_reads* r, const wamd_dist_task* d_tas
         return rc;
     const ReadsView rv = r->view();
     const GenomeView g = genome_view(ctx);
-    hipLaunchKernelGGL(align_classify_kernel, dim3((n + 255) / 256), dim3(256), 0, s, rv, d_tasks, d_dist,
+    hipLaunchKernelGGL(align_classify_kernel, dim3((n + 1023) / 1024), dim3(1024), 0, s, rv, d_tasks, d_dist,
                        n, d_results, d_cigars, cigar_stride, d_lists, d_counters);
     WAMD_HIP(hipGetLastError());
 
