@@ -1143,7 +1143,10 @@ int launch_align(wamd_ctx* ctx, const wamd_reads* r, const wamd_dist_task* d_tas
     const uint64_t region = L.total - L.slots_off;
 
     WAMD_HIP(hipMemsetAsync(d_counters, 0, 256, s));
-    int rc = launch_distance(ctx, r, d_tasks, n, last_symbol, d_dist, WAMD_DISTANCE_EXACT, s);
+    int rc = ensure_pm(r, s);   // the wide classes read the 64-bit vectors
+    if (rc != WAMD_OK)
+        return rc;
+    rc = launch_distance(ctx, r, d_tasks, n, last_symbol, d_dist, WAMD_DISTANCE_EXACT, s);
     if (rc)
         return rc;
     const ReadsView rv = r->view();

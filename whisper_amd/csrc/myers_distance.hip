@@ -326,31 +326,32 @@ __device__ __forceinline__ uint32_t decode_task(const wamd_dist_task& task, cons
     return 0;
 }
 
-static_assert(TEXT_CHUNK == 8, "the text stream fetches two 16-byte pieces per chunk");
+static_assert(TEXT_CHUNK % 4 == 0, "the text stream fetches 16-byte pieces");
 // first TEXT_CHUNK + 1 dwords of a lane's text, nibble-swapped
 __device__ __forceinline__ void load_text_first(const GenomeView& g, uint32_t didx, uint32_t (&R)[TEXT_CHUNK + 1])
 {
-    uint32_t a[4], b[4];
-    load_genome_raw4(g, didx, a);
-    load_genome_raw4(g, didx + 4, b);
-    const uint32_t last = g.dwords[didx + 8 < g.last_dword ? didx + 8 : g.last_dword];
+    uint32_t a[TEXT_CHUNK / 4][4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        R[c] = nibble_swap(a[c]);
-        R[4 + c] = nibble_swap(b[c]);
-    }
-    R[8] = nibble_swap(last);
+    for (int q = 0; q < TEXT_CHUNK / 4; ++q)
+        load_genome_raw4(g, didx + 4 * q, a[q]);
+    const uint32_t last = g.dwords[didx + TEXT_CHUNK < g.last_dword ? didx + TEXT_CHUNK : g.last_dword];
+#pragma unroll
+    for (int q = 0; q < TEXT_CHUNK / 4; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            R[4 * q + c] = nibble_swap(a[q][c]);
+    R[TEXT_CHUNK] = nibble_swap(last);
 }
 // the next TEXT_CHUNK raw dwords
 __device__ __forceinline__ void load_text_chunk(const GenomeView& g, uint32_t didx, uint32_t (&NX)[TEXT_CHUNK])
 {
-    uint32_t a[4], b[4];
-    load_genome_raw4(g, didx, a);
-    load_genome_raw4(g, didx + 4, b);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        NX[c] = a[c];
-        NX[4 + c] = b[c];
+    for (int q = 0; q < TEXT_CHUNK / 4; ++q) {
+        uint32_t a[4];
+        load_genome_raw4(g, didx + 4 * q, a);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            NX[4 * q + c] = a[c];
     }
 }
 

@@ -78,8 +78,7 @@ __device__ __forceinline__ uint32_t oriented_group8(const uint32_t* codes, uint3
 }
 
 // one thread per (read, slot, word)
-__global__ __launch_bounds__(256) void pattern_vectors_kernel(ReadsView rv, uint64_t* __restrict__ pm,
-                                                              uint32_t* __restrict__ meta)
+__global__ __launch_bounds__(256) void pattern_vectors_kernel(ReadsView rv, uint64_t* __restrict__ pm)
 {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t w = (uint32_t)(t % rv.words);
@@ -93,7 +92,6 @@ __global__ __launch_bounds__(256) void pattern_vectors_kernel(ReadsView rv, uint
     const uint8_t* codes = rv.codes + rv.code_off[read];
     const uint32_t* code_dw = reinterpret_cast<const uint32_t*>(codes);
     uint64_t row[4] = {0, 0, 0, 0};
-    uint32_t presence = 0;
     const uint32_t lo = w * 64, hi = min(len, lo + 64);
     for (uint32_t g0 = lo; g0 < hi; g0 += 8) {
         const uint32_t syms = oriented_group8(code_dw, len, rc, (int32_t)g0);
@@ -107,19 +105,50 @@ __global__ __launch_bounds__(256) void pattern_vectors_kernel(ReadsView rv, uint
             row[1] |= c == 1 ? bit : 0;
             row[2] |= c == 2 ? bit : 0;
             row[3] |= c == 3 ? bit : 0;
-            presence |= i < hi ? 1u << c : 0u;
         }
     }
     uint64_t* dst = pm + ((uint64_t)(read * (uint64_t)rv.n_orient + slot) * 4) * rv.words + w;
     for (int c = 0; c < 4; ++c)
         dst[(uint64_t)c * rv.words] = row[c];
-    if (w == 0) {
-        // last_symbol, LevMyers64.cpp:182 / 192
-        const uint32_t last = rc ? rc_code(packed_symbol(codes, 0)) : packed_symbol(codes, len - 1);
-        presence |= last << 16;
+}
+
+// one thread per read: which codes it holds (bits 0..15) and its last symbol (bits 16..19,
+// LevMyers64.cpp:182 / 192), for either orientation - plain stores, no atomics
+__global__ __launch_bounds__(256) void reads_meta_kernel(ReadsView rv, uint32_t* __restrict__ meta)
+{
+    const uint32_t read = blockIdx.x * blockDim.x + threadIdx.x;
+    if (read >= rv.n)
+        return;
+    const uint32_t len = rv.lens[read];
+    const uint8_t* codes = rv.codes + rv.code_off[read];
+    const uint32_t* code_dw = reinterpret_cast<const uint32_t*>(codes);
+    const uint32_t nd = (len + 7) / 8;
+    uint32_t presence = 0;
+    for (uint32_t d4 = 0; d4 < nd; d4 += 4) {   // the codes buffer has 64 bytes of slack behind the last read
+        const wamd_u32x4 v = *reinterpret_cast<const wamd_u32x4_a4*>(code_dw + d4);
+        const uint32_t b[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (uint32_t c = 0; c < 4; ++c) {
+            const uint32_t d = d4 + c;
+            if (d < nd) {
+                const uint32_t w = nibble_swap(b[c]);
+                const uint32_t ns = len - 8 * d;   // symbols of the read in this dword (>= 1)
+#pragma unroll
+                for (uint32_t k = 0; k < 8; ++k)
+                    presence |= k < ns ? 1u << ((w >> (4 * k)) & 15u) : 0u;
+            }
+        }
     }
-    if (presence)
-        atomicOr(meta + (read * (uint64_t)rv.n_orient + slot), presence);
+    if (len == 0)
+        return;
+    if (rv.slot_direct >= 0)
+        meta[read * (uint64_t)rv.n_orient + (uint32_t)rv.slot_direct] = presence | (packed_symbol(codes, len - 1) << 16);
+    if (rv.slot_rc >= 0) {
+        // rc_code (LevMyers64.cpp:40-48): A <-> T, C <-> G, 4..7 stay, 8..15 -> 7
+        const uint32_t p = ((presence & 1u) << 3) | ((presence & 2u) << 1) | ((presence & 4u) >> 1) | ((presence & 8u) >> 3) |
+                           (presence & 0xf0u) | ((presence & 0xff00u) ? 0x80u : 0u);
+        meta[read * (uint64_t)rv.n_orient + (uint32_t)rv.slot_rc] = p | (rc_code(packed_symbol(codes, 0)) << 16);
+    }
 }
 
 // one thread per (read, slot, dword) of the top-aligned 32-bit vectors
@@ -174,10 +203,7 @@ int launch_reads_prepare(wamd_ctx* ctx, wamd_reads* r, const uint8_t* d_raw,
     }
     {
         ReadsView rv = r->view();
-        const uint64_t threads = (uint64_t)r->n * rv.n_orient * rv.words;
-        const uint32_t blocks = (uint32_t)((threads + 255) / 256);
-        hipLaunchKernelGGL(pattern_vectors_kernel, dim3(blocks), dim3(256), 0, s, rv, r->d_pm,
-                           r->d_meta);
+        hipLaunchKernelGGL(reads_meta_kernel, dim3((r->n + 255) / 256), dim3(256), 0, s, rv, r->d_meta);
         WAMD_HIP(hipGetLastError());
     }
     {
@@ -187,6 +213,35 @@ int launch_reads_prepare(wamd_ctx* ctx, wamd_reads* r, const uint8_t* d_raw,
         hipLaunchKernelGGL(pattern_vectors32_kernel, dim3(blocks), dim3(256), 0, s, rv, r->d_pm32);
         WAMD_HIP(hipGetLastError());
     }
+    return WAMD_OK;
+}
+
+// The 64-bit vectors of a batch, built on the stream of the first caller that needs them.
+int ensure_pm(const wamd_reads* cr, hipStream_t s)
+{
+    wamd_reads* r = const_cast<wamd_reads*>(cr);
+    if (r->n == 0)
+        return WAMD_OK;
+    while (__sync_lock_test_and_set(&r->pm_lock, 1)) {
+    }
+    hipError_t e = hipSuccess;
+    if (r->pm_state == 0) {
+        ReadsView rv = r->view();
+        const uint64_t threads = (uint64_t)r->n * rv.n_orient * rv.words;
+        const uint32_t blocks = (uint32_t)((threads + 255) / 256);
+        hipLaunchKernelGGL(pattern_vectors_kernel, dim3(blocks), dim3(256), 0, s, rv, r->d_pm);
+        e = hipGetLastError();
+        if (e == hipSuccess)
+            e = hipEventRecord(r->pm_event, s);
+        if (e == hipSuccess) {
+            r->pm_stream = s;
+            r->pm_state = 1;
+        }
+    } else if (r->pm_stream != s) {
+        e = hipStreamWaitEvent(s, r->pm_event, 0);
+    }
+    __sync_lock_release(&r->pm_lock);
+    WAMD_HIP(e);
     return WAMD_OK;
 }
 

@@ -382,6 +382,10 @@ int wamd_reads_upload(wamd_ctx* ctx, const uint8_t* data, const uint64_t* offset
             rc = hip_fail(e, "hipMalloc(reads)", __FILE__, __LINE__);
             break;
         }
+        if ((e = hipEventCreateWithFlags(&r->pm_event, hipEventDisableTiming)) != hipSuccess) {
+            rc = hip_fail(e, "hipEventCreate(reads)", __FILE__, __LINE__);
+            break;
+        }
         if (n == 0)
             break;
         if ((e = hipMemcpyAsync(d_raw, data, raw_end, hipMemcpyHostToDevice, s)) != hipSuccess ||
@@ -427,6 +431,7 @@ int wamd_reads_free(wamd_reads* r)
     if (r->d_pm) (void)hipFree(r->d_pm);
     if (r->d_pm32) (void)hipFree(r->d_pm32);
     if (r->d_meta) (void)hipFree(r->d_meta);
+    if (r->pm_event) (void)hipEventDestroy(r->pm_event);
     delete r;
     return WAMD_OK;
 }

@@ -100,6 +100,11 @@ struct wamd_reads {
     uint32_t words32;
     uint32_t* d_meta;
     uint64_t codes_bytes;
+    // the 64-bit pattern vectors are only read by the traceback's wide classes: built by the first
+    // wamd_align call on the batch (ensure_pm), on its stream; other streams wait for pm_event
+    int pm_state, pm_lock;
+    hipStream_t pm_stream;
+    hipEvent_t pm_event;
     wamd::ReadsView view() const;
 };
 
@@ -121,6 +126,7 @@ int flags_to_status(uint32_t flags);
 // kernel launchers (each defined next to its kernel)
 int launch_reads_prepare(wamd_ctx* ctx, wamd_reads* r, const uint8_t* d_raw,
                          const uint64_t* d_raw_off, hipStream_t s);
+int ensure_pm(const wamd_reads* r, hipStream_t s);
 int launch_distance(wamd_ctx* ctx, const wamd_reads* r, const wamd_dist_task* d_tasks, uint32_t n,
                     int last_symbol, wamd_dist_result* d_results, int mode, hipStream_t s);
 int launch_levdiag(wamd_ctx* ctx, const wamd_reads* r, const wamd_levdiag_task* d_tasks,
