@@ -168,20 +168,25 @@ __global__ __launch_bounds__(256) void pattern_vectors32_kernel(ReadsView rv, ui
     const uint32_t* code_dw = reinterpret_cast<const uint32_t*>(codes);
     uint32_t row[4] = {0, 0, 0, 0};
     const int32_t i0 = (int32_t)(32 * j) - phantom;
+    // eight symbols at a time: one flag bit per nibble and class, the eight flags squeezed into a byte
+    auto squeeze = [](uint32_t f) -> uint32_t {   // bits 0, 4, .., 28 -> bits 0 .. 7
+        f = (f | (f >> 3)) & 0x03030303u;
+        f = (f | (f >> 6)) & 0x000f000fu;
+        return (f | (f >> 12)) & 0xffu;
+    };
 #pragma unroll
     for (int32_t g0 = 0; g0 < 32; g0 += 8) {
         const uint32_t syms = i0 + g0 + 7 < 0 ? 0u : oriented_group8(code_dw, len, rc, i0 + g0);
-#pragma unroll
-        for (int32_t k = 0; k < 8; ++k) {
-            const int32_t i = i0 + g0 + k;
-            const uint32_t bit = 1u << (g0 + k);
-            // a phantom row (i < 0) matches every text symbol: D stays 0 down to the read's row 0
-            const uint32_t c = (syms >> (4 * k)) & 15u;
-            row[0] |= (i < 0 || c == 0) ? bit : 0;
-            row[1] |= (i < 0 || c == 1) ? bit : 0;
-            row[2] |= (i < 0 || c == 2) ? bit : 0;
-            row[3] |= (i < 0 || c == 3) ? bit : 0;
-        }
+        const uint32_t m1 = 0x11111111u;
+        const uint32_t acgt = ~((syms >> 2) | (syms >> 3)) & m1;   // nibble < 4
+        const uint32_t b0 = syms & m1, b1 = (syms >> 1) & m1;
+        // a phantom row (i < 0) matches every text symbol: D stays 0 down to the read's row 0
+        const int32_t np = -(i0 + g0);   // nibbles of this group that are phantom rows
+        const uint32_t ph = np <= 0 ? 0u : (np >= 8 ? m1 : (m1 & ((1u << (4 * np)) - 1u)));
+        row[0] |= squeeze((acgt & ~b0 & ~b1) | ph) << g0;
+        row[1] |= squeeze((acgt & b0 & ~b1) | ph) << g0;
+        row[2] |= squeeze((acgt & ~b0 & b1) | ph) << g0;
+        row[3] |= squeeze((acgt & b0 & b1) | ph) << g0;
     }
     // [dword][A,C,G,T]: the verification kernels fetch a dword of all four rows with one 16-byte load
     uint4* dst = reinterpret_cast<uint4*>(pm32) + (uint64_t)(read * (uint64_t)rv.n_orient + slot) * rv.words32 + j;
