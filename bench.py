@@ -309,44 +309,78 @@ def main():
     reads = ctx.upload_reads(blob, off, lens, api.READS_NIBBLE, orientations=3)
     d_tasks = torch.from_numpy(tasks.view(np.uint8)).to(device)
     d_results = torch.zeros(n * 2, dtype=torch.int32, device=device)
+    d_results_alt = None   # second result buffer of the multi-rank path (see exchange_step)
     stream = torch.cuda.ExternalStream(ctx.stream(), device=device)
     torch.cuda.synchronize()
 
-    def verify():
-        ctx.dynamic_programming_dev(reads, d_tasks, n, d_results, last_symbol=-1)
+    def verify(out=None):
+        ctx.dynamic_programming_dev(reads, d_tasks, n, d_results if out is None else out, last_symbol=-1)
 
     # mapping records of the accepted candidates (results.cpp:161-217) -> rank 0: the path's
     # only exchange step.  Positions / strands are what the host loop would record
     # (mapping_core_sa.cpp:243, 298); here: the window start + k on the direct strand.
     d_rec_pos = torch.from_numpy((tasks["ref_pos"] + K_ERR).astype(np.uint32).view(np.int32)).to(device)
     d_dir = torch.ones(n, dtype=torch.uint8, device=device)
-    d_records = torch.zeros((n, gather.RECORD_BYTES), dtype=torch.uint8, device=device)
-    d_count = torch.zeros(1, dtype=torch.int32, device=device)
+    n_buf = 2 if multi else 1
+    d_records = [torch.zeros((n, gather.RECORD_BYTES), dtype=torch.uint8, device=device) for _ in range(n_buf)]
+    d_count = [torch.zeros(1, dtype=torch.int32, device=device) for _ in range(n_buf)]
     d_scratch = torch.zeros(ctx.records_scratch_bytes(n), dtype=torch.uint8, device=device)
 
-    # The gather of bin i stays in flight while bin i + 1 is verified (its block is a copy,
-    # so the next emission may overwrite d_records); the last one is waited for before the clock stops.
-    in_flight = [None]
+    # The exchange of bin i runs behind the verification of bin i + 1: bins alternate between two
+    # result buffers, the records of bin i are emitted on a second stream as soon as its
+    # verification is through, the host only looks at their count once bin i + 1 has been
+    # enqueued, and the gather itself - straight out of the record buffer, two of those in turn
+    # as well - stays in flight until its buffer is needed again.  The last one is waited for
+    # before the clock stops.
+    if multi:
+        d_results_alt = torch.zeros(n * 2, dtype=torch.int32, device=device)
+    res_bufs = [d_results, d_results_alt]
+    side_e = torch.cuda.Stream(device=device) if multi else None   # record emission
+    side_g = torch.cuda.Stream(device=device) if multi else None   # counts and gather
+    verified = [torch.cuda.Event() for _ in range(n_buf)]
+    emitted = [torch.cuda.Event() for _ in range(n_buf)]
+    pend = [None] * n_buf
+    bins_done = [0]
 
-    def gather_records():
-        ctx.emit_lev_records_dev(n, d_tasks, d_results, d_rec_pos, d_dir, d_records, d_count, d_scratch)
-        with torch.cuda.stream(stream):
-            cnt = int(d_count.item())
-            nxt = gather.gather_records(d_records, cnt, dst=0, async_op=True)
-            if in_flight[0] is not None:
-                in_flight[0].result()
-            in_flight[0] = nxt
+    def start_gather(b):
+        with torch.cuda.stream(side_g):
+            side_g.wait_event(emitted[b])
+            pend[b] = gather.gather_records(d_records[b], d_count[b], dst=0, async_op=True, copy=False)
+
+    def exchange_step():
+        k = bins_done[0]
+        b = k & 1
+        if k >= 2:
+            stream.wait_event(emitted[b])   # bin k - 2 has been read out of this result buffer
+        verify(res_bufs[b])
+        verified[b].record(stream)
+        if k > 0:
+            start_gather((k - 1) & 1)       # the host reads the counts of bin k - 1 while bin k runs
+        with torch.cuda.stream(side_e):
+            side_e.wait_event(verified[b])
+            if pend[b] is not None:         # the gather of bin k - 2 still reads this record buffer
+                pend[b].result()
+                pend[b] = None
+            ctx.emit_lev_records_dev(n, d_tasks, res_bufs[b], d_rec_pos, d_dir, d_records[b], d_count[b], d_scratch,
+                                     stream=side_e.cuda_stream)
+            emitted[b].record(side_e)
+        bins_done[0] = k + 1
 
     def finish_gathers():
-        if in_flight[0] is not None:
+        if multi and bins_done[0] > 0:
+            start_gather((bins_done[0] - 1) & 1)
             with torch.cuda.stream(stream):
-                in_flight[0].result()
-            in_flight[0] = None
+                for b in range(n_buf):
+                    if pend[b] is not None:
+                        pend[b].result()
+                        pend[b] = None
+            bins_done[0] = 0
 
     def step():
-        verify()
         if multi:
-            gather_records()
+            exchange_step()
+        else:
+            verify()
 
     for _ in range(args.warmup):
         step()
@@ -361,11 +395,11 @@ def main():
            for _ in range(args.steps)]
     t0 = time.perf_counter()
     for a, b in evs:
+        # (in the multi-rank path the bracket also holds the wait for the buffer's last reader)
         a.record(stream)
-        verify()
+        step()
         b.record(stream)
-        if multi:
-            gather_records()
+    last_buf = res_bufs[(args.steps - 1) & 1] if multi else d_results
     finish_gathers()
     ctx.synchronize()
     torch.cuda.synchronize()
@@ -382,7 +416,7 @@ def main():
     if flags:
         raise SystemExit("device error flags 0x%x" % flags)
 
-    res = d_results.view(n, 2).cpu().numpy()
+    res = last_buf.view(n, 2).cpu().numpy()
     accepted = int((res[:, 0] <= K_ERR).sum())
 
     # the same step in accepted-only mode (banded kernels): accepted candidates must come back
@@ -475,7 +509,7 @@ def main():
             if not same:
                 out["parity_error"] = "GPU and CPU results differ on the baseline sample"
         if not args.no_extras and world == 1:
-            del d_tasks, d_results, d_records, d_scratch, d_rec_pos, d_dir
+            del d_tasks, d_results, d_results_alt, res_bufs, last_buf, d_records, d_scratch, d_rec_pos, d_dir, d_count
             reads.free()
             reads = None
             torch.cuda.empty_cache()
