@@ -281,6 +281,12 @@ def main():
                     help="fraction of candidates planted at their locus (S1 = 0.5; other values are experiments)")
     args = ap.parse_args()
 
+    # stdout carries the one JSON line and nothing else: libraries that write to file descriptor 1
+    # (RCCL prints its version banner there at the first collective) are sent to stderr
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     rank = env_int("RANK", 0)
     world = env_int("WORLD_SIZE", 1)
     local = env_int("LOCAL_RANK", 0)
@@ -515,7 +521,8 @@ def main():
             torch.cuda.empty_cache()
             out["extras"] = run_extras(ctx, device, args.genome_symbols, stream, args.extras_tasks)
             out["extras"]["S1_accepted_only"] = banded
-        print(json.dumps(out))
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
     if dist:
         dist.barrier()
         dist.destroy_process_group()
