@@ -214,7 +214,11 @@ __device__ __forceinline__ void load_eq(const FastGroup& f, uint32_t (&eq)[NW])
         eq[w] = *(lds_ptr)(uintptr_t)(addr + (uint32_t)w * (4u * BLOCK * 4u));
 }
 
-template <int NW, int BLOCK, int RULE, bool ENDS, bool HIN, int U>
+// LIGHT: every column of the group lies before column m - k of every lane, where the score row
+// is still above k (D[m][j] >= m - j): which column holds the minimum cannot reach the result
+// (pos is 0 unless the distance ends at or under k, and that takes a strictly smaller value
+// later on), so the tie-break terms are left out.
+template <int NW, int BLOCK, int RULE, bool ENDS, bool HIN, bool LIGHT, int U>
 __device__ __forceinline__ void fast_column(const FastGroup& f, uint32_t (&eq)[NW], uint32_t (&VP)[NW],
                                             uint32_t (&VN)[NW], uint32_t& E, uint32_t& key, uint32_t& deadf)
 {
@@ -234,7 +238,8 @@ __device__ __forceinline__ void fast_column(const FastGroup& f, uint32_t (&eq)[N
     E = v_add(E, v_lshr<31>(hp));
     E = v_add(E, v_lshr<31>(nhn));   // + 1 for the column, - 1 when HN is set
     uint32_t cand = v_add_lit<0u - ((uint32_t)(U + 1) << 17) - (uint32_t)(U + 1)>((E << 17) + f.gconst);
-    if (RULE == RULE_M256) {
+    if (LIGHT) {
+    } else if (RULE == RULE_M256) {
         // a tie moves min_pos unless D0 is set and the text symbol differs from last_symbol
         const uint32_t nzs = U < 4 ? v_lshr<(U < 4 ? 4 * U : 0)>(f.nzA) : v_lshr<(U < 4 ? 0 : 4 * U - 16)>(f.nz);
         cand = v_or(cand, v_bitop3<TT_AND3>(v_lshr<15>(d0), nzs, f.bit16));
@@ -247,12 +252,12 @@ __device__ __forceinline__ void fast_column(const FastGroup& f, uint32_t (&eq)[N
     if (ENDS)   // negative past the lane's last column
         deadf = v_or(deadf, v_add_lit<0u - (uint32_t)(U + 1)>(f.n_left));
     cand = v_bitop3<TT_OR_AND>(cand, deadf, f.sgn);
-    key = v_and_lit<~0x10000u>(v_min(key, cand));
+    key = LIGHT ? v_min(key, cand) : v_and_lit<~0x10000u>(v_min(key, cand));
     if (RULE != RULE_M64)   // ced + col > exit_t and HN clear (LevMyers256.hpp:232-233)
         deadf = v_bitop3<TT_OR_AND>(deadf, v_sub(f.exit_t, E), nhn);
 }
 
-template <int NW, int BLOCK, int RULE, bool ENDS, bool HIN>
+template <int NW, int BLOCK, int RULE, bool ENDS, bool HIN, bool LIGHT>
 __device__ __forceinline__ void group_fast(uint32_t lane_addr, uint32_t syms, uint32_t base, uint32_t lsrep,
                                            uint32_t exit_t, uint32_t n_left, uint32_t rowmask, uint32_t sgn,
                                            uint32_t bit16, uint32_t hin, uint32_t (&VP)[NW], uint32_t (&VN)[NW],
@@ -264,7 +269,7 @@ __device__ __forceinline__ void group_fast(uint32_t lane_addr, uint32_t syms, ui
     f.syms = syms;
     f.symsA = syms << 12;
     f.nz = f.nzA = 0;
-    if (RULE == RULE_M256) {
+    if (RULE == RULE_M256 && !LIGHT) {
         // bit 4u = (text symbol u != last_symbol), LevMyers256.hpp:191-196
         uint32_t t = syms ^ lsrep;
         t |= t >> 1;
@@ -283,14 +288,14 @@ __device__ __forceinline__ void group_fast(uint32_t lane_addr, uint32_t syms, ui
     f.bit16 = bit16;
     uint32_t eq[NW];
     load_eq<NW, BLOCK, 0>(f, eq);
-    fast_column<NW, BLOCK, RULE, ENDS, HIN, 0>(f, eq, VP, VN, E, key, deadf);
-    fast_column<NW, BLOCK, RULE, ENDS, HIN, 1>(f, eq, VP, VN, E, key, deadf);
-    fast_column<NW, BLOCK, RULE, ENDS, HIN, 2>(f, eq, VP, VN, E, key, deadf);
-    fast_column<NW, BLOCK, RULE, ENDS, HIN, 3>(f, eq, VP, VN, E, key, deadf);
-    fast_column<NW, BLOCK, RULE, ENDS, HIN, 4>(f, eq, VP, VN, E, key, deadf);
-    fast_column<NW, BLOCK, RULE, ENDS, HIN, 5>(f, eq, VP, VN, E, key, deadf);
-    fast_column<NW, BLOCK, RULE, ENDS, HIN, 6>(f, eq, VP, VN, E, key, deadf);
-    fast_column<NW, BLOCK, RULE, ENDS, HIN, 7>(f, eq, VP, VN, E, key, deadf);
+    fast_column<NW, BLOCK, RULE, ENDS, HIN, LIGHT, 0>(f, eq, VP, VN, E, key, deadf);
+    fast_column<NW, BLOCK, RULE, ENDS, HIN, LIGHT, 1>(f, eq, VP, VN, E, key, deadf);
+    fast_column<NW, BLOCK, RULE, ENDS, HIN, LIGHT, 2>(f, eq, VP, VN, E, key, deadf);
+    fast_column<NW, BLOCK, RULE, ENDS, HIN, LIGHT, 3>(f, eq, VP, VN, E, key, deadf);
+    fast_column<NW, BLOCK, RULE, ENDS, HIN, LIGHT, 4>(f, eq, VP, VN, E, key, deadf);
+    fast_column<NW, BLOCK, RULE, ENDS, HIN, LIGHT, 5>(f, eq, VP, VN, E, key, deadf);
+    fast_column<NW, BLOCK, RULE, ENDS, HIN, LIGHT, 6>(f, eq, VP, VN, E, key, deadf);
+    fast_column<NW, BLOCK, RULE, ENDS, HIN, LIGHT, 7>(f, eq, VP, VN, E, key, deadf);
 }
 
 // What one task asks for, derived exactly as the reference's caller and loop do.
@@ -374,6 +379,12 @@ __device__ __forceinline__ void run_columns(const GenomeView& g, Lane& t, const 
     // the packed key holds 15 bits of distance + column and 16 bits of column
     const bool fits = __all(!valid || t.m + t.n_cols < 32000u);
     const bool can_fast = uniform_rule && fits;
+    // columns before m - k of every lane: the score row is above k there (see fast_column, LIGHT)
+    uint32_t light_until = valid ? (t.m > t.k ? t.m - t.k : 0u) : 0xffffffffu;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        light_until = min(light_until, (uint32_t)__shfl_xor((int)light_until, o));
+    light_until = __builtin_amdgcn_readfirstlane(light_until);
 
     const uint32_t lsrep = t.last_sym * 0x11111111u;
     const uint32_t rowmask = in_vgpr(3u << (BLOCK == 256 ? 10 : (BLOCK == 128 ? 9 : 8)));
@@ -423,24 +434,31 @@ __device__ __forceinline__ void run_columns(const GenomeView& g, Lane& t, const 
                 }
                 const uint32_t n_left = t.n_cols - base;
                 const bool ends = __any(alive && n_left < 8u);
-#define WAMD_GROUP(RULE, ENDS)                                                                               \
-    group_fast<NW, BLOCK, RULE, ENDS, HIN>(lane_addr, syms, base, lsrep, t.exit_t, n_left, rowmask, sgn, bit16, hin, \
-                                           VP, VN, E, key, deadf)
+                const bool light = !ends && base + 8u < light_until;
+#define WAMD_GROUP(RULE, ENDS, LIGHT)                                                                        \
+    group_fast<NW, BLOCK, RULE, ENDS, HIN, LIGHT>(lane_addr, syms, base, lsrep, t.exit_t, n_left, rowmask, sgn, bit16, \
+                                                  hin, VP, VN, E, key, deadf)
                 if (rule0 == RULE_M256) {
                     if (ends)
-                        WAMD_GROUP(RULE_M256, true);
+                        WAMD_GROUP(RULE_M256, true, false);
+                    else if (light)
+                        WAMD_GROUP(RULE_M256, false, true);
                     else
-                        WAMD_GROUP(RULE_M256, false);
+                        WAMD_GROUP(RULE_M256, false, false);
                 } else if (rule0 == RULE_M128) {
                     if (ends)
-                        WAMD_GROUP(RULE_M128, true);
+                        WAMD_GROUP(RULE_M128, true, false);
+                    else if (light)
+                        WAMD_GROUP(RULE_M128, false, true);
                     else
-                        WAMD_GROUP(RULE_M128, false);
+                        WAMD_GROUP(RULE_M128, false, false);
                 } else {
                     if (ends)
-                        WAMD_GROUP(RULE_M64, true);
+                        WAMD_GROUP(RULE_M64, true, false);
+                    else if (light)
+                        WAMD_GROUP(RULE_M64, false, true);
                     else
-                        WAMD_GROUP(RULE_M64, false);
+                        WAMD_GROUP(RULE_M64, false, false);
                 }
 #undef WAMD_GROUP
                 continue;
