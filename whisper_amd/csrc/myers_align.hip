@@ -188,6 +188,7 @@ struct AlignParams {
     uint32_t path_dwords;
     int refine;
     int ascii;
+    uint32_t rd_cap, gd_cap;   // replay kernel: staged read / genome dwords per lane (from the batch's longest read)
 };
 
 // ---- pass 2b: windowed recompute + traceback + forward emission --------------------
@@ -217,7 +218,10 @@ __global__ __launch_bounds__(BLOCK) void align_traceback_kernel(GenomeView g, Re
     constexpr int SD = (64 * NW + 16 + 64 + 31) / 32 + 1;
     constexpr int LDS_A = HALF ? 4 * SD : 12 * NW;              // forward pass
     constexpr int LDS_B = RD + GD + CHB;                        // staged symbols (+ the old walk's chunk)
-    constexpr int LDS_DW = PHASE == 1 ? LDS_A : (PHASE == 2 ? LDS_B : (LDS_A > LDS_B ? LDS_A : LDS_B));
+    // the replay kernel (PHASE 2) sizes its staging by the batch's longest read, in dynamic LDS:
+    // it is the LDS that limits its waves per CU, and with them its speed
+    constexpr int LDS_DW = PHASE == 1 ? LDS_A : (PHASE == 2 ? 2 : (LDS_A > LDS_B ? LDS_A : LDS_B));
+    extern __shared__ uint64_t lds_dyn[];
     static_assert(PHASE == 0 || HALF, "only the banded class is split");
     __shared__ uint64_t lds_all[LDS_DW * BLOCK / 2];
     uint64_t* pm_lds = lds_all;
@@ -625,37 +629,36 @@ __global__ __launch_bounds__(BLOCK) void align_traceback_kernel(GenomeView g, Re
         bool in_indel = false;
         double score = 0;
         // ---- stage the read and the genome symbols under the recomputed columns ------------
-        uint32_t* st_read = reinterpret_cast<uint32_t*>(lds_all) + tid;
-        uint32_t* st_gen = st_read + RD * BLOCK;
+        const int RDc = PHASE == 2 ? (int)ap.rd_cap : RD, GDc = PHASE == 2 ? (int)ap.gd_cap : GD;
+        uint32_t* st_read = reinterpret_cast<uint32_t*>(PHASE == 2 ? lds_dyn : lds_all) + tid;
+        uint32_t* st_gen = st_read + RDc * BLOCK;
         const int32_t rd_n = valid ? (int32_t)((m + 7) / 8) : 1;
         // the walk reads genome symbols ref_pos + s_col - 2 .. ref_pos + end_pos - 1
         const int64_t g_first = (int64_t)ref_pos + (int64_t)s_col - 2;
         const int64_t g_origin = (g_first < 0 ? 0 : g_first) >> 3;
         int32_t gd_n = valid ? (int32_t)((((int64_t)ref_pos + end_pos - 1) >> 3) - g_origin + 1) : 1;
-        gd_n = gd_n > GD ? GD : (gd_n < 1 ? 1 : gd_n);
+        gd_n = gd_n > GDc ? GDc : (gd_n < 1 ? 1 : gd_n);
         if constexpr (PHASE != 1) {
             // 16-byte loads (a wave's load costs the 64 cache lines it touches, whatever its width);
             // the codes buffer has 64 bytes of slack behind the last read
             const uint32_t* src = reinterpret_cast<const uint32_t*>(my_codes);
-#pragma unroll
-            for (int d4 = 0; d4 < RD; d4 += 4) {
+            for (int d4 = 0; d4 < RDc; d4 += 4) {
                 if (d4 < rd_n) {
                     const wamd_u32x4 v = *reinterpret_cast<const wamd_u32x4_a4*>(src + d4);
                     const uint32_t b[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
-                        if (d4 + c < RD && d4 + c < rd_n)
+                        if (d4 + c < RDc && d4 + c < rd_n)
                             st_read[(d4 + c) * BLOCK] = nibble_swap(b[c]);
                 }
             }
-#pragma unroll
-            for (int d4 = 0; d4 < GD; d4 += 4) {
+            for (int d4 = 0; d4 < GDc; d4 += 4) {
                 if (d4 < gd_n) {
                     uint32_t b[4];
                     load_genome_raw4(g, (uint32_t)(g_origin + d4), b);
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
-                        if (d4 + c < GD && d4 + c < gd_n)
+                        if (d4 + c < GDc && d4 + c < gd_n)
                             st_gen[(d4 + c) * BLOCK] = nibble_swap(b[c]);
                 }
             }
@@ -1102,7 +1105,8 @@ static int launch_tb(const GenomeView& g, const ReadsView& rv, AlignParams ap, u
     if constexpr (WW == 0) {
         hipLaunchKernelGGL((align_traceback_kernel<NW, WW, BLOCK, 1>), dim3(blocks), dim3(BLOCK), 0, s, g, rv, ap);
         const uint32_t b2 = groups < 256u * 32u ? (groups ? groups : 1u) : 256u * 32u;
-        hipLaunchKernelGGL((align_traceback_kernel<NW, WW, BLOCK, 2>), dim3(b2), dim3(BLOCK), 0, s, g, rv, ap);
+        hipLaunchKernelGGL((align_traceback_kernel<NW, WW, BLOCK, 2>), dim3(b2), dim3(BLOCK),
+                           (size_t)(ap.rd_cap + ap.gd_cap) * BLOCK * sizeof(uint32_t), s, g, rv, ap);
     } else {
         hipLaunchKernelGGL((align_traceback_kernel<NW, WW, BLOCK, 0>), dim3(blocks), dim3(BLOCK), 0, s, g, rv, ap);
     }
@@ -1172,6 +1176,10 @@ int launch_align(wamd_ctx* ctx, const wamd_reads* r, const wamd_dist_task* d_tas
         ap.path_dwords = L.path_dwords;
         ap.refine = refine;
         ap.ascii = r->encoding == WAMD_READS_ASCII;
+        // replay of the banded class (ed <= 14): the read, and the m + ed + 2 genome symbols the
+        // alignment can span, from whatever nibble of a dword they start at
+        ap.rd_cap = (r->max_len + 7) / 8 + 1;
+        ap.gd_cap = (r->max_len + 30) / 8 + 2;
         const uint64_t per_block = L.per_block[cls];
         ap.slot_words = per_block / 8;
         uint64_t blocks64 = region / per_block;
