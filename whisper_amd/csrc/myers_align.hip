@@ -196,7 +196,12 @@ struct AlignParams {
 // pays for its own LDS: PHASE 1 = forward pass + walk (path and totals go to memory),
 // PHASE 2 = forward replay of the recorded path (ext-CIGAR, refinement).
 template <int NW, int WW, int BLOCK, int PHASE>
-__global__ __launch_bounds__(BLOCK) void align_traceback_kernel(GenomeView g, ReadsView rv, AlignParams ap)
+#ifndef WAMD_WALK_WAVES
+#define WAMD_WALK_WAVES 4
+#endif
+// (second launch bound = waves per SIMD the register budget must allow: the walk kernel sat at 133
+// VGPRs, one wave per SIMD short of what its LDS permits)
+__global__ __launch_bounds__(BLOCK, (PHASE == 1 && NW <= 4 ? WAMD_WALK_WAVES : 1)) void align_traceback_kernel(GenomeView g, ReadsView rv, AlignParams ap)
 {
     // WW = 0: 32-row windows kept as dwords; otherwise WW 64-bit words per window (at most NW)
     constexpr bool HALF = WW == 0;
