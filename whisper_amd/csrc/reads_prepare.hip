@@ -8,6 +8,21 @@
 
 namespace wamd {
 
+// t = q * d + r for a thread index: a 32-bit division whenever the index fits (a 64-bit division
+// by a run-time value is a call of some 200 instructions, more than these kernels' own work)
+__device__ __forceinline__ void thread_divmod(uint64_t t, uint32_t d, uint64_t& q, uint32_t& r)
+{
+    if ((t >> 32) == 0) {
+        const uint32_t t32 = (uint32_t)t;
+        q = t32 / d;
+        r = t32 % d;
+    } else {
+        q = t / d;
+        r = (uint32_t)(t % d);
+    }
+}
+
+
 // one thread per output dword (eight symbols) of the canonical code array
 __global__ __launch_bounds__(256) void canonical_codes_kernel(
     const uint8_t* __restrict__ raw, const uint64_t* __restrict__ raw_off,
@@ -15,15 +30,25 @@ __global__ __launch_bounds__(256) void canonical_codes_kernel(
     uint32_t dwords_per_read, int ascii, uint8_t* __restrict__ codes)
 {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t read = (uint32_t)(t / dwords_per_read);
-    const uint32_t d = (uint32_t)(t % dwords_per_read);
-    if (read >= n)
+    uint64_t read64;
+    uint32_t d;
+    thread_divmod(t, dwords_per_read, read64, d);
+    if (read64 >= n)
         return;
+    const uint32_t read = (uint32_t)read64;
     const uint32_t len = lens[read];
     const uint32_t padded_dw = ((len + 1) / 2 + 3) / 4;
     if (d >= padded_dw)
         return;
-    const uint8_t* src = raw + raw_off[read];
+    // the thread's input bytes (4 packed or 8 ASCII) from aligned dwords and a byte funnel: reads
+    // start at any byte, and byte loads cost an instruction each (the raw buffer has 64 bytes of
+    // slack behind the last read)
+    const uint64_t at = raw_off[read] + (ascii ? 8ull : 4ull) * d;
+    const uint32_t* adw = reinterpret_cast<const uint32_t*>(raw) + (at >> 2);
+    const uint32_t sh = (uint32_t)at & 3u;
+    const uint32_t a0 = adw[0], a1 = adw[1];
+    const uint32_t in0 = __builtin_amdgcn_alignbyte(a1, a0, sh);
+    const uint32_t in1 = ascii ? __builtin_amdgcn_alignbyte(adw[2], a1, sh) : 0u;
     uint32_t out = 0;
 #pragma unroll
     for (uint32_t k = 0; k < 4; ++k) {
@@ -31,7 +56,7 @@ __global__ __launch_bounds__(256) void canonical_codes_kernel(
         uint32_t c0 = 15, c1 = 15;      // padding: code 15
         if (!ascii) {
             if (2 * b < len) {
-                const uint32_t x = src[b];
+                const uint32_t x = (in0 >> (8 * k)) & 0xffu;
                 c0 = x >> 4;
                 if (2 * b + 1 < len)
                     c1 = x & 15u;
@@ -41,10 +66,11 @@ __global__ __launch_bounds__(256) void canonical_codes_kernel(
             auto code = [](uint32_t ch) -> uint32_t {
                 return ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : ch == 'N' ? 4u : 6u;
             };
+            const uint32_t pair = ((k < 2 ? in0 : in1) >> (16 * (k & 1u))) & 0xffffu;
             if (2 * b < len)
-                c0 = code(src[2 * b]);
+                c0 = code(pair & 0xffu);
             if (2 * b + 1 < len)
-                c1 = code(src[2 * b + 1]);
+                c1 = code(pair >> 8);
         }
         out |= ((c0 << 4) | c1) << (8 * k);
     }
@@ -81,12 +107,14 @@ __device__ __forceinline__ uint32_t oriented_group8(const uint32_t* codes, uint3
 __global__ __launch_bounds__(256) void pattern_vectors_kernel(ReadsView rv, uint64_t* __restrict__ pm)
 {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t w = (uint32_t)(t % rv.words);
-    const uint64_t rs = t / rv.words;
-    const uint32_t slot = (uint32_t)(rs % rv.n_orient);
-    const uint32_t read = (uint32_t)(rs / rv.n_orient);
-    if (read >= rv.n)
+    uint32_t w;
+    uint64_t rs;
+    thread_divmod(t, rv.words, rs, w);
+    const uint32_t slot = rv.n_orient == 2 ? (uint32_t)(rs & 1u) : 0u;
+    const uint64_t read64 = rv.n_orient == 2 ? rs >> 1 : rs;
+    if (read64 >= rv.n)
         return;
+    const uint32_t read = (uint32_t)read64;
     const bool rc = ((int32_t)slot == rv.slot_rc);
     const uint32_t len = rv.lens[read];
     const uint8_t* codes = rv.codes + rv.code_off[read];
@@ -155,12 +183,14 @@ __global__ __launch_bounds__(256) void reads_meta_kernel(ReadsView rv, uint32_t*
 __global__ __launch_bounds__(256) void pattern_vectors32_kernel(ReadsView rv, uint32_t* __restrict__ pm32)
 {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t j = (uint32_t)(t % rv.words32);
-    const uint64_t rs = t / rv.words32;
-    const uint32_t slot = (uint32_t)(rs % rv.n_orient);
-    const uint32_t read = (uint32_t)(rs / rv.n_orient);
-    if (read >= rv.n)
+    uint32_t j;
+    uint64_t rs;
+    thread_divmod(t, rv.words32, rs, j);
+    const uint32_t slot = rv.n_orient == 2 ? (uint32_t)(rs & 1u) : 0u;
+    const uint64_t read64 = rv.n_orient == 2 ? rs >> 1 : rs;
+    if (read64 >= rv.n)
         return;
+    const uint32_t read = (uint32_t)read64;
     const bool rc = ((int32_t)slot == rv.slot_rc);
     const uint32_t len = rv.lens[read];
     const uint8_t* codes = rv.codes + rv.code_off[read];
