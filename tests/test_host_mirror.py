@@ -51,3 +51,13 @@ def test_replay_matches_oracle(tmp_path, oracle):
     np.testing.assert_array_equal(got_d[:, 0], want_d["edit_distance"])
     np.testing.assert_array_equal(got_d[:, 1], want_d["pos"])
     np.testing.assert_array_equal(got_l, want_l)
+    # the switch a mapping stage flips: accepted candidates unchanged, the others {k + 1, 0}
+    subprocess.run([BIN, str(fin), str(fout), "--accepted-only"], check=True, timeout=120)
+    raw = np.fromfile(fout, np.uint32)
+    got_a = raw[: 2 * len(dtasks)].reshape(-1, 2)
+    rej = want_d["edit_distance"] > k
+    assert rej.any() and (~rej).any()
+    np.testing.assert_array_equal(got_a[~rej, 0], want_d["edit_distance"][~rej])
+    np.testing.assert_array_equal(got_a[~rej, 1], want_d["pos"][~rej])
+    assert (got_a[rej, 0] == k + 1).all() and (got_a[rej, 1] == 0).all()
+    np.testing.assert_array_equal(raw[2 * len(dtasks):], want_l)

@@ -22,8 +22,8 @@ template <class T> static std::vector<T> read_vec(std::ifstream& f)
 
 int main(int argc, char** argv)
 {
-    if (argc != 3) {
-        std::cerr << "usage: replay_batch <in.bin> <out.bin>\n";
+    if (argc != 3 && !(argc == 4 && std::string(argv[3]) == "--accepted-only")) {
+        std::cerr << "usage: replay_batch <in.bin> <out.bin> [--accepted-only]\n";
         return 2;
     }
     try {
@@ -37,6 +37,8 @@ int main(int argc, char** argv)
         const uint32_t stride = (hdr[2] + 1) / 2;
 
         GpuReference ref(0, genome.data(), genome.size(), hdr[0], hdr[1]);
+        if (argc == 4)   // what a mapping stage asks for: rejected candidates as {k + 1, 0}
+            ref.setAcceptedOnly(true);
         GpuLevMyers lm(ref);
         std::vector<size_t> dist_tickets(dist.size()), lev_tickets(lev.size());
         size_t di = 0, li = 0;
