@@ -202,3 +202,41 @@ def test_accepted_only_on_several_streams(ctx, oracle):
         np.testing.assert_array_equal(got[:, 1], want["pos"])
     for reads, _, _, _ in work:
         reads.free()
+
+
+def test_accepted_only_equals_exact_at_scale():
+    """Size-independent property at 2^20 candidates per shape, generated on the GPU: the banded
+    chain returns the exact kernels' answer for every accepted candidate and {k + 1, 0} for every
+    other one (the exact kernels are pinned to the oracle by test_gpu_parity / test_gpu_golden)."""
+    dev = torch.device("cuda", 0)
+    n = 1 << 20
+    codes = synth.make_genome(1 << 24, seed=77, device=dev)
+    packed = synth.pack_nibbles(codes)
+    c = api.Context(packed, ref_size=codes.numel(), cur_offset=0, device=0)
+    try:
+        for m, k, extra in ((150, 12, 0), (150, 15, 0), (151, 5, 3), (250, 17, 0), (250, 7, 1), (100, 10, 0),
+                            (300, 20, 0), (150, 13, 1)):
+            rd = synth.make_reads(codes, n, m, k, seed=1000 + m + k, chunk=1 << 15)
+            blob, off, lens = synth.pack_reads(rd["codes"], 0)
+            reads = c.upload_reads(blob.cpu().numpy(), off.cpu().numpy().astype(np.uint64),
+                                   lens.cpu().numpy().astype(np.uint32), api.READS_NIBBLE, orientations=3)
+            t = synth.distance_tasks(rd, m, k, W=m + 2 * k + extra)
+            d_t = torch.from_numpy(t.view(np.uint8)).to(dev)
+            out = []
+            for mode in (0, ACCEPTED_ONLY):
+                c.set_distance_mode(mode)
+                d_r = torch.zeros(n * 2, dtype=torch.int32, device=dev)
+                c.dynamic_programming_dev(reads, d_t, n, d_r, last_symbol=-1)
+                c.synchronize()
+                out.append(d_r.cpu().numpy().view(np.uint32).reshape(-1, 2))
+            c.set_distance_mode(0)
+            assert c.take_flags() == 0
+            exact, banded = out
+            rej = exact[:, 0] > k
+            assert (~rej).sum() > n // 4
+            bad = np.flatnonzero((banded[~rej] != exact[~rej]).any(axis=1))
+            assert len(bad) == 0, "m=%d k=%d: accepted candidates differ, first %s" % (m, k, bad[:5])
+            assert (banded[rej, 0] == k + 1).all() and (banded[rej, 1] == 0).all()
+            reads.free()
+    finally:
+        c.destroy()
