@@ -46,17 +46,21 @@ struct NibStream {
     uint32_t stride;
     uint32_t cur;
     int64_t cur_dw;
+    bool packed;   // dwords as they lie in memory (two symbols per byte, even one high): swap on load
     __device__ __forceinline__ void load()
     {
         int64_t d = (idx >> 3) - origin_dw;
         d = d < 0 ? 0 : (d >= n_dw ? n_dw - 1 : d);
         cur_dw = idx >> 3;
-        cur = base[d * stride];
+        const uint32_t v = base[d * stride];
+        cur = packed ? nibble_swap(v) : v;
     }
-    __device__ __forceinline__ void init(const uint32_t* b, uint32_t stride_, int64_t origin, int32_t n, int64_t start)
+    __device__ __forceinline__ void init(const uint32_t* b, uint32_t stride_, int64_t origin, int32_t n, int64_t start,
+                                         bool packed_ = false)
     {
         base = b;
         stride = stride_;
+        packed = packed_;
         origin_dw = origin;
         n_dw = n;
         idx = start;
@@ -635,6 +639,8 @@ __global__ __launch_bounds__(BLOCK, (PHASE == 1 && NW <= 4 ? WAMD_WALK_WAVES : 1
         double score = 0;
         // ---- stage the read and the genome symbols under the recomputed columns ------------
         const int RDc = PHASE == 2 ? (int)ap.rd_cap : RD, GDc = PHASE == 2 ? (int)ap.gd_cap : GD;
+        // (the replay kernel reads the read straight from its code dwords, one dword per eight
+        // symbols and lane: staging it as well would cost a third of the waves the LDS allows)
         uint32_t* st_read = reinterpret_cast<uint32_t*>(PHASE == 2 ? lds_dyn : lds_all) + tid;
         uint32_t* st_gen = st_read + RDc * BLOCK;
         const int32_t rd_n = valid ? (int32_t)((m + 7) / 8) : 1;
@@ -647,7 +653,7 @@ __global__ __launch_bounds__(BLOCK, (PHASE == 1 && NW <= 4 ? WAMD_WALK_WAVES : 1
             // 16-byte loads (a wave's load costs the 64 cache lines it touches, whatever its width);
             // the codes buffer has 64 bytes of slack behind the last read
             const uint32_t* src = reinterpret_cast<const uint32_t*>(my_codes);
-            for (int d4 = 0; d4 < RDc; d4 += 4) {
+            for (int d4 = 0; d4 < RDc; d4 += 4) {   // RDc = 0 in the replay kernel
                 if (d4 < rd_n) {
                     const wamd_u32x4 v = *reinterpret_cast<const wamd_u32x4_a4*>(src + d4);
                     const uint32_t b[4] = {v.x, v.y, v.z, v.w};
@@ -947,7 +953,10 @@ __global__ __launch_bounds__(BLOCK, (PHASE == 1 && NW <= 4 ? WAMD_WALK_WAVES : 1
                 acc |= (uint32_t)slot[q] << (8 * (q & 3u));
         };
         NibStream rf, gf;
-        rf.init(st_read, BLOCK, 0, rd_n, rev ? (int64_t)m - 1 : 0);
+        if constexpr (PHASE == 2)
+            rf.init(reinterpret_cast<const uint32_t*>(my_codes), 1, 0, rd_n, rev ? (int64_t)m - 1 : 0, true);
+        else
+            rf.init(st_read, BLOCK, 0, rd_n, rev ? (int64_t)m - 1 : 0);
         gf.init(st_gen, BLOCK, g_origin, gd_n, (int64_t)ref_pos + begin_pos);
         uint32_t hist = 0, ref_hist = 0;
         uint32_t pw = 0;
@@ -1183,7 +1192,7 @@ int launch_align(wamd_ctx* ctx, const wamd_reads* r, const wamd_dist_task* d_tas
         ap.ascii = r->encoding == WAMD_READS_ASCII;
         // replay of the banded class (ed <= 14): the read, and the m + ed + 2 genome symbols the
         // alignment can span, from whatever nibble of a dword they start at
-        ap.rd_cap = (r->max_len + 7) / 8 + 1;
+        ap.rd_cap = 0;   // the read comes straight from memory
         ap.gd_cap = (r->max_len + 30) / 8 + 2;
         const uint64_t per_block = L.per_block[cls];
         ap.slot_words = per_block / 8;
