@@ -204,9 +204,40 @@ __global__ __launch_bounds__(256) void pattern_vectors32_kernel(ReadsView rv, ui
         f = (f | (f >> 6)) & 0x000f000fu;
         return (f | (f >> 12)) & 0xffu;
     };
+    // the 32 oriented symbols i0 .. i0 + 31 are 32 consecutive stored symbols either way (read
+    // backwards for the other strand): five dwords, four funnels
+    uint32_t grp[4];
+    {
+        const int32_t last_dw = (int32_t)((len + 7) / 8) - 1;
+        const int32_t start = rc ? (int32_t)len - 32 - i0 : i0;   // first stored symbol of the span
+        const int32_t q0 = start >> 3;                             // floor: start may be negative
+        const uint32_t sh = (uint32_t)(start & 7) * 4u;
+        uint32_t D[5];
+#pragma unroll
+        for (int32_t k = 0; k < 5; ++k) {
+            const int32_t q = q0 + k;
+            D[k] = (q < 0 || q > last_dw) ? 0xffffffffu : nibble_swap(code_dw[q]);
+        }
+#pragma unroll
+        for (int32_t k = 0; k < 4; ++k) {
+            uint32_t w = __builtin_amdgcn_alignbit(D[k + 1], D[k], sh);   // stored symbols start + 8k ..
+            if (rc) {
+                // oriented symbol i = rc_code(stored[len - 1 - i]): reverse the eight symbols ...
+                w = __builtin_bswap32(w);
+                w = ((w & 0x0f0f0f0fu) << 4) | ((w >> 4) & 0x0f0f0f0fu);
+                // ... and rc_code per nibble (LevMyers64.cpp:40-48): c < 4 -> 3 - c, c < 8 -> c, else 7
+                const uint32_t mm = 0x11111111u;
+                const uint32_t ge8 = (w >> 3) & mm, ge4 = ((w >> 2) | (w >> 3)) & mm;
+                const uint32_t lt4 = ~ge4 & mm;
+                w ^= lt4 * 3u;
+                w = (w & ~(ge8 * 15u)) | (ge8 * 7u);
+            }
+            grp[rc ? 3 - k : k] = w;
+        }
+    }
 #pragma unroll
     for (int32_t g0 = 0; g0 < 32; g0 += 8) {
-        const uint32_t syms = i0 + g0 + 7 < 0 ? 0u : oriented_group8(code_dw, len, rc, i0 + g0);
+        const uint32_t syms = grp[g0 >> 3];
         const uint32_t m1 = 0x11111111u;
         const uint32_t acgt = ~((syms >> 2) | (syms >> 3)) & m1;   // nibble < 4
         const uint32_t b0 = syms & m1, b1 = (syms >> 1) & m1;
