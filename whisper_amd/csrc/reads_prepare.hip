@@ -23,58 +23,83 @@ __device__ __forceinline__ void thread_divmod(uint64_t t, uint32_t d, uint64_t& 
 }
 
 
-// one thread per output dword (eight symbols) of the canonical code array
+// one thread per four output dwords (32 symbols) of the canonical code array
 __global__ __launch_bounds__(256) void canonical_codes_kernel(
     const uint8_t* __restrict__ raw, const uint64_t* __restrict__ raw_off,
     const uint32_t* __restrict__ lens, const uint64_t* __restrict__ code_off, uint32_t n,
     uint32_t dwords_per_read, int ascii, uint8_t* __restrict__ codes)
 {
+    // one thread per four output dwords (32 symbols) of a read
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t quads_per_read = (dwords_per_read + 3) / 4;
     uint64_t read64;
-    uint32_t d;
-    thread_divmod(t, dwords_per_read, read64, d);
+    uint32_t dq;
+    thread_divmod(t, quads_per_read, read64, dq);
     if (read64 >= n)
         return;
     const uint32_t read = (uint32_t)read64;
     const uint32_t len = lens[read];
     const uint32_t padded_dw = ((len + 1) / 2 + 3) / 4;
-    if (d >= padded_dw)
+    const uint32_t d0 = 4 * dq;
+    if (d0 >= padded_dw)
         return;
-    // the thread's input bytes (4 packed or 8 ASCII) from aligned dwords and a byte funnel: reads
+    // the thread's input bytes (16 packed or 32 ASCII) from aligned dwords and a byte funnel: reads
     // start at any byte, and byte loads cost an instruction each (the raw buffer has 64 bytes of
     // slack behind the last read)
-    const uint64_t at = raw_off[read] + (ascii ? 8ull : 4ull) * d;
+    const uint64_t at = raw_off[read] + (ascii ? 8ull : 4ull) * d0;
     const uint32_t* adw = reinterpret_cast<const uint32_t*>(raw) + (at >> 2);
     const uint32_t sh = (uint32_t)at & 3u;
-    const uint32_t a0 = adw[0], a1 = adw[1];
-    const uint32_t in0 = __builtin_amdgcn_alignbyte(a1, a0, sh);
-    const uint32_t in1 = ascii ? __builtin_amdgcn_alignbyte(adw[2], a1, sh) : 0u;
-    uint32_t out = 0;
+    uint32_t in[8];
+    {
+        uint32_t a[9];
 #pragma unroll
-    for (uint32_t k = 0; k < 4; ++k) {
-        const uint32_t b = 4 * d + k;   // output byte: symbols 2b (high nibble) and 2b + 1
-        uint32_t c0 = 15, c1 = 15;      // padding: code 15
-        if (!ascii) {
-            if (2 * b < len) {
-                const uint32_t x = (in0 >> (8 * k)) & 0xffu;
-                c0 = x >> 4;
-                if (2 * b + 1 < len)
-                    c1 = x & 15u;
-            }
-        } else {
-            // raw_code, LevMyers64.cpp:50-60: ACGT 0..3, N 4, anything else 6
-            auto code = [](uint32_t ch) -> uint32_t {
-                return ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : ch == 'N' ? 4u : 6u;
-            };
-            const uint32_t pair = ((k < 2 ? in0 : in1) >> (16 * (k & 1u))) & 0xffffu;
-            if (2 * b < len)
-                c0 = code(pair & 0xffu);
-            if (2 * b + 1 < len)
-                c1 = code(pair >> 8);
-        }
-        out |= ((c0 << 4) | c1) << (8 * k);
+        for (int q = 0; q < 9; ++q)
+            a[q] = (q < 5 || ascii) ? adw[q] : 0u;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            in[q] = __builtin_amdgcn_alignbyte(a[q + 1], a[q], sh);
     }
-    *reinterpret_cast<uint32_t*>(codes + code_off[read] + 4ull * d) = out;
+    uint32_t outv[4];
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) {
+        const uint32_t d = d0 + j;
+        uint32_t out = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t b = 4 * d + k;   // output byte: symbols 2b (high nibble) and 2b + 1
+            uint32_t c0 = 15, c1 = 15;      // padding: code 15
+            if (!ascii) {
+                if (2 * b < len) {
+                    const uint32_t x = (in[j] >> (8 * k)) & 0xffu;
+                    c0 = x >> 4;
+                    if (2 * b + 1 < len)
+                        c1 = x & 15u;
+                }
+            } else {
+                // raw_code, LevMyers64.cpp:50-60: ACGT 0..3, N 4, anything else 6
+                auto code = [](uint32_t ch) -> uint32_t {
+                    return ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : ch == 'N' ? 4u : 6u;
+                };
+                const uint32_t pair = (in[2 * j + (k >> 1)] >> (16 * (k & 1u))) & 0xffffu;
+                if (2 * b < len)
+                    c0 = code(pair & 0xffu);
+                if (2 * b + 1 < len)
+                    c1 = code(pair >> 8);
+            }
+            out |= ((c0 << 4) | c1) << (8 * k);
+        }
+        outv[j] = out;
+    }
+    uint32_t* dst = reinterpret_cast<uint32_t*>(codes + code_off[read]) + d0;
+    if (d0 + 4 <= padded_dw) {
+        const wamd_u32x4 v = {outv[0], outv[1], outv[2], outv[3]};
+        *reinterpret_cast<wamd_u32x4_a4*>(dst) = v;
+    } else {
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j)
+            if (d0 + j < padded_dw)
+                dst[j] = outv[j];
+    }
 }
 
 // Eight symbols i0 .. i0+7 of a read in the orientation asked for, symbol k at bits 4k; symbols
@@ -260,7 +285,7 @@ int launch_reads_prepare(wamd_ctx* ctx, wamd_reads* r, const uint8_t* d_raw,
     (void)ctx;
     const uint32_t dwords_per_read = ((r->max_len + 1) / 2 + 3) / 4;
     {
-        const uint64_t threads = (uint64_t)r->n * dwords_per_read;
+        const uint64_t threads = (uint64_t)r->n * ((dwords_per_read + 3) / 4);
         const uint32_t blocks = (uint32_t)((threads + 255) / 256);
         hipLaunchKernelGGL(canonical_codes_kernel, dim3(blocks), dim3(256), 0, s, d_raw, d_raw_off,
                            r->d_lens, r->d_code_off, r->n, dwords_per_read,
