@@ -538,6 +538,20 @@ WAMD_API int wamd_emit_lev_records_dev(wamd_ctx* ctx, uint32_t n, const wamd_dis
                                        const uint8_t* d_direction, uint8_t* d_records, uint32_t* d_count,
                                        void* d_scratch, void* stream);
 
+/* The same emission for callers that cannot allocate device memory or bring a scratch
+ * buffer: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.
+ * No counterpart in the reference.  The block counts of the record scan live in a static
+ * device array of the library (256.25 KiB per GPU, held until the process ends) instead of
+ * d_scratch; the call allocates nothing and is asynchronous on `stream`.  Output is byte for
+ * byte that of wamd_emit_lev_records_dev.  n above WAMD_STATIC_RECORDS_MAX_TASKS fails with
+ * WAMD_ERR_CAPACITY.  All calls on one GPU share the array: calls that overlap in time on one
+ * GPU (two streams, two contexts of one device) race - serialise them. */
+#define WAMD_STATIC_RECORDS_MAX_TASKS (1u << 24)
+WAMD_API int wamd_emit_lev_records_static_dev(wamd_ctx* ctx, uint32_t n, const wamd_dist_task* d_tasks,
+                                              const wamd_dist_result* d_results, const uint32_t* d_record_pos,
+                                              const uint8_t* d_direction, uint8_t* d_records, uint32_t* d_count,
+                                              void* stream);
+
 #ifdef __cplusplus
 }
 #endif

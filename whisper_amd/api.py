@@ -92,6 +92,7 @@ EXPORTS = [
     "wamd_clip_overlapping_pairs", "wamd_clip_overlapping_pairs_dev", "wamd_softclip_match",
     "wamd_softclip_match_dev", "wamd_serialize_mappings",
     "wamd_serialize_mappings_dev", "wamd_sam_cigar", "wamd_sam_cigar_dev", "wamd_records_scratch_bytes", "wamd_emit_lev_records_dev",
+    "wamd_emit_lev_records_static_dev",
 ]
 
 
@@ -375,6 +376,13 @@ class Context:
         _check(lib().wamd_emit_lev_records_dev(self.h, C.c_uint32(n), _ptr(d_tasks), _ptr(d_results),
                                                _ptr(d_record_pos), _ptr(d_direction), _ptr(d_records),
                                                _ptr(d_count), _ptr(d_scratch), C.c_void_p(stream or 0)))
+
+    def emit_lev_records_static_dev(self, n, d_tasks, d_results, d_record_pos, d_direction, d_records, d_count,
+                                    stream=None):
+        """The no-alloc form: scratch in the library's static device array (n <= 2^24)."""
+        _check(lib().wamd_emit_lev_records_static_dev(self.h, C.c_uint32(n), _ptr(d_tasks), _ptr(d_results),
+                                                      _ptr(d_record_pos), _ptr(d_direction), _ptr(d_records),
+                                                      _ptr(d_count), C.c_void_p(stream or 0)))
 
     def indel_match_dev(self, reads, d_tasks, n, d_results, params=None, stream=None):
         prm = params or default_indel_params()

@@ -5,6 +5,8 @@
 // One record per lane.  All three are byte-stream scans with a handful of double adds
 // in a fixed order, so they are HBM/latency bound; they exist on the device so that
 // ext-CIGARs produced by the align kernels need not travel to the host and back.
+#include <mutex>
+
 #include "wamd_internal.h"
 
 namespace wamd {
@@ -831,6 +833,53 @@ int launch_emit_lev_records(wamd_ctx* ctx, uint32_t n, const wamd_dist_task* d_t
                        d_direction, counts, d_records);
     WAMD_HIP(hipGetLastError());
     return WAMD_OK;
+}
+
+// ---- the same emission for callers that cannot allocate (wamd_emit_lev_records_static_dev) ----
+// The block counts of the record scan live in a file-scope device array instead of a caller
+// buffer.  Every GPU holds its own copy at its own address: the address is looked up once per
+// device (records_static_init, called by wamd_ctx_create with that device current) and only that
+// pointer is ever handed to a kernel - the array's name is a host-side stand-in here.
+// Nothing in it must start at zero: the count kernel rewrites words [0, nb) before the scan reads
+// them.  Calls that overlap on one GPU share the array and race.
+constexpr uint32_t REC_STATIC_WORDS = WAMD_STATIC_RECORDS_MAX_TASKS / 256 + 64;   // 256.25 KiB
+static __device__ __align__(256) uint32_t scratch[REC_STATIC_WORDS];
+constexpr int REC_MAX_DEVICES = 64;
+static uint32_t* g_scratch_ptr[REC_MAX_DEVICES];
+static std::mutex g_scratch_lock;
+
+int records_static_init(int device)
+{
+    if (device < 0 || device >= REC_MAX_DEVICES)
+        return WAMD_OK;   // such a device simply has no static form (the entry point says so)
+    std::lock_guard<std::mutex> hold(g_scratch_lock);
+    if (g_scratch_ptr[device])
+        return WAMD_OK;
+    uint32_t* ptr = nullptr;
+    WAMD_HIP(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
+    g_scratch_ptr[device] = ptr;
+    return WAMD_OK;
+}
+
+int launch_emit_lev_records_static(wamd_ctx* ctx, uint32_t n, const wamd_dist_task* d_tasks,
+                                   const wamd_dist_result* d_results, const uint32_t* d_record_pos,
+                                   const uint8_t* d_direction, uint8_t* d_records, uint32_t* d_count, hipStream_t s)
+{
+    if (n > WAMD_STATIC_RECORDS_MAX_TASKS) {
+        set_error("wamd_emit_lev_records_static_dev: %u tasks, the static scratch holds %u at most", n,
+                  WAMD_STATIC_RECORDS_MAX_TASKS);
+        return WAMD_ERR_CAPACITY;
+    }
+    uint32_t* ptr = nullptr;
+    if (ctx->device >= 0 && ctx->device < REC_MAX_DEVICES) {
+        std::lock_guard<std::mutex> hold(g_scratch_lock);
+        ptr = g_scratch_ptr[ctx->device];
+    }
+    if (!ptr) {
+        set_error("wamd_emit_lev_records_static_dev: no static scratch on device %d", ctx->device);
+        return WAMD_ERR_CAPACITY;
+    }
+    return launch_emit_lev_records(ctx, n, d_tasks, d_results, d_record_pos, d_direction, d_records, d_count, ptr, s);
 }
 
 int launch_indel_ext_cigar(wamd_ctx* ctx, const wamd_reads* r, const wamd_indel_cigar_task* d_tasks,

@@ -183,6 +183,11 @@ static int ctx_create_common(int device, const uint8_t* genome, bool on_device, 
         return WAMD_ERR_INVALID_ARG;
     }
     WAMD_HIP(hipSetDevice(device));
+    {   // this device's address of the static scratch of wamd_emit_lev_records_static_dev
+        int rc0 = records_static_init(device);
+        if (rc0)
+            return rc0;
+    }
     wamd_ctx* c = new wamd_ctx();
     memset(c, 0, sizeof(*c));
     c->device = device;
@@ -960,6 +965,22 @@ int wamd_emit_lev_records_dev(wamd_ctx* ctx, uint32_t n, const wamd_dist_task* d
         return WAMD_ERR_INVALID_ARG;
     return launch_emit_lev_records(ctx, n, d_tasks, d_results, d_record_pos, d_direction, d_records, d_count,
                                    d_scratch, pick(ctx, stream));
+}
+
+int wamd_emit_lev_records_static_dev(wamd_ctx* ctx, uint32_t n, const wamd_dist_task* d_tasks,
+                                     const wamd_dist_result* d_results, const uint32_t* d_record_pos,
+                                     const uint8_t* d_direction, uint8_t* d_records, uint32_t* d_count, void* stream)
+{
+    if (!ctx || !d_count)
+        return WAMD_ERR_INVALID_ARG;
+    if (n == 0) {
+        WAMD_HIP(hipMemsetAsync(d_count, 0, sizeof(uint32_t), pick(ctx, stream)));
+        return WAMD_OK;
+    }
+    if (!d_tasks || !d_results || !d_record_pos || !d_direction || !d_records || ((uintptr_t)d_records & 3u))
+        return WAMD_ERR_INVALID_ARG;
+    return launch_emit_lev_records_static(ctx, n, d_tasks, d_results, d_record_pos, d_direction, d_records, d_count,
+                                          pick(ctx, stream));
 }
 
 } // extern "C"

@@ -166,6 +166,11 @@ int launch_emit_lev_records(wamd_ctx* ctx, uint32_t n, const wamd_dist_task* d_t
                             const uint8_t* d_direction, uint8_t* d_records, uint32_t* d_count, void* d_scratch,
                             hipStream_t s);
 
+int records_static_init(int device);   // with `device` current; once per device
+int launch_emit_lev_records_static(wamd_ctx* ctx, uint32_t n, const wamd_dist_task* d_tasks,
+                                   const wamd_dist_result* d_results, const uint32_t* d_record_pos,
+                                   const uint8_t* d_direction, uint8_t* d_records, uint32_t* d_count, hipStream_t s);
+
 #ifdef __HIPCC__
 // ---- device helpers -------------------------------------------------------------
 
