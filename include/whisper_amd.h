@@ -13,7 +13,10 @@
  *   - "*_dev" entry points take DEVICE pointers and a hipStream_t passed as
  *     void*; they are asynchronous on that stream and allocate nothing;
  *   - the other entry points take HOST pointers, stage through the context's
- *     pinned buffers and return when the results are in the caller's memory;
+ *     buffers and return when the results are in the caller's memory; they may be
+ *     called from several threads on one context (a lock inside the context
+ *     serialises them - threads that want to overlap use one context each over
+ *     wamd_ctx_create_dev, or the "*_dev" forms on streams of their own);
  *   - symbol codes are the reference's: A 0, C 1, G 2, T 3, N_read 4,
  *     N_ref 5 (common/defs.h:55-60); the genome is the reference's own
  *     packed layout: two 4-bit symbols per byte, even position in the HIGH
@@ -174,6 +177,11 @@ typedef struct wamd_mapping {
 typedef struct wamd_indel_params {
     wamd_scoring scoring;
     double min_clipped_factor;     /* mapper/params.h:158: 1.0                          */
+    uint32_t max_indel_bound;      /* wamd_indel_match_dev only: an upper bound of max_indel_size   */
+                                   /* over the batch (params->max_approx_indel_len at both call     */
+                                   /* sites, mapper/params.h:135: 50); it picks the kernel and sizes */
+                                   /* its LDS.  0 = 80.  The host-pointer form scans the tasks.      */
+    uint32_t reserved;
 } wamd_indel_params;
 
 /* Input of CIndelMatching::GetExtCigarNew (indels.cpp:938-957) as called from
@@ -260,7 +268,9 @@ WAMD_API int wamd_device_count(void);
  * The genome is uploaded once and stays resident in HBM. */
 WAMD_API int wamd_ctx_create(int device, const uint8_t* genome, uint64_t genome_bytes,
                              uint32_t ref_size, uint32_t cur_offset, wamd_ctx** out);
-/* Same, for a genome already resident on the device (not copied, not owned). */
+/* Same, for a genome already resident on the device (not copied, not owned).  The kernels
+ * read it as whole dwords: d_genome must be 4-byte aligned and genome_bytes a multiple of 4
+ * (pad with 0xff = two symbols that match nothing), else WAMD_ERR_INVALID_ARG. */
 WAMD_API int wamd_ctx_create_dev(int device, const uint8_t* d_genome, uint64_t genome_bytes,
                                  uint32_t ref_size, uint32_t cur_offset, wamd_ctx** out);
 WAMD_API int wamd_ctx_destroy(wamd_ctx* ctx);

@@ -74,11 +74,12 @@ class Scoring(C.Structure):  # noqa: E302
 
 
 class IndelParams(C.Structure):
-    _fields_ = [("scoring", Scoring), ("min_clipped_factor", C.c_double)]
+    _fields_ = [("scoring", Scoring), ("min_clipped_factor", C.c_double), ("max_indel_bound", C.c_uint32),
+                ("reserved", C.c_uint32)]
 
 
 def default_indel_params(min_clipped_factor=1.0):
-    return IndelParams(default_scoring(), min_clipped_factor)
+    return IndelParams(default_scoring(), min_clipped_factor, 0, 0)
 
 
 def default_scoring():

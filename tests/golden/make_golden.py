@@ -110,11 +110,83 @@ def make_softclip(ref, codes, packed):
         print(name, "found", int(res["found"].sum()), "of", n, "indels", int((res["del_size"] != 0).sum()))
 
 
+def make_round2(ref, codes, packed, ref_size):
+    """Shapes no round-1 fixture reached: LevDiag beyond 160 symbols (BASELINE configs[4] runs it in
+    stages 1-4 at 250 bp; 300 / 600 bp for the two widest kernel instantiations), the long-indel
+    matcher on reads above 256 symbols and with max_indel_size above 80, the untrained-model
+    rescue window W = 1427 (sam.cpp:185-188), the CF pre-filter at min_read_len = 250 and the 250 bp
+    k = 7 stage.  Own seeds, so the older fixtures stay byte for byte what they were."""
+    seed = 5000
+    lev = [("lev_m250_k%d_seg%d" % (k, j), 250, k, j, 300) for k in (1, 2, 3, 4) for j in range(k + 1)]
+    lev += [("lev_m300_k4_seg1", 300, 4, 1, 300), ("lev_m300_k6_seg6", 300, 6, 6, 300),
+            ("lev_m600_k6_seg0", 600, 6, 0, 200), ("lev_m600_k5_seg3", 600, 5, 3, 200)]
+    for name, m, k, j, n in lev:
+        seed += 1
+        fl, fr = common.stage_segments(m, k)[j]
+        rd = synth.make_reads(codes, n, m, k, seed, rc_frac=0.0, protect=(fl, fr))
+        blob, off, lens = common.host_reads(rd, 0)
+        tasks = synth.levdiag_tasks(rd, k, fl, fr, 0)
+        rc, res = ref.levdiag(packed, ref_size, 0, blob, off, lens, tasks)
+        assert rc == 0
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), kind="levdiag", blob=blob, off=off,
+                            lens=lens, tasks=tasks, results=res, cur_offset=0)
+        print(name, "accepted", int((res <= k).sum()), "of", n)
+    for name, m, max_indel, max_mm, stage, mcf, n in [("indel_m300_maxindel50", 300, 50, 20, 8, 1.0, 500),
+                                                      ("indel_m150_maxindel100", 150, 100, 12, 5, 0.6, 500)]:
+        seed += 1
+        _, _, (blob, off, lens), tasks = common.indel_workload(n, m, seed, max_indel=max_indel, max_mm=max_mm,
+                                                               stage_major=stage, gen=(codes, packed))
+        prm = bindings.default_indel_params(mcf)
+        rc, res = ref.indel_match(packed, blob, off, lens, 0, tasks, prm)
+        ct = common.indel_cigar_tasks(tasks, res)
+        stride = 4 * ((2 * (m + 2 * max_indel) + 16 + 3) // 4)
+        rc, cres, ccig = ref.indel_ext_cigar(packed, blob, off, lens, 0, ct, max_indel=max_indel, cigar_stride=stride)
+        direction = (np.arange(len(res)) % 3 != 0).astype(np.uint8)
+        rc, wire, sizes = ref.serialize(res, direction)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), kind="indel", blob=blob, off=off, lens=lens,
+                            encoding=0, min_clipped_factor=mcf, tasks=tasks, results=res,
+                            cigar_tasks=ct, cigar_results=cres, cigars=ccig, cigar_stride=stride,
+                            direction=direction, wire=wire, wire_sizes=sizes)
+        print(name, "found", int(res["found"].sum()), "types", np.bincount(res["type"][res["found"] == 1], minlength=9))
+    for name, m, k, W, n in [("align_m150_k26_w1427", 150, 26, 1427, 400), ("align_m250_k44_w1500", 250, 44, 1500, 200)]:
+        seed += 1
+        rd = synth.make_reads(codes, n, m, k, seed)
+        blob, off, lens = common.host_reads(rd, 1)
+        tasks = synth.distance_tasks(rd, m, k, W, 0)
+        stride = 4 * ((2 * (m + k) + 8 + 3) // 4)
+        rc, res, cig = ref.align(packed, ref_size, blob, off, lens, 1, tasks, 0, 1, cigar_stride=stride)
+        assert rc == 0
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), kind="align", blob=blob, off=off,
+                            lens=lens, encoding=1, last_symbol=0, refine=1, tasks=tasks,
+                            results=res, cigars=cig, cigar_stride=stride)
+        print(name, "ok", int(res["ok"].sum()), "refined", int(res["refined"].sum()), "of", n)
+    for name, k, cur_offset, n in (("cf_m250_k7", 7, 0, 800), ("cf_m250_k3_off62", 3, 62, 600)):
+        _, _, (blob, off, lens), tasks = common.cf_workload(n, seed=5700 + k, min_len=250, k=k, cur_offset=cur_offset,
+                                                            gen=(codes, packed))
+        rc, res, ok = ref.cf_filter(packed, ref_size, cur_offset, blob, off, lens, tasks, max_diff=4 * k)
+        assert rc == 0
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), kind="cf", blob=blob, off=off, lens=lens, tasks=tasks,
+                            results=res, passed=ok, cur_offset=cur_offset, max_diff=4 * k)
+        print(name, "passed", int(ok.sum()), "of", n)
+    seed += 1
+    rd = synth.make_reads(codes, 600, 250, 7, seed)
+    blob, off, lens = common.host_reads(rd, 0)
+    tasks = synth.distance_tasks(rd, 250, 7, None, 0)
+    rc, res = ref.distance(packed, ref_size, blob, off, lens, 0, tasks, -1)
+    assert rc == 0
+    np.savez_compressed(os.path.join(HERE, "dist_m250_k7.npz"), kind="distance", blob=blob, off=off,
+                        lens=lens, encoding=0, last_symbol=-1, tasks=tasks, results=res)
+    print("dist_m250_k7 accepted", int((res["edit_distance"] <= 7).sum()), "of", 600)
+
+
 def main():
     ref = bindings.Reference()
     codes = synth.make_genome(GENOME_SYMBOLS, seed=GENOME_SEED)
     packed = synth.pack_nibbles(codes).numpy()
     ref_size = codes.numel()
+    if len(sys.argv) > 1 and sys.argv[1] == "round2":
+        make_round2(ref, codes, packed, ref_size)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "cf":   # only the fixtures of this family
         make_cf(ref, codes, packed, ref_size)
         return
@@ -198,6 +270,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "clip_m150.npz"), kind="clip", records=rec, cigars=cig,
                         out_records=rec2, out_cigars=cig2)
     print("clip_m150 changed", int((cig2 != cig).any(axis=1).sum()), "of", len(rec))
+    make_round2(ref, codes, packed, ref_size)
 
 
 if __name__ == "__main__":

@@ -118,6 +118,52 @@ def test_levdiag_stage_segments(ctx, oracle, k):
         np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("m,ks", [(250, (1, 2, 3, 4)), (200, (6,)), (300, (4, 6)), (512, (5,)), (600, (3, 6)),
+                                  (1000, (6,))])
+def test_levdiag_long_reads(ctx, oracle, m, ks):
+    """Reads above 160 symbols: levdiag_kernel<34,128> (161..256; BASELINE configs[4] runs LevDiag in
+    stages 1-4 at 250 bp), <66,64> (257..512) and <130,64> (513..1024), every stage segment."""
+    for k in ks:
+        for j, (fl, fr) in enumerate(common.stage_segments(m, k)):
+            codes, packed, (blob, off, lens), tasks = common.levdiag_workload(m, k, fl, fr, 1500,
+                                                                             seed=1200 + m + 10 * k + j)
+            rc, want = oracle.levdiag(packed, codes.numel(), 0, blob, off, lens, tasks)
+            reads = ctx.upload_reads(blob, off, lens, 0, orientations=1)
+            got = ctx.lev_diag(reads, tasks)
+            reads.free()
+            assert (want <= k).sum() > 150
+            np.testing.assert_array_equal(got, want)
+
+
+def test_levdiag_mixed_lengths(ctx, oracle):
+    """One batch holding reads of 40 .. 250 symbols: the kernel is picked by the longest read."""
+    import torch
+    codes, packed = common.genome()
+    g = torch.Generator().manual_seed(17)
+    reads_codes, tasks = [], []
+    for i in range(3000):
+        m = [40, 77, 100, 150, 161, 200, 249, 250][i % 8]
+        k = 1 + i % 6
+        fl, fr = common.stage_segments(m, k)[i % (k + 1)]
+        p = int(torch.randint(20000, 900000, (1,), generator=g))
+        r = codes[p:p + m].clone()
+        for _ in range(int(torch.randint(0, k + 2, (1,), generator=g))):
+            z = int(torch.randint(0, m, (1,), generator=g))
+            if not (fl <= z < fr):
+                r[z] = (int(r[z]) + 1) & 3
+        r[r > 3] = 4
+        reads_codes.append(r)
+        tasks.append((i, p, fl, fr, k, 1))
+    blob, off, lens = common.mixed_reads(reads_codes, 0)
+    tasks = np.array(tasks, api.LEVDIAG_TASK)
+    rc, want = oracle.levdiag(packed, codes.numel(), 0, blob, off, lens, tasks)
+    reads = ctx.upload_reads(blob, off, lens, 0, orientations=1)
+    got = ctx.lev_diag(reads, tasks)
+    reads.free()
+    assert (want <= tasks["max_mismatches"]).sum() > 800
+    np.testing.assert_array_equal(got, want)
+
+
 @pytest.mark.parametrize("k", [2, 4, 6])
 def test_levdiag_low_complexity(oracle, k):
     """Tandem repeats: many equally good alignments, anchors that extend far, runs that end
@@ -139,10 +185,12 @@ def test_levdiag_low_complexity(oracle, k):
         c.destroy()
 
 
-@pytest.mark.parametrize("k,cur_offset", [(5, 0), (1, 0), (6, 17)])
-def test_cf_filter(ctx, oracle, k, cur_offset):
+@pytest.mark.parametrize("k,cur_offset,min_len", [(5, 0, 150), (1, 0, 150), (6, 17, 150), (7, 0, 250), (3, 62, 250),
+                                                   (4, 9, 100), (8, 33, 300)])
+def test_cf_filter(ctx, oracle, k, cur_offset, min_len):
     """Row C: dinucleotide histograms, both strands, odd / even window starts, ragged read lengths."""
-    codes, packed, (blob, off, lens), tasks = common.cf_workload(6000, seed=60 + k, k=k, cur_offset=cur_offset)
+    codes, packed, (blob, off, lens), tasks = common.cf_workload(6000, seed=60 + k, k=k, cur_offset=cur_offset,
+                                                                 min_len=min_len)
     rc, want = oracle.cf_filter(packed, codes.numel(), cur_offset, blob, off, lens, tasks)
     assert rc == 0
     ctx.set_reference_params(codes.numel(), cur_offset)
@@ -196,6 +244,9 @@ ALIGN_CASES = [
     (150, 12, None, 3, 1, 0),
     (150, 12, None, 0, 1, 1),       # M64 on a short read
     (60, 40, None, 0, 1, 0),        # ed > 30 with a single word: whole columns kept
+    (150, 26, 1427, 0, 1, 0),       # rescue window before the insert-size model is trained (sam.cpp:185-188)
+    (250, 44, 1588, 0, 1, 0),       # the same at 250 bp: 500 + 7 * 125 + 2 * 44 ... and beyond
+    (150, 26, 16384, 0, 0, 0),      # max_text_len itself
 ]
 
 
@@ -241,19 +292,25 @@ def test_align(ctx, oracle, m, k, W, last, refine, variant):
         assert bytes(gcig[i, :n + 1]) == bytes(wcig[i, :n + 1]), i
 
 
-@pytest.mark.parametrize("m,enc,mcf,stage", [(150, 0, 1.0, 5), (150, 1, 0.6, 5), (100, 0, 0.5, 4), (250, 0, 1.0, 4)])
-def test_indel_match_chain(ctx, oracle, m, enc, mcf, stage):
+@pytest.mark.parametrize("m,enc,mcf,stage,max_indel", [(150, 0, 1.0, 5, 50), (150, 1, 0.6, 5, 50), (100, 0, 0.5, 4, 50),
+                                                        (250, 0, 1.0, 4, 50),
+                                                        (300, 0, 0.6, 8, 50),      # reads above 256: indel_match_kernel<false>
+                                                        (150, 0, 0.6, 5, 100),     # max_indel_size above 80: the same
+                                                        (150, 0, 0.6, 5, 80),      # the staged kernel's largest
+                                                        (600, 1, 0.7, 8, 120)])
+def test_indel_match_chain(ctx, oracle, m, enc, mcf, stage, max_indel):
     """Match -> GetExtCigarNew -> serialize, each against the oracle."""
     from oracle import bindings
-    codes, packed, (blob, off, lens), tasks = common.indel_workload(2000, m, seed=400 + m + enc, encoding=enc,
-                                                                   stage_major=stage)
+    codes, packed, (blob, off, lens), tasks = common.indel_workload(2000, m, seed=400 + m + enc + max_indel, encoding=enc,
+                                                                   stage_major=stage, max_indel=max_indel,
+                                                                   max_mm=12 if m <= 250 else 20)
     _, want = oracle.indel_match(packed, blob, off, lens, enc, tasks, bindings.default_indel_params(mcf))
     reads = ctx.upload_reads(blob, off, lens, enc, orientations=1)
     got = ctx.indel_match(reads, tasks, api.default_indel_params(mcf))
     assert want["found"].sum() > 500
     np.testing.assert_array_equal(got, want)
     ct = common.indel_cigar_tasks(tasks, want)
-    stride = 4 * ((2 * (m + 120) + 8 + 3) // 4)
+    stride = 4 * ((2 * (m + 2 * max_indel + 20) + 8 + 3) // 4)
     _, wres, wcig = oracle.indel_ext_cigar(packed, blob, off, lens, enc, ct, cigar_stride=stride)
     gres, gcig = ctx.indel_ext_cigar(reads, ct, cigar_stride=stride)
     reads.free()

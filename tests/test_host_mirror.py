@@ -35,11 +35,32 @@ def test_replay_matches_oracle(tmp_path, oracle):
     ltasks["fixed_left"], ltasks["fixed_right"] = fl, fr
     ltasks["max_mismatches"] = 5
     ltasks["dir_gen_flag"] = 1
+    # The reference's rc branch (mapping_core_sa.cpp:289-291): the pattern is rc_data, handed to
+    # preprocess() as genome_t::direct like on the other strand; the window comes from a position in
+    # the other strand's suffix array, g0 = ref_size - position - m + cur_offset - k.  Every other
+    # task is such a call: same stored symbols, dir_gen_flag = 0, and the distance task's ref_pos
+    # written the way :289 computes it.  cur_offset = the anchor's start (mapping_core.cpp:156).
+    ref_size, cur_offset = codes.numel(), fl
+    p = dtasks["ref_pos"].astype(np.int64) + k
+    ltasks["position_in_text"] = p + cur_offset
+    rcb = np.arange(len(dtasks)) % 2 == 1
+    sa_rc = ref_size - p - m + cur_offset
+    ltasks["position_in_text"][rcb] = sa_rc[rcb]
+    ltasks["dir_gen_flag"][rcb] = 0
+    dtasks["ref_pos"][rcb] = (ref_size - sa_rc - m + cur_offset - k)[rcb]
     _, want_d = oracle.distance(packed, blob, off, lens, 0, dtasks, -1)
-    _, want_l = oracle.levdiag(packed, codes.numel(), 0, blob, off, lens, ltasks)
+    _, want_l = oracle.levdiag(packed, ref_size, cur_offset, blob, off, lens, ltasks)
+    assert (want_l[rcb] <= 5).sum() > 200 and (want_l[~rcb] <= 5).sum() > 200
+    from oracle import bindings
+    if bindings.have_reference():      # the reference's own objects agree on both strands
+        ref = bindings.Reference()
+        _, ref_d = ref.distance(packed, ref_size, blob, off, lens, 0, dtasks, -1)
+        _, ref_l = ref.levdiag(packed, ref_size, cur_offset, blob, off, lens, ltasks)
+        np.testing.assert_array_equal(ref_d, want_d)
+        np.testing.assert_array_equal(ref_l, want_l)
     fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
     with open(fin, "wb") as f:
-        f.write(struct.pack("<4I", codes.numel(), 0, m, len(lens)))
+        f.write(struct.pack("<4I", ref_size, cur_offset, m, len(lens)))
         f.write(_vec(packed))
         f.write(_vec(blob))
         f.write(_vec(dtasks))
@@ -61,3 +82,40 @@ def test_replay_matches_oracle(tmp_path, oracle):
     np.testing.assert_array_equal(got_a[~rej, 1], want_d["pos"][~rej])
     assert (got_a[rej, 0] == k + 1).all() and (got_a[rej, 1] == 0).all()
     np.testing.assert_array_equal(raw[2 * len(dtasks):], want_l)
+
+
+@pytest.mark.gpu
+def test_two_threads_flush_on_one_context(oracle):
+    """INTEGRATION section 3 shares one context between the worker threads, each flushing its own
+    batches through the host-pointer entry points: the context's lock must keep their staging
+    apart (ctypes releases the GIL during a call, so the two threads really overlap)."""
+    import threading
+    from whisper_amd import api
+    codes, packed = common.genome()
+    ctx = api.Context(packed, ref_size=codes.numel(), cur_offset=0)
+    errors = []
+
+    def worker(seed0, sizes):
+        try:
+            for j, n in enumerate(sizes):
+                _, _, (blob, off, lens), tasks = common.distance_workload(150, 12, n, seed=seed0 + j)
+                _, want = oracle.distance(packed, blob, off, lens, 0, tasks, -1)
+                reads = ctx.upload_reads(blob, off, lens, 0, orientations=3)
+                for _ in range(3):
+                    got = ctx.dynamic_programming(reads, tasks)
+                    if not (got == want).all():
+                        errors.append("thread %d batch %d differs" % (seed0, j))
+                reads.free()
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+
+    try:
+        ts = [threading.Thread(target=worker, args=(500, [3000, 700, 9000, 50, 4000])),
+              threading.Thread(target=worker, args=(600, [900, 8000, 60, 5000, 2500]))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+    finally:
+        ctx.destroy()
+    assert not errors, errors

@@ -9,7 +9,8 @@ SHAPES = [(150, 12, None, 0, 0, -1), (150, 12, None, 0, 1, 0), (150, 12, None, 0
           (250, 17, None, 0, 0, -1), (100, 10, None, 0, 0, -1), (300, 20, None, 0, 0, -1),
           (64, 6, None, 0, 0, -1), (65, 6, None, 0, 0, -1), (127, 8, None, 0, 0, -1),
           (128, 8, None, 0, 0, -1), (255, 10, None, 0, 0, -1), (256, 10, None, 0, 0, -1),
-          (150, 12, None, 1, 0, -1), (150, 26, 660, 0, 1, 0), (250, 44, 700, 0, 1, 0)]
+          (150, 12, None, 1, 0, -1), (150, 26, 660, 0, 1, 0), (250, 44, 700, 0, 1, 0),
+          (250, 7, None, 0, 0, -1), (150, 26, 1427, 0, 1, 0)]
 
 
 @pytest.mark.parametrize("m,k,W,variant,enc,last", SHAPES)
@@ -40,6 +41,19 @@ def test_levdiag(oracle, reference, k):
         np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize("m,ks", [(250, (1, 2, 3, 4)), (300, (4, 6)), (600, (3, 6)), (1000, (6,))])
+def test_levdiag_long_reads(oracle, reference, m, ks):
+    """The shapes of the GPU test of the same name (reads beyond 160 symbols; 250 bp = BASELINE configs[4])."""
+    for k in ks:
+        for j, (fl, fr) in enumerate(common.stage_segments(m, k)):
+            codes, packed, (blob, off, lens), tasks = common.levdiag_workload(m, k, fl, fr, 1500,
+                                                                             seed=1200 + m + 10 * k + j)
+            _, a = oracle.levdiag(packed, codes.numel(), 0, blob, off, lens, tasks)
+            _, b = reference.levdiag(packed, codes.numel(), 0, blob, off, lens, tasks)
+            assert (a <= k).sum() > 150
+            np.testing.assert_array_equal(a, b)
+
+
 @pytest.mark.parametrize("k", [2, 4, 6])
 def test_levdiag_low_complexity(oracle, reference, k):
     """The same tandem-repeat workload the GPU test uses: pins the oracle where alignments are ambiguous."""
@@ -56,7 +70,8 @@ def test_levdiag_low_complexity(oracle, reference, k):
 @pytest.mark.parametrize("m,k,W,last,refine", [(150, 12, None, 0, 1), (150, 13, 177, 0, 1),
                                                (150, 26, 660, 0, 1), (250, 17, None, 0, 1),
                                                (100, 10, None, 0, 0), (300, 20, None, 0, 1),
-                                               (150, 12, None, 3, 1)])
+                                               (150, 12, None, 3, 1), (150, 26, 1427, 0, 1),
+                                               (250, 44, 1588, 0, 1)])
 def test_align(oracle, reference, m, k, W, last, refine):
     codes, packed, (blob, off, lens), tasks = common.distance_workload(m, k, 4000, seed=7 * m + k,
                                                                       encoding=1, W=W)
@@ -106,6 +121,26 @@ def test_indel_match_m100_and_m250(oracle, reference):
         np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize("m,enc,mcf,stage,max_indel", [(300, 0, 0.6, 8, 50), (150, 0, 0.6, 5, 100), (150, 0, 0.6, 5, 80),
+                                                        (600, 1, 0.7, 8, 120)])
+def test_indel_match_long_reads_and_wide_indels(oracle, reference, m, enc, mcf, stage, max_indel):
+    """The shapes that run indel_match_kernel<false> on the GPU (reads above 256, max_indel_size above 80)."""
+    from oracle import bindings
+    codes, packed, (blob, off, lens), tasks = common.indel_workload(2000, m, seed=400 + m + enc + max_indel, encoding=enc,
+                                                                   stage_major=stage, max_indel=max_indel,
+                                                                   max_mm=12 if m <= 250 else 20)
+    prm = bindings.default_indel_params(mcf)
+    _, a = oracle.indel_match(packed, blob, off, lens, enc, tasks, prm)
+    _, b = reference.indel_match(packed, blob, off, lens, enc, tasks, prm)
+    assert b["found"].sum() > 500
+    np.testing.assert_array_equal(a, b)
+    ct = common.indel_cigar_tasks(tasks, b)
+    _, ra, ca = oracle.indel_ext_cigar(packed, blob, off, lens, enc, ct, cigar_stride=2048)
+    _, rb, cb = reference.indel_ext_cigar(packed, blob, off, lens, enc, ct, max_indel=max_indel, cigar_stride=2048)
+    np.testing.assert_array_equal(ra, rb)
+    np.testing.assert_array_equal(ca, cb)
+
+
 def test_clip_boundary(oracle, reference):
     rec, cig = common.clip_workload(2500, 150, seed=17)
     _, ra, ca = oracle.clip_boundary(rec, cig)
@@ -117,9 +152,11 @@ def test_clip_boundary(oracle, reference):
     np.testing.assert_array_equal(ca, cb)
 
 
-@pytest.mark.parametrize("k,cur_offset", [(5, 0), (2, 0), (5, 31)])
-def test_cf_filter(oracle, reference, k, cur_offset):
-    codes, packed, (blob, off, lens), tasks = common.cf_workload(3000, seed=40 + k, k=k, cur_offset=cur_offset)
+@pytest.mark.parametrize("k,cur_offset,min_len", [(5, 0, 150), (2, 0, 150), (5, 31, 150), (7, 0, 250), (3, 62, 250),
+                                                   (4, 9, 100), (8, 33, 300)])
+def test_cf_filter(oracle, reference, k, cur_offset, min_len):
+    codes, packed, (blob, off, lens), tasks = common.cf_workload(3000, seed=40 + k, k=k, cur_offset=cur_offset,
+                                                                 min_len=min_len)
     rc1, a = oracle.cf_filter(packed, codes.numel(), cur_offset, blob, off, lens, tasks)
     rc2, b, ok = reference.cf_filter(packed, codes.numel(), cur_offset, blob, off, lens, tasks, max_diff=4 * k)
     assert rc1 == 0 and rc2 == 0

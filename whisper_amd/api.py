@@ -102,12 +102,13 @@ class Scoring(C.Structure):
 
 
 class IndelParams(C.Structure):
-    _fields_ = [("scoring", Scoring), ("min_clipped_factor", C.c_double)]
+    _fields_ = [("scoring", Scoring), ("min_clipped_factor", C.c_double), ("max_indel_bound", C.c_uint32),
+                ("reserved", C.c_uint32)]
 
 
 def default_indel_params(min_clipped_factor=1.0):
     # mapper/params.h:145-158
-    return IndelParams(Scoring(1.0, -5.0, -5.0, -0.4, -5.0, -0.4, -6.0), min_clipped_factor)
+    return IndelParams(Scoring(1.0, -5.0, -5.0, -0.4, -5.0, -0.4, -6.0), min_clipped_factor, 0, 0)
 
 
 class WamdError(RuntimeError):

@@ -619,10 +619,11 @@ int launch_indel_match(wamd_ctx* ctx, const wamd_reads* r, const wamd_indel_task
     const ReadsView rv = r->view();
     const int ascii = r->encoding == WAMD_READS_ASCII;
     const uint32_t hit_bytes = 2 * IM_HITS * 2 * 64;   // seed-hit lists: two sides, uint16 per hit and lane
-    // staged variant: reads up to 256 symbols with max_indel up to 80; tasks beyond that are
-    // flagged by the kernel, so pick the unstaged one when the batch has longer reads
-    if (r->max_len <= IM_MAX_READ) {
-        const uint32_t text_dw = (r->max_len + 2 * IM_MAX_INDEL + 2 + 7) / 8 + 1;
+    // staged variant: reads up to 256 symbols with max_indel up to 80, LDS sized by the batch's bound
+    // (a task beyond the bound is flagged by the kernel); anything larger runs unstaged
+    const uint32_t bound = prm->max_indel_bound ? prm->max_indel_bound : IM_MAX_INDEL;
+    if (r->max_len <= IM_MAX_READ && bound <= IM_MAX_INDEL) {
+        const uint32_t text_dw = (r->max_len + 2 * bound + 2 + 7) / 8 + 1;
         const uint32_t seq_bytes = (text_dw + (r->max_len + 7) / 8 + 1) * 4 * 64;
         hipLaunchKernelGGL(indel_match_kernel<true>, dim3(blocks), dim3(64), seq_bytes + hit_bytes, s, ctx->d_genome,
                            2 * ctx->genome_bytes, rv, ascii, d_tasks, n, kp, text_dw, seq_bytes, d_results,

@@ -101,6 +101,7 @@ static int clip_pass_host(wamd_ctx* ctx, uint32_t n_tasks, uint32_t n_records, c
     if (!ctx || !tasks || !records || !cigars || cigar_stride < 2)
         return WAMD_ERR_INVALID_ARG;
     WAMD_HIP(hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> hold(ctx->host_mutex);
     auto up = [](uint64_t x) { return (x + 255) / 256 * 256; };
     const uint64_t tb = (uint64_t)n_tasks * sizeof(Task), rb = (uint64_t)n_records * sizeof(wamd_clip_record),
                    cb = (uint64_t)n_records * cigar_stride;
@@ -188,8 +189,7 @@ static int ctx_create_common(int device, const uint8_t* genome, bool on_device, 
         if (rc0)
             return rc0;
     }
-    wamd_ctx* c = new wamd_ctx();
-    memset(c, 0, sizeof(*c));
+    wamd_ctx* c = new wamd_ctx();   // value-initialised: every plain member starts at zero
     c->device = device;
     c->genome_bytes = genome_bytes;
     c->ref_size = ref_size;
@@ -204,6 +204,12 @@ static int ctx_create_common(int device, const uint8_t* genome, bool on_device, 
             break;
         }
         if (on_device) {
+            if ((genome_bytes & 3u) || ((uintptr_t)genome & 3u)) {
+                set_error("wamd_ctx_create_dev: a borrowed genome is read as dwords - 4-byte aligned, a multiple of "
+                          "4 bytes (pad with 0xff)");
+                rc = WAMD_ERR_INVALID_ARG;
+                break;
+            }
             c->d_genome = const_cast<uint8_t*>(genome);
             c->owns_genome = false;
         } else {
@@ -322,6 +328,7 @@ int wamd_ctx_take_flags(wamd_ctx* ctx, void* stream, uint32_t* flags)
     if (!ctx || !flags)
         return WAMD_ERR_INVALID_ARG;
     WAMD_HIP(hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> hold(ctx->host_mutex);   // h_flags is one pinned word per context
     return fetch_flags(ctx, stream ? (hipStream_t)stream : ctx->stream, flags);
 }
 
@@ -478,6 +485,7 @@ int wamd_verify_distance(wamd_ctx* ctx, const wamd_reads* reads, const wamd_dist
     if (rc)
         return rc;
     WAMD_HIP(hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> hold(ctx->host_mutex);
     const uint64_t tb = (uint64_t)n * sizeof(wamd_dist_task), rb = (uint64_t)n * sizeof(wamd_dist_result);
     rc = ensure_stage(ctx, tb + rb, 0);
     if (rc)
@@ -515,6 +523,7 @@ int wamd_levdiag(wamd_ctx* ctx, const wamd_reads* reads, const wamd_levdiag_task
     if (rc)
         return rc;
     WAMD_HIP(hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> hold(ctx->host_mutex);
     const uint64_t tb = (uint64_t)n * sizeof(wamd_levdiag_task), rb = (uint64_t)n * sizeof(uint32_t);
     rc = ensure_stage(ctx, tb + rb, 0);
     if (rc)
@@ -552,6 +561,7 @@ int wamd_cf_filter(wamd_ctx* ctx, const wamd_reads* reads, const wamd_cf_task* t
     if (rc)
         return rc;
     WAMD_HIP(hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> hold(ctx->host_mutex);
     const uint64_t tb = (uint64_t)n * sizeof(wamd_cf_task), rb = (uint64_t)n * sizeof(uint32_t);
     rc = ensure_stage(ctx, tb + rb, 0);
     if (rc)
@@ -605,6 +615,7 @@ int wamd_align(wamd_ctx* ctx, const wamd_reads* reads, const wamd_dist_task* tas
     if (!cigars)
         return WAMD_ERR_INVALID_ARG;
     WAMD_HIP(hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> hold(ctx->host_mutex);
     const uint64_t tb = (uint64_t)n * sizeof(wamd_dist_task);
     const uint64_t rb = (uint64_t)n * sizeof(wamd_align_result);
     const uint64_t cb = (uint64_t)n * cigar_stride;
@@ -656,7 +667,10 @@ int wamd_indel_match(wamd_ctx* ctx, const wamd_reads* reads, const wamd_indel_ta
     int rc = check_batch(ctx, reads, tasks, results, "wamd_indel_match");
     if (rc)
         return rc;
+    if (!params)
+        return WAMD_ERR_INVALID_ARG;
     WAMD_HIP(hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> hold(ctx->host_mutex);
     const uint64_t tb = (uint64_t)n * sizeof(wamd_indel_task), rb = (uint64_t)n * sizeof(wamd_mapping);
     rc = ensure_stage(ctx, tb + rb + 256, 0);
     if (rc)
@@ -665,7 +679,11 @@ int wamd_indel_match(wamd_ctx* ctx, const wamd_reads* reads, const wamd_indel_ta
     auto* d_res = (wamd_mapping*)((char*)ctx->d_stage + (tb + 255) / 256 * 256);
     hipStream_t s = ctx->stream;
     WAMD_HIP(hipMemcpyAsync(d_tasks, tasks, tb, hipMemcpyHostToDevice, s));
-    rc = wamd_indel_match_dev(ctx, reads, d_tasks, n, params, d_res, s);
+    wamd_indel_params prm = *params;
+    prm.max_indel_bound = 1;
+    for (uint32_t i = 0; i < n; ++i)
+        prm.max_indel_bound = tasks[i].max_indel_size > prm.max_indel_bound ? tasks[i].max_indel_size : prm.max_indel_bound;
+    rc = wamd_indel_match_dev(ctx, reads, d_tasks, n, &prm, d_res, s);
     if (rc)
         return rc;
     WAMD_HIP(hipMemcpyAsync(results, d_res, rb, hipMemcpyDeviceToHost, s));
@@ -699,6 +717,7 @@ int wamd_indel_ext_cigar(wamd_ctx* ctx, const wamd_reads* reads, const wamd_inde
     if (!cigars)
         return WAMD_ERR_INVALID_ARG;
     WAMD_HIP(hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> hold(ctx->host_mutex);
     auto up = [](uint64_t x) { return (x + 255) / 256 * 256; };
     const uint64_t tb = (uint64_t)n * sizeof(wamd_indel_cigar_task), rb = (uint64_t)n * sizeof(wamd_indel_cigar_result);
     const uint64_t cb = (uint64_t)n * cigar_stride;
@@ -738,6 +757,7 @@ int wamd_clip_boundary(wamd_ctx* ctx, uint32_t n, wamd_clip_record* records, uin
     if (!ctx || !records || !cigars || cigar_stride == 0)
         return WAMD_ERR_INVALID_ARG;
     WAMD_HIP(hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> hold(ctx->host_mutex);
     auto up = [](uint64_t x) { return (x + 255) / 256 * 256; };
     const uint64_t rb = (uint64_t)n * sizeof(wamd_clip_record), cb = (uint64_t)n * cigar_stride;
     int rc = ensure_stage(ctx, up(rb) + up(cb), 0);
@@ -828,6 +848,7 @@ int wamd_softclip_match(wamd_ctx* ctx, const wamd_reads* reads, const wamd_softc
     for (uint32_t i = 0; i < n; ++i)
         max_window = tasks[i].max_distance_in_ref > max_window ? tasks[i].max_distance_in_ref : max_window;
     WAMD_HIP(hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> hold(ctx->host_mutex);
     auto up = [](uint64_t x) { return (x + 255) / 256 * 256; };
     const uint64_t tb = (uint64_t)n * sizeof(wamd_softclip_task), rb = (uint64_t)n * sizeof(wamd_softclip_result),
                    cb = (uint64_t)n * cigar_stride;
@@ -874,6 +895,7 @@ int wamd_sam_cigar(wamd_ctx* ctx, uint32_t n, const uint8_t* ext_cigars, uint32_
     if (!ctx || !ext_cigars || !cigars || !mdz || !lens)
         return WAMD_ERR_INVALID_ARG;
     WAMD_HIP(hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> hold(ctx->host_mutex);
     auto up = [](uint64_t x) { return (x + 255) / 256 * 256; };
     const uint64_t eb = (uint64_t)n * ext_stride, cb = (uint64_t)n * cigar_stride, mb = (uint64_t)n * mdz_stride,
                    bb = cigar_bin ? (uint64_t)n * bin_stride * sizeof(uint32_t) : 0,
@@ -925,6 +947,7 @@ int wamd_serialize_mappings(wamd_ctx* ctx, uint32_t n, const wamd_mapping* mappi
     if (!ctx || !mappings || !direction || !out || !sizes)
         return WAMD_ERR_INVALID_ARG;
     WAMD_HIP(hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> hold(ctx->host_mutex);
     auto up = [](uint64_t x) { return (x + 255) / 256 * 256; };
     const uint64_t mb = (uint64_t)n * sizeof(wamd_mapping), ob = (uint64_t)n * 12;
     int rc = ensure_stage(ctx, up(mb) + up(n) + up(ob) + up(n), 0);

@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "../../include/whisper_amd.h"
 
 namespace wamd {
@@ -83,6 +85,10 @@ struct wamd_ctx {
     uint64_t d_stage_bytes;
     void* h_stage;
     uint64_t h_stage_bytes;
+    // Host-pointer entry points share d_stage, h_flags and `stream`: each of them holds this lock
+    // from its first use of the staging buffer to its last read of the results, so worker threads
+    // that flush on one shared context are serialised, never interleaved.
+    std::mutex host_mutex;
 };
 
 struct wamd_reads {

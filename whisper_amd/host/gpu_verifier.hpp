@@ -6,7 +6,8 @@
 // candidate and returns a ticket; flush() verifies the whole batch on the GPU through
 // include/whisper_amd.h, after which the results are read back by ticket in the order the
 // loop enqueued them.  One object per worker thread, as in the reference
-// (mapper/mapping_core.cpp:154-191); objects are not thread-safe, a wamd_ctx may be shared.
+// (mapper/mapping_core.cpp:154-191); objects are not thread-safe; a GpuReference (wamd_ctx) may be
+// shared by the worker threads - its host-pointer calls are serialised by a lock inside the context.
 //
 // Header-only C++17, no dependency besides the C-ABI; errors become std::runtime_error
 // like the reference's own (mapper/LevMyers64.cpp:244-252).
@@ -69,6 +70,12 @@ public:
 
     // LevMyers::preprocess(seq, seq_len, orientation): the read every following
     // dynamicProgramming()/LevDiag() call verifies (mapper/mapping_core_sa.cpp:212-213).
+    // Pass what the reference passes: the call site's own pattern_ptr with genome_t::direct, on
+    // BOTH strands - in the rc branch pattern_ptr already is rc_data, the reverse-complemented read
+    // (mapper/mapping_core.cpp:563-569, 1063), and LevDiag() verifies these very symbols as they
+    // are.  genome_t::rev_comp makes dynamicProgramming() verify the reverse complement of `seq`
+    // (what LevMyers::preprocess does with it, LevMyers64.cpp:184-194); no mapping-stage call site
+    // asks for that.
     bool preprocess(const uchar_t* seq, uint32_t seq_len, genome_t orientation)
     {
         offsets_.push_back(blob_.size());
@@ -76,6 +83,7 @@ public:
         blob_.insert(blob_.end(), seq, seq + (seq_len + 1) / 2);
         cur_read_ = (uint32_t)lens_.size() - 1;
         cur_flags_ = orientation == genome_t::rev_comp ? WAMD_TASK_FLAG_REV_COMP : 0;
+        need_rc_ = need_rc_ || cur_flags_ != 0;
         return true;
     }
 
@@ -119,8 +127,10 @@ public:
             return;
         offsets_.push_back(blob_.size());
         wamd_reads* reads = nullptr;
+        // pattern vectors of the stored orientation only, unless a caller asked for rev_comp
         check(wamd_reads_upload(ref_.ctx(), blob_.data(), offsets_.data(), lens_.data(), (uint32_t)lens_.size(),
-                                WAMD_READS_NIBBLE, 3, &reads), "wamd_reads_upload");
+                                WAMD_READS_NIBBLE, need_rc_ ? 3 : 1, &reads), "wamd_reads_upload");
+        need_rc_ = false;
         int rc = WAMD_OK;
         if (!dist_tasks_.empty())
             rc = wamd_verify_distance(ref_.ctx(), reads, dist_tasks_.data(), (uint32_t)dist_tasks_.size(),
@@ -157,6 +167,7 @@ private:
     std::vector<uint32_t> lev_results_;
     uint32_t cur_read_ = 0;
     uint32_t cur_flags_ = 0;
+    bool need_rc_ = false;
 };
 
 // Mirrors the post-processing use: preprocessRawSeq + dynamicProgramming + getExtCigar
