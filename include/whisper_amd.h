@@ -71,6 +71,11 @@ enum {
 
 #define WAMD_MAX_READ_LEN 1024u        /* symbols; 16 x 64-bit words per bit-vector      */
 #define WAMD_TASK_FLAG_REV_COMP 1u     /* genome_t::rev_comp orientation of the read     */
+/* read_idx of a slot that holds no task: wamd_align[_dev] and wamd_indel_ext_cigar[_dev] skip it
+ * (ok = 0, edit_distance = 0xffffffff / ok = 0; its ext-CIGAR slot is left alone by
+ * wamd_indel_ext_cigar and emptied by wamd_align) and raise no error flag.  Lets a caller keep
+ * task i, result i and slot i aligned across kernels that each serve a subset. */
+#define WAMD_READ_NONE 0xffffffffu
 #define WAMD_LAST_SYMBOL_FROM_READ (-1)
 
 /* scoring_t (common/types.h:574-612); defaults: match 1, mismatch -5,
@@ -547,6 +552,94 @@ WAMD_API int wamd_emit_lev_records_dev(wamd_ctx* ctx, uint32_t n, const wamd_dis
                                        const wamd_dist_result* d_results, const uint32_t* d_record_pos,
                                        const uint8_t* d_direction, uint8_t* d_records, uint32_t* d_count,
                                        void* d_scratch, void* stream);
+
+/* ---- finishing the chosen pair: ext-CIGAR, clipping, SAM CIGAR / MD:Z in one call -------- *
+ * What store_mapped_pair_reads does to the two mappings of the pair it has picked
+ * (mapper/sam.cpp:1871-1900, then 1992-2007), for a batch of pairs, without leaving the device:
+ *   fill_cigar                  sam_matching.cpp:667-686   perfect match: no alignment at all
+ *     fill_cigar_with_lev       sam_matching.cpp:689-752   preprocessRawSeq + dynamicProgramming +
+ *                                                          getExtCigar + refine_ext_cigar
+ *     fill_cigar_with_indel_matching  sam_matching.cpp:824-852   GetExtCigarNew
+ *   clipIllegalPositions        sam.cpp:1889               soft_clipping.cpp:592-729
+ *   clipBoundaryPositions       sam.cpp:1890-1892          soft_clipping.cpp:827-994
+ *   clipOverlappingPairs        sam.cpp:1898-1900          soft_clipping.cpp:997-1151
+ *   extract_cigar_and_mdz       sam.cpp:2002-2007          sam.cpp:805-928 (perfect matches keep
+ *                                                          "<len>M" / "<len>", sam.cpp:1504-1515)
+ * Read slot 2i is p.first of pair i, slot 2i + 1 p.second.  A task is the mapping_desc_t the
+ * generator built from the mapping record (sam.cpp:1555-1580): the deserialised
+ * candidate_mapping_t, Translate()'s chromosome and position, the constructor's
+ * err_edit_distance (common/types.h:390-425); `distant` is fill_cigar's argument (the insert
+ * size against the model, sam.cpp:1879-1883: host logic).  For the non-lev types the host passes
+ * the chromosome (ref_seq_id, ref_seq_pos, ref_size) of Translate(examined_start_pos),
+ * examined_start_pos = direct ? pos : pos - (length - 1): what fill_cigar_with_indel_matching
+ * stores (sam_matching.cpp:826-828, 843-849) - the constructor's values unless the window start
+ * lies across a chromosome border. */
+typedef struct wamd_finish_task {
+    uint32_t read_idx;             /* ASCII read of the batch                               */
+    uint32_t pos;                  /* candidate_mapping_t::pos                              */
+    uint32_t type;                 /* WAMD_MAP_*                                            */
+    uint32_t penalty;              /* candidate_mapping_t::penalty as the generator holds it */
+    uint32_t matching_len1;
+    uint32_t matching_len2;
+    int32_t indel_len1;
+    int32_t indel_len2;
+    uint32_t clipping_len;
+    int32_t ref_seq_id;
+    int32_t ref_seq_pos;
+    int32_t ref_size;              /* the chromosome's size + no_initial_Ns + no_final_Ns   */
+    uint16_t err_edit_distance;
+    uint8_t direct;                /* mapping.direction == genome_t::direct                 */
+    uint8_t distant;
+    uint32_t reserved[3];
+} wamd_finish_task;
+
+/* CParams fields the chain reads. */
+typedef struct wamd_finish_params {
+    uint32_t flank;                          /* sam_matching.cpp:696: uint32(sensitive_mode ? max_no_errors *  */
+                                             /* sensitivity_factor : max_no_errors) + 1                        */
+    uint32_t enable_short_indel_refinement;  /* mapper/params.h: 1                                             */
+    uint32_t enable_boundary_clipping;       /* 1                                                              */
+    uint32_t enable_paired_clipping;         /* 1                                                              */
+} wamd_finish_params;
+
+/* MatchingMethod::Enumeration (common/types.h:168-175) values this path sets. */
+enum {
+    WAMD_METHOD_PERFECT = 0, WAMD_METHOD_PERFECT_DISTANT = 1, WAMD_METHOD_FROM_MAPPING = 2,
+    WAMD_METHOD_FROM_MAPPING_DISTANT = 3, WAMD_METHOD_UNMATCHED = 26
+};
+
+/* The fields of mapping_desc_t the SAM record is written from (store_mapping_result,
+ * sam.cpp:2013-2017).  ok = 0: fill_cigar could not align the record (the reference counts it in
+ * stat_mapped_pe_errors and goes on with a null ext-CIGAR); the slot's outputs are then empty. */
+typedef struct wamd_finish_result {
+    double score;                  /* AS:i: is Double2PChar of it                            */
+    uint32_t pos;                  /* mapping.pos after fill_cigar                           */
+    int32_t ref_seq_pos;
+    uint16_t ref_length;
+    uint16_t err_edit_distance;    /* NM:i:                                                  */
+    uint16_t num_events;
+    uint16_t left_clipping;
+    uint16_t right_clipping;
+    uint16_t method;               /* XM:Z:                                                  */
+    uint32_t ext_cigar_len;
+    uint32_t cigar_len;
+    uint32_t mdz_len;
+    uint32_t ok;
+    uint32_t reserved;
+} wamd_finish_result;
+
+/* ext-CIGARs at ext_cigars + slot * ext_stride (a multiple of 4, >= 2 * (read length + flank + 1) + 8),
+ * SAM CIGAR text at cigars + slot * cigar_stride, MD:Z at mdz + slot * mdz_stride, all NUL-terminated. */
+WAMD_API uint64_t wamd_finish_workspace_bytes(const wamd_reads* reads, uint32_t n_pairs);
+WAMD_API int wamd_finish_pairs(wamd_ctx* ctx, const wamd_reads* reads, const wamd_finish_task* tasks,
+                               uint32_t n_pairs, const wamd_finish_params* params, wamd_finish_result* results,
+                               uint8_t* ext_cigars, uint32_t ext_stride, uint8_t* cigars, uint32_t cigar_stride,
+                               uint8_t* mdz, uint32_t mdz_stride);
+WAMD_API int wamd_finish_pairs_dev(wamd_ctx* ctx, const wamd_reads* reads, const wamd_finish_task* d_tasks,
+                                   uint32_t n_pairs, const wamd_finish_params* params,
+                                   wamd_finish_result* d_results, uint8_t* d_ext_cigars, uint32_t ext_stride,
+                                   uint8_t* d_cigars, uint32_t cigar_stride, uint8_t* d_mdz, uint32_t mdz_stride,
+                                   void* d_workspace, uint64_t workspace_bytes, void* stream);
 
 /* The same emission for callers that cannot allocate device memory or bring a scratch
  * buffer: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.

@@ -68,6 +68,27 @@ def _sam_cigar(fn, ext_cigars, out_stride=None):
     return rc, cig, mdz, cbin, lens
 
 
+FINISH_TASK = np.dtype([("read_idx", "<u4"), ("pos", "<u4"), ("type", "<u4"), ("penalty", "<u4"), ("matching_len1", "<u4"),
+                        ("matching_len2", "<u4"), ("indel_len1", "<i4"), ("indel_len2", "<i4"), ("clipping_len", "<u4"),
+                        ("ref_seq_id", "<i4"), ("ref_seq_pos", "<i4"), ("ref_size", "<i4"), ("err_edit_distance", "<u2"),
+                        ("direct", "u1"), ("distant", "u1"), ("reserved", "<u4", (3,))])
+FINISH_RESULT = np.dtype([("score", "<f8"), ("pos", "<u4"), ("ref_seq_pos", "<i4"), ("ref_length", "<u2"),
+                          ("err_edit_distance", "<u2"), ("num_events", "<u2"), ("left_clipping", "<u2"),
+                          ("right_clipping", "<u2"), ("method", "<u2"), ("ext_cigar_len", "<u4"), ("cigar_len", "<u4"),
+                          ("mdz_len", "<u4"), ("ok", "<u4"), ("reserved", "<u4")])
+assert FINISH_TASK.itemsize == 64 and FINISH_RESULT.itemsize == 48
+
+
+class FinishParams(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("flank", "enable_short_indel_refinement", "enable_boundary_clipping",
+                                          "enable_paired_clipping")]
+
+
+def default_finish_params(flank=6):
+    # mapper/params.h: refinement, boundary and paired clipping on; flank = max_no_errors (+ sensitivity) + 1
+    return FinishParams(flank, 1, 1, 1)
+
+
 class Scoring(C.Structure):  # noqa: E302
     _fields_ = [(n, C.c_double) for n in ("match", "mismatch", "gap_ins_open", "gap_ins_extend",
                                            "gap_del_open", "gap_del_extend", "clipping")]
@@ -413,3 +434,44 @@ def _r_softclip(self, genome, reads, offsets, lens, encoding, tasks, params=None
 
 Oracle.softclip_match = _o_softclip
 Reference.softclip_match = _r_softclip
+
+
+# ---- the chosen pair: fill_cigar + clipping passes + SAM CIGAR / MD:Z (sam.cpp:1871-1900, 1992-2007)
+def _finish_out(n_slots, ext_stride, out_stride):
+    return (np.zeros(n_slots, FINISH_RESULT), np.zeros((n_slots, ext_stride), np.uint8),
+            np.zeros((n_slots, out_stride), np.uint8), np.zeros((n_slots, out_stride), np.uint8))
+
+
+def _o_finish_pairs(self, genome, reads, offsets, lens, tasks, params=None, scoring=None, ext_stride=512):
+    t = np.ascontiguousarray(tasks, FINISH_TASK)
+    prm = params or default_finish_params()
+    sc = scoring or default_scoring()
+    res, ext, cig, mdz = _finish_out(len(t), ext_stride, 2 * ext_stride + 16)
+    rc = self.lib.wo_finish_pairs_batch(_p(genome), _p(reads), _p(offsets), _p(lens), _p(t), C.c_uint32(len(t) // 2),
+                                        C.byref(prm), C.byref(sc), _p(res), _p(ext), C.c_uint32(ext.shape[1]), _p(cig),
+                                        C.c_uint32(cig.shape[1]), _p(mdz), C.c_uint32(mdz.shape[1]))
+    return rc, res, ext, cig, mdz
+
+
+def _r_finish_pairs(self, genome, ref_size, desc, reads, offsets, lens, read_idx, wire, distant, stale_penalty,
+                    params=None, scoring=None, max_approx_indel_len=50, ext_stride=512):
+    """The reference's own chain from the wire records on: returns (rc, tasks as the generator constructs them,
+    results, ext-CIGARs, CIGARs, MD:Z)."""
+    prm = params or default_finish_params()
+    sc = scoring or default_scoring()
+    n = len(read_idx)
+    desc = np.ascontiguousarray(desc, np.uint64)
+    tasks = np.zeros(n, FINISH_TASK)
+    res, ext, cig, mdz = _finish_out(n, ext_stride, 2 * ext_stride + 16)
+    rc = self.lib.ref_finish_pairs_batch(_p(genome), C.c_uint32(ref_size), _p(desc), C.c_uint32(len(desc)), _p(reads),
+                                         _p(offsets), _p(lens), C.c_uint32(n // 2), _p(_c(read_idx, np.uint32)),
+                                         _p(_c(wire, np.uint8)), _p(_c(distant, np.uint8)),
+                                         _p(_c(stale_penalty, np.uint32)), C.byref(prm), C.byref(sc),
+                                         C.c_uint32(max_approx_indel_len), _p(tasks), _p(res), _p(ext),
+                                         C.c_uint32(ext.shape[1]), _p(cig), C.c_uint32(cig.shape[1]), _p(mdz),
+                                         C.c_uint32(mdz.shape[1]))
+    return rc, tasks, res, ext, cig, mdz
+
+
+Oracle.finish_pairs = _o_finish_pairs
+Reference.finish_pairs = _r_finish_pairs

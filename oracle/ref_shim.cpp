@@ -715,3 +715,189 @@ REF_API int ref_softclip_batch(const uint8_t* genome, const uint8_t* reads, cons
     }
     return 0;
 }
+
+
+/* ---- the chosen pair, from its two mapping records to the SAM fields --------------------------
+ * The reference's own order on the reference's own objects (store_mapped_pair_reads):
+ *   sam.cpp:1555-1580   candidate_mapping_t::deserialize, CRefSeqDesc::Translate, mapping_desc_t(...)
+ *   sam.cpp:1871-1900   per read: CSamGenerator::fill_cigar (sam_matching.cpp:667-852: perfect match,
+ *                       fill_cigar_with_lev or fill_cigar_with_indel_matching), clipIllegalPositions,
+ *                       clipBoundaryPositions; then clipOverlappingPairs
+ *   sam.cpp:1992-2007   extract_cigar_and_mdz unless the method is Perfect / PerfectDistant
+ * fill_cigar runs on a CSamGenerator whose storage is never constructed: only the members the three
+ * fill_cigar routines read are set (verifier objects, params, scratch sequences, the genome behind an
+ * equally unconstructed CReference, the ext-CIGAR pool, the scoring inside an InsertSizeModel, the
+ * chromosome table).  tasks_out receives what the GPU entry point takes as its input: the
+ * mapping_desc_t as constructed, before fill_cigar. */
+#include "common/reference.h"
+#include "mapper/probabilistic.h"
+#include "mapper/ref_desc.h"
+
+REF_API int ref_finish_pairs_batch(const uint8_t* genome, uint32_t ref_size, const uint64_t* seq_desc5, uint32_t n_seq,
+                                   const uint8_t* reads, const uint64_t* offsets, const uint32_t* lens,
+                                   uint32_t n_pairs, const uint32_t* read_idx, const uint8_t* wire,
+                                   const uint8_t* distant, const uint32_t* stale_penalty,
+                                   const wamd_finish_params* prm, const wamd_scoring* sc, uint32_t max_approx_indel_len,
+                                   wamd_finish_task* tasks_out, wamd_finish_result* results, uint8_t* ext_cigars,
+                                   uint32_t ext_stride, uint8_t* cigars, uint32_t cigar_stride, uint8_t* mdz,
+                                   uint32_t mdz_stride)
+{
+    const uint32_t max_query_len = 1024, max_text_len = 16384;
+    Verifiers v(max_query_len, max_text_len, 0, const_cast<uint8_t*>(genome), ref_size, 0);
+    SamGenBox box;
+    CSamGenerator* gen = box.get();
+    fill_params(box.params, sc, 1.0);
+    box.params.sensitive_mode = false;
+    box.params.max_no_errors = prm->flank - 1;   /* flank = uint32(max_no_errors) + 1, sam_matching.cpp:696 */
+    box.params.sensitivity_factor = 1.0;
+    box.params.enable_short_indel_refinement = prm->enable_short_indel_refinement != 0;
+    box.params.max_approx_indel_len = max_approx_indel_len;
+    scoring_t scoring = make_scoring(sc);
+    InsertSizeModel model(500.0, 125.0, 100, 10000, 4.0, 7.0, 7.0, scoring);
+    CSoftClipping clip(max_query_len, max_text_len, 3, max_approx_indel_len, 0);
+    clip.setReference(const_cast<uint8_t*>(genome), 0, 0);
+    CIndelMatching im(&box.params);
+    im.SetReference(const_cast<uint8_t*>(genome), 0, 0);
+    CMemoryPool<uchar_t> pool(64 * (int64_t)ext_stride, ext_stride, "shim");
+    alignas(CReference) unsigned char ref_raw[sizeof(CReference)];
+    memset(ref_raw, 0, sizeof(ref_raw));
+    CReference* ref_box = reinterpret_cast<CReference*>(ref_raw);
+    ref_box->data = const_cast<uint8_t*>(genome);
+    ref_box->size = ref_size;
+    CRefSeqDesc desc;
+    for (uint32_t i = 0; i < n_seq; ++i) {
+        const uint64_t* d = seq_desc5 + 5 * (size_t)i;
+        desc.seq_desc.push_back(seq_desc_t("chr" + std::to_string(i + 1), (int32_t)i, d[0], d[1], d[2], d[3], d[4]));
+    }
+    std::vector<uint8_t> read_codes(max_query_len + 8), ref_codes(max_text_len + 8);
+    gen->levMyers64 = v.m64.get();
+    gen->levMyers128 = v.m128.get();
+    gen->levMyers256 = v.m256.get();
+    gen->softClipping = &clip;
+    gen->indelMatching = &im;
+    gen->insertSizeModel = &model;
+    gen->reference = ref_box;
+    gen->ref_seq_desc = &desc;
+    gen->mp_ext_cigar = &pool;
+    gen->tmp_read_sequence = read_codes.data();
+    gen->tmp_ref_sequence = ref_codes.data();
+    uint8_t name[] = "shim";
+
+    for (uint32_t i = 0; i < n_pairs; ++i) {
+        mapping_desc_t md[2];
+        uint8_t* seq[2];
+        uint32_t len[2];
+        for (int r = 0; r < 2; ++r) {
+            const uint32_t slot = 2 * i + r;
+            seq[r] = const_cast<uint8_t*>(reads + offsets[read_idx[slot]]);
+            len[r] = lens[read_idx[slot]];
+            /* sam.cpp:1551-1580 */
+            candidate_mapping_t cm;
+            cm.penalty = stale_penalty ? stale_penalty[slot] : cm.penalty;   /* what an earlier record of this read left */
+            cm.deserialize(const_cast<uint8_t*>(wire + 12 * (size_t)slot));
+            int32_t ref_seq_id = 0, ref_seq_pos = 0;
+            std::string ref_seq_name;
+            if (desc.Translate(cm.pos, ref_seq_name, ref_seq_pos, ref_seq_id, name)) {
+                if (cm.direction == genome_t::rev_comp)
+                    ref_seq_pos -= len[r] - 1;
+            } else {
+                ref_seq_pos = 0;
+            }
+            md[r] = mapping_desc_t(cm, ref_seq_id, ref_seq_pos, (uint16_t)len[r], nullptr, box.params.gap_ins_open,
+                                   box.params.gap_ins_extend, box.params.gap_del_open, box.params.gap_del_extend,
+                                   box.params.mismatch_score);
+            md[r].ref_length = (uint16_t)len[r];
+            wamd_finish_task& t = tasks_out[slot];
+            memset(&t, 0, sizeof(t));
+            t.read_idx = read_idx[slot];
+            t.pos = cm.pos;
+            t.type = (uint32_t)cm.type;
+            t.penalty = (uint32_t)cm.penalty;
+            t.matching_len1 = cm.matching_len1;
+            t.matching_len2 = cm.matching_len2;
+            t.indel_len1 = cm.indel_len1;
+            t.indel_len2 = cm.indel_len2;
+            t.clipping_len = cm.clipping_len;
+            /* Contract of wamd_finish_task for the non-lev types: the chromosome and position the host's
+             * Translate gives for examined_start_pos, which is what fill_cigar_with_indel_matching stores
+             * (sam_matching.cpp:826-828, 843-849) - the constructor's values unless the window start lies
+             * across a chromosome border. */
+            if (cm.type != mapping_type_t::lev && !(md[r].err_edit_distance == 0 && cm.penalty == 0)) {
+                const uint32_t examined = cm.direction == genome_t::direct ? cm.pos : cm.pos - (len[r] - 1);
+                int32_t id2 = 0, pos2 = 0;
+                if (desc.Translate(examined, ref_seq_name, pos2, id2, name)) {
+                    ref_seq_id = id2;
+                    ref_seq_pos = pos2;
+                }
+            }
+            t.ref_seq_id = ref_seq_id;
+            t.ref_seq_pos = ref_seq_pos;
+            const seq_desc_t& sd = desc[ref_seq_id];
+            t.ref_size = (int32_t)(sd.size + sd.no_final_Ns + sd.no_initial_Ns);   /* soft_clipping.cpp:594-595 */
+            t.err_edit_distance = md[r].err_edit_distance;
+            t.direct = cm.direction == genome_t::direct;
+            t.distant = distant[slot];
+        }
+        mapping_pair_t mp(&md[0], &md[1]);
+        bool pair_ok = true;
+        /* sam.cpp:1871-1896 */
+        for (int r = 0; r < 2 && pair_ok; ++r) {
+            gen->fill_cigar(mp[r], name, seq[r], len[r], nullptr, distant[2 * i + r] != 0, true);
+            const bool perfect = mp[r].method == MatchingMethod::Enumeration::Perfect ||
+                                 mp[r].method == MatchingMethod::Enumeration::PerfectDistant;
+            if (!perfect && !mp[r].ext_cigar) {   /* stat_mapped_pe_errors: the reference goes on with a null ext-CIGAR */
+                pair_ok = false;
+                break;
+            }
+            clip.clipIllegalPositions(mp[r], model.getScoring(), desc.GetDescription(), pool);
+            if (prm->enable_boundary_clipping)
+                clip.clipBoundaryPositions(mp[r], model.getScoring());
+        }
+        if (pair_ok && prm->enable_paired_clipping)
+            clip.clipOverlappingPairs(mp, model.getScoring(), pool);   /* sam.cpp:1898-1900 */
+        for (int r = 0; r < 2; ++r) {
+            const uint32_t slot = 2 * i + r;
+            wamd_finish_result& o = results[slot];
+            memset(&o, 0, sizeof(o));
+            uint8_t* ec = ext_cigars + (size_t)slot * ext_stride;
+            uint8_t* cg = cigars + (size_t)slot * cigar_stride;
+            uint8_t* mz = mdz + (size_t)slot * mdz_stride;
+            ec[0] = cg[0] = mz[0] = 0;
+            mapping_desc_t& m = mp[r];
+            if (pair_ok) {
+                o.ok = 1;
+                o.score = m.score;
+                o.pos = m.mapping.pos;
+                o.ref_seq_pos = m.ref_seq_pos;
+                o.ref_length = m.ref_length;
+                o.err_edit_distance = m.err_edit_distance;
+                o.num_events = m.num_events;
+                o.left_clipping = m.left_clipping;
+                o.right_clipping = m.right_clipping;
+                o.method = (uint16_t)m.method;
+                if (m.ext_cigar) {
+                    strncpy((char*)ec, (const char*)m.ext_cigar, ext_stride - 1);
+                    ec[ext_stride - 1] = 0;
+                }
+                /* sam.cpp:1992-2007, perfect strings sam.cpp:1504-1515 */
+                if (m.method != MatchingMethod::Enumeration::Perfect && m.method != MatchingMethod::Enumeration::PerfectDistant) {
+                    std::vector<uint8_t> c2(4 * ext_stride + 64), m2(4 * ext_stride + 64);
+                    gen->extract_cigar_and_mdz(m.ext_cigar, c2.data(), m2.data());
+                    strncpy((char*)cg, (const char*)c2.data(), cigar_stride - 1);
+                    cg[cigar_stride - 1] = 0;
+                    strncpy((char*)mz, (const char*)m2.data(), mdz_stride - 1);
+                    mz[mdz_stride - 1] = 0;
+                } else {
+                    snprintf((char*)cg, cigar_stride, "%uM", len[r]);
+                    snprintf((char*)mz, mdz_stride, "%u", len[r]);
+                }
+                o.ext_cigar_len = (uint32_t)strlen((const char*)ec);
+                o.cigar_len = (uint32_t)strlen((const char*)cg);
+                o.mdz_len = (uint32_t)strlen((const char*)mz);
+            }
+            if (m.ext_cigar)
+                pool.Free(m.ext_cigar);
+        }
+    }
+    return 0;
+}

@@ -10,6 +10,7 @@
  */
 #include "wv_oracle.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -2328,4 +2329,168 @@ int wo_sam_cigar_batch(uint32_t n, const uint8_t* ext_cigars, uint32_t ext_strid
         wo_sam_cigar(ext_cigars + (uint64_t)i * ext_stride, cigars + (uint64_t)i * cigar_stride,
                      mdz + (uint64_t)i * mdz_stride, cigar_bin ? cigar_bin + (uint64_t)i * bin_stride : NULL, &lens[i]);
     return 0;
+}
+
+
+/* ---- the chosen pair, from its two mapping_desc_t to the SAM fields -----------------------------
+ * store_mapped_pair_reads, sam.cpp:1871-1900 and 1992-2007, restated as a chain of the routines
+ * above with the glue of fill_cigar (sam_matching.cpp:667-686), fill_cigar_with_lev (689-752) and
+ * fill_cigar_with_indel_matching (824-852).  Input: the descriptors as the generator constructs
+ * them (sam.cpp:1555-1580); slot 2i = p.first, 2i + 1 = p.second. */
+int wo_finish_pairs_batch(const uint8_t* genome, const uint8_t* reads, const uint64_t* offsets, const uint32_t* lens,
+                          const wamd_finish_task* tasks, uint32_t n_pairs, const wamd_finish_params* prm,
+                          const wamd_scoring* sc, wamd_finish_result* results, uint8_t* ext_cigars,
+                          uint32_t ext_stride, uint8_t* cigars, uint32_t cigar_stride, uint8_t* mdz,
+                          uint32_t mdz_stride)
+{
+    uint8_t* big_c = (uint8_t*)malloc(4 * (size_t)ext_stride + 64);
+    uint8_t* big_m = (uint8_t*)malloc(4 * (size_t)ext_stride + 64);
+    uint8_t* query = (uint8_t*)malloc(64 * WO_MAX_WORDS + 16);
+    int rc = 0;
+    for (uint32_t i = 0; i < n_pairs && !rc; ++i) {
+        wamd_clip_record rec[2];
+        int perfect[2] = {0, 0}, method[2] = {WAMD_METHOD_UNMATCHED, WAMD_METHOD_UNMATCHED};
+        uint32_t pos[2], events[2] = {0, 0};
+        int pair_ok = 1;
+        for (int r = 0; r < 2; ++r) {
+            const uint32_t slot = 2 * i + r;
+            const wamd_finish_task* t = &tasks[slot];
+            uint8_t* ec = ext_cigars + (size_t)slot * ext_stride;
+            const uint32_t m = lens[t->read_idx];
+            ec[0] = 0;
+            memset(&rec[r], 0, sizeof(rec[r]));
+            rec[r].ref_seq_pos = t->ref_seq_pos;
+            rec[r].ref_length = (uint16_t)m;          /* sam.cpp:1578 */
+            rec[r].err_edit_distance = t->err_edit_distance;
+            rec[r].score = -1;
+            pos[r] = t->pos;
+            if (!pair_ok)
+                continue;
+            if (t->err_edit_distance == 0 && t->penalty == 0) {   /* sam_matching.cpp:670-680 */
+                perfect[r] = 1;
+                method[r] = t->distant ? WAMD_METHOD_PERFECT_DISTANT : WAMD_METHOD_PERFECT;
+                rec[r].score = m * sc->match;
+            } else if (t->type == WAMD_MAP_LEV) {                  /* sam_matching.cpp:689-752 */
+                wamd_dist_task dt;
+                wamd_align_result ar;
+                const uint32_t begin = t->direct ? t->pos : t->pos - m + 1;
+                dt.read_idx = t->read_idx;
+                dt.ref_pos = begin - prm->flank;
+                dt.max_distance_in_ref = m + 2 * prm->flank + 1;
+                dt.max_ed = t->err_edit_distance;
+                dt.variant = WAMD_VARIANT_AUTO;
+                dt.flags = t->direct ? 0 : WAMD_TASK_FLAG_REV_COMP;
+                rc = wo_align_batch(genome, reads, offsets, lens, WAMD_READS_ASCII, &dt, 1, 0,
+                                    (int)prm->enable_short_indel_refinement, 16384, sc, &ar, ec, ext_stride);
+                if (rc)
+                    break;
+                if (!ar.ok) {
+                    pair_ok = 0;
+                    continue;
+                }
+                const int64_t delta = ((int64_t)dt.ref_pos + ar.begin_pos) - (int64_t)begin;
+                if (ar.refined)
+                    rec[r].err_edit_distance = (uint16_t)(t->err_edit_distance + 1);
+                pos[r] = (uint32_t)((int64_t)t->pos + delta);
+                rec[r].ref_seq_pos = (int32_t)((int64_t)t->ref_seq_pos + delta);
+                rec[r].ref_length = (uint16_t)(ar.end_pos - ar.begin_pos);
+                method[r] = t->distant ? WAMD_METHOD_FROM_MAPPING_DISTANT : WAMD_METHOD_FROM_MAPPING;
+                events[r] = ar.num_events;
+                rec[r].score = ar.affine_score;
+            } else {                                               /* sam_matching.cpp:824-852 */
+                wamd_indel_cigar_task ct;
+                wamd_indel_cigar_result cr;
+                memset(&ct, 0, sizeof(ct));
+                ct.read_idx = t->read_idx;
+                ct.examined_start_pos = t->direct ? t->pos : t->pos - (m - 1);
+                ct.type = t->type;
+                ct.matching_len1 = t->matching_len1;
+                ct.matching_len2 = t->matching_len2;
+                ct.indel_len1 = t->indel_len1;
+                ct.indel_len2 = t->indel_len2;
+                ct.clipping_len = t->clipping_len;
+                ct.flags = t->direct ? 0 : WAMD_TASK_FLAG_REV_COMP;
+                wo_indel_query(query, reads + offsets[t->read_idx], m, WAMD_READS_ASCII, !t->direct);
+                if (!wo_indel_ext_cigar(genome, query, m, &ct, sc, &cr, ec)) {
+                    pair_ok = 0;
+                    continue;
+                }
+                pos[r] = ct.examined_start_pos;
+                rec[r].score = cr.score;
+                rec[r].err_edit_distance = cr.err_edit_distance;
+                rec[r].ref_length = cr.ref_length;
+                rec[r].left_clipping = cr.left_clipping;
+                rec[r].right_clipping = cr.right_clipping;
+                method[r] = cr.method;
+                events[r] = cr.num_events;
+            }
+            /* sam.cpp:1889-1892 */
+            wamd_clip_illegal_task it;
+            it.ref_size = t->ref_size;
+            it.read_length = (uint16_t)m;
+            it.perfect = (uint16_t)perfect[r];
+            if (wo_clip_illegal(&rec[r], &it, ec, ext_stride, sc))
+                rc = WAMD_ERR_INVALID_ARG;
+            if (prm->enable_boundary_clipping)
+                wo_clip_boundary(&rec[r], ec, sc);
+        }
+        if (rc)
+            break;
+        if (pair_ok && prm->enable_paired_clipping) {   /* sam.cpp:1898-1900 */
+            wamd_clip_pair_task pt;
+            for (int r = 0; r < 2; ++r) {
+                pt.ref_seq_id[r] = tasks[2 * i + r].ref_seq_id;
+                pt.read_length[r] = (uint16_t)lens[tasks[2 * i + r].read_idx];
+                pt.direct[r] = tasks[2 * i + r].direct;
+                pt.perfect[r] = (uint8_t)perfect[r];
+            }
+            if (wo_clip_overlapping_pair(rec, &pt, ext_cigars + (size_t)(2 * i) * ext_stride,
+                                         ext_cigars + (size_t)(2 * i + 1) * ext_stride, ext_stride))
+                rc = WAMD_ERR_INVALID_ARG;
+        }
+        for (int r = 0; r < 2; ++r) {
+            const uint32_t slot = 2 * i + r;
+            const uint32_t m = lens[tasks[slot].read_idx];
+            wamd_finish_result* o = &results[slot];
+            uint8_t* ec = ext_cigars + (size_t)slot * ext_stride;
+            uint8_t* cg = cigars + (size_t)slot * cigar_stride;
+            uint8_t* mz = mdz + (size_t)slot * mdz_stride;
+            memset(o, 0, sizeof(*o));
+            cg[0] = mz[0] = 0;
+            if (!pair_ok) {
+                ec[0] = 0;
+                continue;
+            }
+            o->ok = 1;
+            o->score = rec[r].score;
+            o->pos = pos[r];
+            o->ref_seq_pos = rec[r].ref_seq_pos;
+            o->ref_length = rec[r].ref_length;
+            o->err_edit_distance = rec[r].err_edit_distance;
+            o->num_events = (uint16_t)events[r];
+            o->left_clipping = rec[r].left_clipping;
+            o->right_clipping = rec[r].right_clipping;
+            o->method = (uint16_t)method[r];
+            if (!perfect[r]) {   /* sam.cpp:1992-2007 */
+                wamd_sam_cigar_len l;
+                wo_sam_cigar(ec, big_c, big_m, NULL, &l);
+                if (l.cigar_len + 1 > cigar_stride || l.mdz_len + 1 > mdz_stride) {
+                    rc = WAMD_ERR_INVALID_ARG;
+                    break;
+                }
+                memcpy(cg, big_c, l.cigar_len + 1);
+                memcpy(mz, big_m, l.mdz_len + 1);
+            } else {             /* perfect_cigar / perfect_mdz, sam.cpp:1504-1515 */
+                snprintf((char*)cg, cigar_stride, "%uM", m);
+                snprintf((char*)mz, mdz_stride, "%u", m);
+            }
+            o->ext_cigar_len = (uint32_t)strlen((const char*)ec);
+            o->cigar_len = (uint32_t)strlen((const char*)cg);
+            o->mdz_len = (uint32_t)strlen((const char*)mz);
+        }
+    }
+    free(big_c);
+    free(big_m);
+    free(query);
+    return rc;
 }

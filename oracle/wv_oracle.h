@@ -166,6 +166,14 @@ int wo_softclip_batch(const uint8_t* genome, const uint8_t* reads, const uint64_
                       int encoding, const wamd_softclip_task* tasks, uint32_t n, const wamd_softclip_params* prm,
                       const wamd_scoring* sc, wamd_softclip_result* results, uint8_t* cigars, uint32_t cigar_stride);
 
+/* store_mapped_pair_reads' finish of the chosen pair: fill_cigar, the three clipping passes,
+ * extract_cigar_and_mdz (sam.cpp:1871-1900, 1992-2007; sam_matching.cpp:667-852). */
+int wo_finish_pairs_batch(const uint8_t* genome, const uint8_t* reads, const uint64_t* offsets, const uint32_t* lens,
+                          const wamd_finish_task* tasks, uint32_t n_pairs, const wamd_finish_params* prm,
+                          const wamd_scoring* sc, wamd_finish_result* results, uint8_t* ext_cigars,
+                          uint32_t ext_stride, uint8_t* cigars, uint32_t cigar_stride, uint8_t* mdz,
+                          uint32_t mdz_stride);
+
 #ifdef __cplusplus
 }
 #endif

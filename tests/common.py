@@ -443,3 +443,219 @@ def softclip_workload(n, seed, m=150, W=700, encoding=1, gen=None, lens_jitter=F
         tasks[i] = (i, start, W, 20, 1 if rc else 0, 0)
     blob, off, lens = mixed_reads(reads, encoding)
     return codes, packed, (blob, off, lens), tasks
+
+
+# ---- the chosen pair: records -> SAM fields (sam.cpp:1555-1580, 1871-1900, 1992-2007) ------------------
+SEPARATE_N_LEN = 1536      # common/defs.h:43
+
+
+def chromosomes(ref_size):
+    """A chromosome table over the test genome: rows of (size, pos_in_ref_seq, no_initial_Ns, no_final_Ns,
+    no_starting_Ns) as CRefSeqDesc::Load reads them (ref_desc.cpp:33-75).  The third one starts with trimmed Ns,
+    so positions in its first symbols translate to ref_seq_pos <= 0."""
+    b = synth.BOUNDARY_N_LEN
+    usable = ref_size - 2 * b
+    s1, s2 = usable // 3, usable // 3
+    p1 = b
+    p2 = p1 + s1 + SEPARATE_N_LEN
+    p3 = p2 + s2 + SEPARATE_N_LEN
+    s3 = ref_size - b - p3
+    return np.array([[s1, p1, 7, 0, 0], [s2, p2, 0, 11, 0], [s3, p3, 0, 0, 900]], np.uint64)
+
+
+def translate(desc, raw_pos):
+    """CRefSeqDesc::Translate (ref_desc.cpp:102-140): (ok, ref_seq_id, ref_seq_pos)."""
+    raw1 = raw_pos + 1
+    keys = desc[:, 1].astype(np.int64) + SEPARATE_N_LEN // 2
+    j = int(np.searchsorted(keys, raw1, side="left"))      # first row with key >= raw1
+    if j == len(desc) and raw_pos >= int(desc[-1, 1]) + int(desc[-1, 0]) + 2 * SEPARATE_N_LEN:
+        return False, 0, 0
+    if j == 0:
+        return False, 0, 0
+    c = desc[j - 1].astype(np.int64)
+    return True, j - 1, int(raw_pos - c[1] + c[2] - c[4] + 1)
+
+
+def finish_tasks(desc, read_idx, lens, mappings, direct, distant, stale_penalty=None, scoring=(1.0, -5.0, -5.0, -0.4, -5.0, -0.4)):
+    """mapping_desc_t as store_mapped_pair_reads constructs it from a record (sam.cpp:1555-1580,
+    common/types.h:371-425): the input of wamd_finish_pairs."""
+    from whisper_amd import api
+    match, mismatch, ins_o, ins_e, del_o, del_e = scoring
+    n = len(read_idx)
+    t = np.zeros(n, api.FINISH_TASK)
+
+    def i2m(size):     # indel_to_mismatch_score, types.h:342-352
+        a = del_o + (size - 1) * del_e if size > 0 else ins_o + (-size - 1) * ins_e
+        return int(a / mismatch) & 0xFFFF
+
+    for i in range(n):
+        mp = mappings[i]
+        m = int(lens[read_idx[i]])
+        ok, sid, spos = translate(desc, int(mp["pos"]))
+        if ok and not direct[i]:
+            spos -= m - 1
+        if not ok:
+            spos = 0
+        ty, nm = int(mp["type"]), int(mp["no_mismatches"]) & 0x3f
+        if ty == 0:
+            ed, pen = nm, int(stale_penalty[i]) if stale_penalty is not None else 0
+        else:
+            pen = nm + (1 if ty in (1, 5, 6) else 2)              # calc_penalty, results.cpp:327-343
+            l1 = int(mp["indel_len1"]) if ty in (1, 2, 3, 4) else 0
+            l2 = int(mp["indel_len2"]) if ty == 2 else 0
+            ed = {1: nm + i2m(l1), 2: nm + i2m(l1) + i2m(l2), 7: nm + 2, 3: nm + 1 + i2m(l1), 4: nm + 1 + i2m(l1),
+                  5: nm + 1, 6: nm + 1}[ty] & 0xFFFF
+        if ty != 0 and not (ed == 0 and pen == 0):
+            # the non-lev types end up where Translate puts examined_start_pos (sam_matching.cpp:826-828, 843-849)
+            ok2, sid2, spos2 = translate(desc, int(mp["pos"]) if direct[i] else int(mp["pos"]) - (m - 1))
+            if ok2:
+                sid, spos = sid2, spos2
+        # what the wire record carries per type (results.cpp:161-275): the rest deserialises as 0
+        carried = {0: (), 1: ("matching_len1", "indel_len1"), 2: ("matching_len1", "matching_len2", "indel_len1", "indel_len2"),
+                   3: ("matching_len1", "clipping_len", "indel_len1"), 4: ("matching_len1", "clipping_len", "indel_len1"),
+                   5: ("matching_len1",), 6: ("matching_len1",), 7: ("matching_len1", "clipping_len")}[ty]
+        v = {f: (int(mp[f]) if f in carried else 0)
+             for f in ("matching_len1", "matching_len2", "indel_len1", "indel_len2", "clipping_len")}
+        t[i] = (read_idx[i], mp["pos"], ty, pen, v["matching_len1"], v["matching_len2"], v["indel_len1"],
+                v["indel_len2"], v["clipping_len"], sid, spos, int(desc[sid, 0] + desc[sid, 2] + desc[sid, 3]),
+                ed, direct[i], distant[i], (0, 0, 0))
+    return t
+
+
+def finish_workload(oracle, n_pairs, seed, m=150, flank=6, gen=None):
+    """Pairs as store_mapped_pair_reads holds them once it has picked one: perfect matches, lev records with
+    substitutions / short indels / the refinement pattern, indel-matcher records of every type, junk ends (boundary
+    clipping), mappings over a chromosome's end or before its first base (illegal positions), reverse reads left of
+    and overlapping their forward mates (paired clipping).  Returns (genome, reads, desc, read_idx, mappings, direct,
+    distant, stale_penalty)."""
+    import torch
+    from oracle import bindings as ob
+    codes, packed = gen if gen is not None else genome()
+    G = codes.numel()
+    desc = chromosomes(G)
+    g = torch.Generator().manual_seed(seed)
+
+    def rnd(lo, hi):
+        return int(torch.randint(lo, hi, (1,), generator=g))
+
+    # a pool of indel-matcher records (direct-strand Match on reads carrying one long indel or junk ends)
+    _, _, (iblob, ioff, ilens), itasks = indel_workload(max(64, n_pairs), m, seed + 1, gen=(codes, packed))
+    _, imap = oracle.indel_match(packed, iblob, ioff, ilens, 0, itasks, ob.default_indel_params(0.6))
+    ipool = [j for j in np.nonzero(imap["found"])[0]]
+    icodes = np.zeros((len(ilens), m), np.uint8)
+    ib = iblob.reshape(len(ilens), -1)
+    icodes[:, 0::2] = (ib >> 4)[:, :(m + 1) // 2]
+    icodes[:, 1::2] = (ib & 15)[:, :m // 2]
+
+    clean = codes.clone()
+    clean[clean > 3] = 0
+    reads, mappings, direct = [], np.zeros(2 * n_pairs, ob.MAPPING), np.zeros(2 * n_pairs, np.uint8)
+    want_lev = []
+
+    def mutate(r, kind):
+        r = r.clone()
+        if kind == "subs":
+            for _ in range(rnd(1, 5)):
+                z = rnd(0, m)
+                r[z] = (int(r[z]) + rnd(1, 4)) & 3
+        elif kind == "indel":
+            q = rnd(10, m - 20)
+            if rnd(0, 2):
+                r = torch.cat([r[:q], r[q + 2:], torch.randint(0, 4, (2,), generator=g, dtype=torch.uint8)])
+            else:
+                r = torch.cat([r[:q], torch.randint(0, 4, (1,), generator=g, dtype=torch.uint8), r[q:m - 1]])
+        elif kind == "refine":      # 1I2M1D: what refine_ext_cigar rewrites
+            q = rnd(10, m - 20)
+            x = (int(r[q + 3]) + 1) & 3
+            r = torch.cat([r[:q], torch.tensor([x], dtype=torch.uint8), r[q:q + 2], r[q + 3:]])[:m]
+        elif kind == "junk":
+            c = rnd(8, 30)
+            if rnd(0, 2):
+                r[:c] = torch.randint(0, 4, (c,), generator=g, dtype=torch.uint8)
+            else:
+                r[m - c:] = torch.randint(0, 4, (c,), generator=g, dtype=torch.uint8)
+            z = rnd(40, m - 40)
+            r[z] = (int(r[z]) + 1) & 3
+        return r[:m].clone()
+
+    for i in range(n_pairs):
+        kind = i % 10
+        while True:
+            c = rnd(0, 3)
+            c_pos, c_size = int(desc[c, 1]), int(desc[c, 0])
+            f = c_pos + rnd(1000, c_size - 2000)
+            isize = rnd(m + 60, 520)
+            pf, pr = f, f + isize - m                    # forward read's start, reverse read's start
+            if kind in (2, 6):                           # reverse read left of and overlapping the forward read
+                pr = f
+                pf = f + rnd(0, m - 10)
+            if kind == 5:                                # over the end of the chromosome / before its first base
+                if c == 2 and rnd(0, 2):
+                    pf = c_pos + rnd(780, 905)
+                    pr = pf + isize - m
+                else:
+                    pr = c_pos + c_size - m + rnd(1, 40)
+                    pf = pr - (isize - m)
+            if int(codes[pf - 8:pf + m + 8].max()) <= 3 and int(codes[pr - 8:pr + m + 8].max()) <= 3:
+                break                                    # no N run under either read
+        first_forward = bool(rnd(0, 2))
+        for r in range(2):
+            slot = 2 * i + r
+            fwd = (r == 0) == first_forward
+            p = pf if fwd else pr
+            src = clean[p:p + m + 4]
+            if kind == 4 and r == 0 and ipool:           # an indel-matcher record
+                j = ipool[(i // 10) % len(ipool)]
+                q = torch.from_numpy(icodes[j].copy())
+                mappings[slot] = imap[j]
+                if fwd:
+                    reads.append(q)
+                else:
+                    reads.append(synth.rev_comp(q))
+                    mappings[slot]["pos"] = int(imap[j]["pos"]) + m - 1
+                direct[slot] = fwd
+                continue
+            mk = {0: "subs", 1: "none", 2: "subs", 3: "junk", 4: "subs", 5: "subs", 6: "none", 7: "indel", 8: "refine",
+                  9: "subs" if r else "none"}[kind]
+            q = mutate(src[:m], mk) if mk != "none" else src[:m].clone()
+            reads.append(q if fwd else synth.rev_comp(q))
+            direct[slot] = fwd
+            mappings[slot]["type"] = 0
+            mappings[slot]["pos"] = p if fwd else p + m - 1
+            want_lev.append(slot)
+    blob, off, lens = mixed_reads(reads, 1)
+    read_idx = np.arange(2 * n_pairs, dtype=np.uint32)
+    # the error count the mapping stage recorded = the distance inside fill_cigar_with_lev's window
+    lev = np.array(want_lev)
+    dt = np.zeros(len(lev), ob.DIST_TASK)
+    dt["read_idx"] = lev
+    begin = np.where(direct[lev] == 1, mappings["pos"][lev], mappings["pos"][lev] - m + 1)
+    dt["ref_pos"] = begin - flank
+    dt["max_distance_in_ref"] = m + 2 * flank + 1
+    dt["max_ed"] = 40
+    dt["flags"] = 1 - direct[lev]
+    _, dres = oracle.distance(packed, blob, off, lens, 1, dt, 0)
+    assert (dres["edit_distance"] <= 40).all()
+    mappings["no_mismatches"][lev] = dres["edit_distance"]
+    mappings["found"] = 1
+    rng = np.random.default_rng(seed)
+    slack = rng.random(len(lev)) < 0.2                   # LevDiag's anchored distance can exceed the window's
+    mappings["no_mismatches"][lev[slack]] += ((dres["edit_distance"][slack] > 0) *
+                                              rng.integers(1, 3, slack.sum())).astype(np.uint32)
+    distant = (rng.random(2 * n_pairs) < 0.1).astype(np.uint8)
+    stale = np.zeros(2 * n_pairs, np.uint32)
+    stale[lev] = np.where(rng.random(len(lev)) < 0.05, 3, 0)   # a lev record deserialised after a non-lev one
+    return (codes, packed), (blob, off, lens), desc, read_idx, mappings, direct, distant, stale
+
+
+def same_finish_output(got, want, skip=()):
+    """(results, ext-CIGARs, CIGARs, MD:Z) of two finish_pairs runs: every field and every string equal."""
+    gr, ge, gc, gm = got
+    wr, we, wc, wm = want
+    for f in wr.dtype.names:
+        if f not in ("reserved",) + tuple(skip):
+            np.testing.assert_array_equal(gr[f], wr[f], err_msg=f)
+    for i in range(len(wr)):
+        for a, b, what in ((ge, we, "ext-CIGAR"), (gc, wc, "CIGAR"), (gm, wm, "MD:Z")):
+            x, y = bytes(a[i]).split(b"\0")[0], bytes(b[i]).split(b"\0")[0]
+            assert x == y, "%s of slot %d: %r != %r" % (what, i, x, y)

@@ -110,6 +110,28 @@ def make_softclip(ref, codes, packed):
         print(name, "found", int(res["found"].sum()), "of", n, "indels", int((res["del_size"] != 0).sum()))
 
 
+def make_finish(ref, codes, packed, ref_size):
+    """The chosen pair from its two wire records to the SAM fields: the reference's own deserialize, Translate,
+    mapping_desc_t, fill_cigar, clipIllegalPositions, clipBoundaryPositions, clipOverlappingPairs and
+    extract_cigar_and_mdz in the order of sam.cpp:1555-1580, 1871-1900, 1992-2007 (oracle/ref_shim.cpp,
+    ref_finish_pairs_batch).  `tasks` is what the GPU entry point takes: the descriptors as constructed."""
+    orc = bindings.Oracle()
+    for name, n_pairs, seed, m in (("finish_m150", 400, 8100, 150), ("finish_m100", 150, 8101, 100)):
+        (_, _), (blob, off, lens), desc, ridx, maps, direct, distant, stale = common.finish_workload(
+            orc, n_pairs, seed, m=m, gen=(codes, packed))
+        _, wire, sizes = ref.serialize(maps, direct)
+        rc, tasks, res, ext, cig, mdz = ref.finish_pairs(packed, ref_size, desc, blob, off, lens, ridx, wire, distant,
+                                                         stale, ext_stride=512)
+        assert rc == 0 and res["ok"].all()
+        w = [int(res[f].max()) + 1 for f in ("ext_cigar_len", "cigar_len", "mdz_len")]
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), kind="finish", blob=blob, off=off, lens=lens, desc=desc,
+                            read_idx=ridx, wire=wire, wire_sizes=sizes, distant=distant, stale_penalty=stale,
+                            tasks=tasks, results=res, ext_cigars=ext[:, :w[0]], cigars=cig[:, :w[1]], mdz=mdz[:, :w[2]],
+                            flank=6, ext_stride=512)
+        print(name, "methods", np.bincount(res["method"], minlength=27), "clipped",
+              int(((res["left_clipping"] > 0) | (res["right_clipping"] > 0)).sum()))
+
+
 def make_round2(ref, codes, packed, ref_size):
     """Shapes no round-1 fixture reached: LevDiag beyond 160 symbols (BASELINE configs[4] runs it in
     stages 1-4 at 250 bp; 300 / 600 bp for the two widest kernel instantiations), the long-indel
@@ -168,6 +190,7 @@ def make_round2(ref, codes, packed, ref_size):
         np.savez_compressed(os.path.join(HERE, name + ".npz"), kind="cf", blob=blob, off=off, lens=lens, tasks=tasks,
                             results=res, passed=ok, cur_offset=cur_offset, max_diff=4 * k)
         print(name, "passed", int(ok.sum()), "of", n)
+    make_finish(ref, codes, packed, ref_size)
     seed += 1
     rd = synth.make_reads(codes, 600, 250, 7, seed)
     blob, off, lens = common.host_reads(rd, 0)
@@ -184,6 +207,9 @@ def main():
     codes = synth.make_genome(GENOME_SYMBOLS, seed=GENOME_SEED)
     packed = synth.pack_nibbles(codes).numpy()
     ref_size = codes.numel()
+    if len(sys.argv) > 1 and sys.argv[1] == "finish":
+        make_finish(ref, codes, packed, ref_size)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "round2":
         make_round2(ref, codes, packed, ref_size)
         return

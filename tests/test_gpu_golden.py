@@ -144,3 +144,18 @@ def test_softclip_match(ctx, name):
     np.testing.assert_array_equal(res, z["results"])
     for i in range(len(res)):
         assert gu.cigar_bytes(cig, i) == gu.cigar_bytes(z["cigars"], i), i
+
+
+@pytest.mark.parametrize("name", gu.cases("finish"))
+def test_finish_pairs(ctx, name):
+    """mapping records -> ext-CIGAR -> three clipping passes -> CIGAR / MD:Z / NM / AS without leaving the device,
+    against the reference's own chain (oracle/ref_shim.cpp: ref_finish_pairs_batch)."""
+    import common
+    z = gu.load(name)
+    reads = ctx.upload_reads(z["blob"], z["off"], z["lens"], 1, orientations=3)
+    got = ctx.finish_pairs(reads, z["tasks"], api.default_finish_params(int(z["flank"])), ext_stride=int(z["ext_stride"]))
+    reads.free()
+    common.same_finish_output(got, (z["results"], z["ext_cigars"], z["cigars"], z["mdz"]))
+    # AS:i: is Double2PChar of the score (utils.h:276-286): one decimal, identical because the doubles are
+    want, have = z["results"]["score"], got[0]["score"]
+    assert [("%.1f" % v) for v in want] == [("%.1f" % v) for v in have]

@@ -465,6 +465,61 @@ def test_sam_cigar(ctx, oracle):
         ctx.sam_cigar(ext[:64], out_stride=16)
 
 
+@pytest.mark.parametrize("seed,m,flank", [(31, 150, 6), (32, 250, 8), (33, 100, 5), (34, 150, 13)])
+def test_finish_pairs_chain(ctx, oracle, seed, m, flank):
+    """Row N1's stand-in: the reference's post-processing order on one set of pairs - fill_cigar (perfect / lev /
+    indel-matcher records), clipIllegalPositions, clipBoundaryPositions, clipOverlappingPairs,
+    extract_cigar_and_mdz - through one entry point; every SAM-visible field and string against the oracle."""
+    (codes, packed), (blob, off, lens), desc, ridx, maps, direct, distant, stale = common.finish_workload(
+        oracle, 1500, seed, m=m, flank=flank)
+    tasks = common.finish_tasks(desc, ridx, lens, maps, direct, distant, stale)
+    from oracle import bindings as ob
+    rc, *want = oracle.finish_pairs(packed, blob, off, lens, tasks, ob.default_finish_params(flank), ext_stride=768)
+    assert rc == 0 and want[0]["ok"].all()
+    reads = ctx.upload_reads(blob, off, lens, 1, orientations=3)
+    got = ctx.finish_pairs(reads, tasks, api.default_finish_params(flank), ext_stride=768)
+    common.same_finish_output(got, want)
+    # the switches of CParams: no refinement, no boundary clipping, no paired clipping
+    for sw in ((0, 1, 1), (1, 0, 1), (1, 1, 0)):
+        rc, *want = oracle.finish_pairs(packed, blob, off, lens, tasks[:600], ob.FinishParams(flank, *sw), ext_stride=768)
+        got = ctx.finish_pairs(reads, tasks[:600], api.FinishParams(flank, *sw), ext_stride=768)
+        common.same_finish_output(got, want)
+    reads.free()
+
+
+def test_finish_pairs_dev_stays_on_the_device(ctx, oracle):
+    """The _dev form on device-resident tasks and slots (caller's workspace, caller's stream, nothing allocated by
+    the library, no host round trip between the stages), plus a pair whose record cannot be aligned."""
+    import torch
+    (codes, packed), (blob, off, lens), desc, ridx, maps, direct, distant, stale = common.finish_workload(oracle, 800, 41)
+    tasks = common.finish_tasks(desc, ridx, lens, maps, direct, distant, stale)
+    lev = np.nonzero((tasks["type"] == 0) & (tasks["err_edit_distance"] > 2))[0]
+    tasks["err_edit_distance"][lev[0]] = 0          # claims fewer errors than the read has: fill_cigar_with_lev fails
+    tasks["penalty"][lev[0]] = 1
+    rc, *want = oracle.finish_pairs(packed, blob, off, lens, tasks, ext_stride=512)
+    assert rc == 0 and want[0]["ok"].sum() == len(tasks) - 2
+    dev = torch.device("cuda", 0)
+    n = len(tasks)
+    reads = ctx.upload_reads(blob, off, lens, 1, orientations=3)
+    d_tasks = torch.from_numpy(tasks.view(np.uint8).copy()).to(dev)
+    d_res = torch.zeros(n * api.FINISH_RESULT.itemsize, dtype=torch.uint8, device=dev)
+    d_ext = torch.full((n, 512), 0x7f, dtype=torch.uint8, device=dev)
+    d_cig = torch.full((n, 1040), 0x7f, dtype=torch.uint8, device=dev)
+    d_mdz = torch.full((n, 1040), 0x7f, dtype=torch.uint8, device=dev)
+    wsb = ctx.finish_workspace_bytes(reads, n // 2)
+    d_ws = torch.zeros(wsb + 256, dtype=torch.uint8, device=dev)
+    pad = (-d_ws.data_ptr()) % 256
+    st = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    ctx.finish_pairs_dev(reads, d_tasks, n // 2, d_res, d_ext, 512, d_cig, 1040, d_mdz, 1040, d_ws[pad:], wsb,
+                         stream=st.cuda_stream)
+    st.synchronize()
+    assert ctx.take_flags(st.cuda_stream) == 0
+    reads.free()
+    res = d_res.cpu().numpy().view(api.FINISH_RESULT)
+    common.same_finish_output((res, d_ext.cpu().numpy(), d_cig.cpu().numpy(), d_mdz.cpu().numpy()), want)
+
+
 def test_emit_lev_records(ctx, oracle):
     """Accepted candidates -> 12-byte mapping records in task order (wamd_emit_lev_records_dev)."""
     import torch

@@ -149,3 +149,20 @@ def test_softclip_match(oracle, name):
     assert rc == 0
     np.testing.assert_array_equal(res, z["results"])
     np.testing.assert_array_equal(cig, z["cigars"])
+
+
+@pytest.mark.parametrize("name", gu.cases("finish"))
+def test_finish_pairs(oracle, name):
+    """The chain fixture: descriptors in, SAM fields out, as the reference's own objects produced them."""
+    import common
+    from oracle import bindings
+    packed, _ = gu.load_genome()
+    z = gu.load(name)
+    prm = bindings.default_finish_params(int(z["flank"]))
+    rc, *got = oracle.finish_pairs(packed, z["blob"], z["off"], z["lens"], z["tasks"], prm,
+                                   ext_stride=int(z["ext_stride"]))
+    assert rc == 0
+    common.same_finish_output(got, (z["results"], z["ext_cigars"], z["cigars"], z["mdz"]))
+    # the descriptors themselves follow from the wire records and the chromosome table
+    maps_dir = z["wire"][:, 4] >> 7
+    assert ((z["tasks"]["direct"] == maps_dir)).all()

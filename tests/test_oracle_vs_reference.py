@@ -229,3 +229,30 @@ def test_softclip_match(oracle, reference, lowcx, fresh, enc, W):
     np.testing.assert_array_equal(ca, cb)
     assert a["found"].sum() > 1000 and (a["del_size"] > 0).sum() > 30 and (a["del_size"] < 0).sum() > 30
     assert (a["no_mismatches"] > 0).sum() > 20 and (a["found"] == 0).sum() > 100
+
+
+@pytest.mark.parametrize("seed,m", [(21, 150), (22, 250), (23, 100)])
+def test_finish_pairs_chain(oracle, reference, seed, m):
+    """The chosen pair from its wire records to the SAM fields (sam.cpp:1555-1580, 1871-1900, 1992-2007): the
+    reference's own order on its own objects against the oracle's chain, and the Python construction of the
+    descriptors (what the GPU tests feed the entry point) against the reference's deserialize + Translate +
+    mapping_desc_t constructor."""
+    (codes, packed), (blob, off, lens), desc, ridx, maps, direct, distant, stale = common.finish_workload(
+        oracle, 500, seed, m=m)
+    _, wire, _ = oracle.serialize(maps, direct)
+    rc, tasks, res, ext, cig, mdz = reference.finish_pairs(packed, codes.numel(), desc, blob, off, lens, ridx, wire,
+                                                           distant, stale, ext_stride=768)
+    assert rc == 0 and res["ok"].all()
+    mine = common.finish_tasks(desc, ridx, lens, maps, direct, distant, stale)
+    for f in tasks.dtype.names:
+        np.testing.assert_array_equal(mine[f], tasks[f], err_msg=f)
+    rc, *got = oracle.finish_pairs(packed, blob, off, lens, tasks, ext_stride=768)
+    assert rc == 0
+    common.same_finish_output(got, (res, ext, cig, mdz))
+    # the workload reaches every branch of the chain
+    meth = np.bincount(res["method"], minlength=27)
+    assert meth[0] + meth[1] > 100 and meth[2] + meth[3] > 400 and meth[13:26].sum() > 20
+    assert (res["left_clipping"] > 0).sum() > 50 and (res["right_clipping"] > 0).sum() > 50
+    assert (res["err_edit_distance"] != tasks["err_edit_distance"]).sum() > 50
+    perfect_clipped = (res["method"] < 2) & ((res["left_clipping"] > 0) | (res["right_clipping"] > 0))
+    assert perfect_clipped.sum() > 5            # a perfect match that a clipping pass gave an ext-CIGAR keeps "<len>M"

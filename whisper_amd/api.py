@@ -76,6 +76,27 @@ CLIP_RECORD = np.dtype([("score", "<f8"), ("ref_seq_pos", "<i4"), ("ref_length",
                         ("right_clipping", "<u2"), ("cigar_len", "<u4"), ("no_clippings", "<u4"),
                         ("reserved", "<u4")])
 
+FINISH_TASK = np.dtype([("read_idx", "<u4"), ("pos", "<u4"), ("type", "<u4"), ("penalty", "<u4"), ("matching_len1", "<u4"),
+                        ("matching_len2", "<u4"), ("indel_len1", "<i4"), ("indel_len2", "<i4"), ("clipping_len", "<u4"),
+                        ("ref_seq_id", "<i4"), ("ref_seq_pos", "<i4"), ("ref_size", "<i4"), ("err_edit_distance", "<u2"),
+                        ("direct", "u1"), ("distant", "u1"), ("reserved", "<u4", (3,))])
+FINISH_RESULT = np.dtype([("score", "<f8"), ("pos", "<u4"), ("ref_seq_pos", "<i4"), ("ref_length", "<u2"),
+                          ("err_edit_distance", "<u2"), ("num_events", "<u2"), ("left_clipping", "<u2"),
+                          ("right_clipping", "<u2"), ("method", "<u2"), ("ext_cigar_len", "<u4"), ("cigar_len", "<u4"),
+                          ("mdz_len", "<u4"), ("ok", "<u4"), ("reserved", "<u4")])
+assert FINISH_TASK.itemsize == 64 and FINISH_RESULT.itemsize == 48
+
+
+class FinishParams(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("flank", "enable_short_indel_refinement", "enable_boundary_clipping",
+                                          "enable_paired_clipping")]
+
+
+def default_finish_params(flank=6):
+    # mapper/params.h: refinement, boundary and paired clipping on; flank = max_no_errors (+ sensitivity) + 1
+    return FinishParams(flank, 1, 1, 1)
+
+
 STATUS = {0: "WAMD_OK", 1: "WAMD_ERR_INVALID_ARG", 2: "WAMD_ERR_HIP", 3: "WAMD_ERR_NO_DEVICE",
           4: "WAMD_ERR_TOO_LONG", 5: "WAMD_ERR_TEXT_LEN", 6: "WAMD_ERR_RANGE",
           7: "WAMD_ERR_NO_MEMORY", 8: "WAMD_ERR_CAPACITY"}
@@ -92,7 +113,7 @@ EXPORTS = [
     "wamd_clip_overlapping_pairs", "wamd_clip_overlapping_pairs_dev", "wamd_softclip_match",
     "wamd_softclip_match_dev", "wamd_serialize_mappings",
     "wamd_serialize_mappings_dev", "wamd_sam_cigar", "wamd_sam_cigar_dev", "wamd_records_scratch_bytes", "wamd_emit_lev_records_dev",
-    "wamd_emit_lev_records_static_dev",
+    "wamd_emit_lev_records_static_dev", "wamd_finish_workspace_bytes", "wamd_finish_pairs", "wamd_finish_pairs_dev",
 ]
 
 
@@ -135,6 +156,7 @@ def lib():
         L.wamd_align_workspace_bytes.restype = C.c_uint64
         L.wamd_reads_count.restype = C.c_uint32
         L.wamd_records_scratch_bytes.restype = C.c_uint64
+        L.wamd_finish_workspace_bytes.restype = C.c_uint64
         _lib = L
     return _lib
 
@@ -348,6 +370,32 @@ class Context:
         _check(lib().wamd_sam_cigar(self.h, C.c_uint32(n), _ptr(ext), C.c_uint32(es), _ptr(cig), C.c_uint32(os_),
                                     _ptr(mdz), C.c_uint32(os_), _ptr(cbin), C.c_uint32(es + 4), _ptr(lens)))
         return cig, mdz, cbin, lens
+
+    def finish_pairs(self, reads, tasks, params=None, ext_stride=512):
+        """store_mapped_pair_reads' finish of the chosen pairs (sam.cpp:1871-1900, 1992-2007): returns results,
+        ext-CIGARs, SAM CIGARs, MD:Z; slots 2i / 2i + 1 = p.first / p.second of pair i."""
+        t = np.ascontiguousarray(tasks, FINISH_TASK)
+        prm = params or default_finish_params()
+        n = len(t)
+        res = np.zeros(n, FINISH_RESULT)
+        ext = np.zeros((n, ext_stride), np.uint8)
+        cig = np.zeros((n, 2 * ext_stride + 16), np.uint8)
+        mdz = np.zeros((n, 2 * ext_stride + 16), np.uint8)
+        _check(lib().wamd_finish_pairs(self.h, reads.h, _ptr(t), C.c_uint32(n // 2), C.byref(prm), _ptr(res), _ptr(ext),
+                                       C.c_uint32(ext_stride), _ptr(cig), C.c_uint32(cig.shape[1]), _ptr(mdz),
+                                       C.c_uint32(mdz.shape[1])))
+        return res, ext, cig, mdz
+
+    def finish_workspace_bytes(self, reads, n_pairs):
+        return int(lib().wamd_finish_workspace_bytes(reads.h, C.c_uint32(n_pairs)))
+
+    def finish_pairs_dev(self, reads, d_tasks, n_pairs, d_results, d_ext, ext_stride, d_cigars, cigar_stride, d_mdz,
+                         mdz_stride, d_ws, ws_bytes, params=None, stream=None):
+        prm = params or default_finish_params()
+        _check(lib().wamd_finish_pairs_dev(self.h, reads.h, _ptr(d_tasks), C.c_uint32(n_pairs), C.byref(prm),
+                                           _ptr(d_results), _ptr(d_ext), C.c_uint32(ext_stride), _ptr(d_cigars),
+                                           C.c_uint32(cigar_stride), _ptr(d_mdz), C.c_uint32(mdz_stride), _ptr(d_ws),
+                                           C.c_uint64(ws_bytes), C.c_void_p(stream or 0)))
 
     def serialize_mappings(self, mappings, direction):
         """candidate_mapping_t::serialize for a batch (results.cpp:161-217)."""

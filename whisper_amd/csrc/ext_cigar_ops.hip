@@ -61,6 +61,10 @@ __global__ __launch_bounds__(256) void indel_ext_cigar_kernel(const uint8_t* __r
     r.err_edit_distance = r.num_events = r.ref_length = r.left_clipping = r.right_clipping = r.method = 0;
     r.reserved = 0;
     uint8_t* slot = cigars + (uint64_t)gid * cigar_stride;
+    if (t.read_idx == WAMD_READ_NONE) {   // a slot without a task: skipped, its ext-CIGAR left alone, no flag
+        results[gid] = r;
+        return;
+    }
     slot[0] = 0;
     uint32_t err = 0;
     uint32_t m = 0;

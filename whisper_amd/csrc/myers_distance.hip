@@ -571,7 +571,11 @@ __global__ __launch_bounds__(BLOCK) WAMD_KATTR void myers_distance_kernel(
         const uint32_t err = decode_task(task, rv, g, max_text_len, 32u * NW, t);
         read_idx = task.read_idx;
         ref_pos = task.ref_pos;
-        if (err) {
+        if (task.read_idx == WAMD_READ_NONE) {   // a slot without a task: skipped, no flag
+            results[gid].edit_distance = RESULT_ERROR;
+            results[gid].pos = 0;
+            valid = false;
+        } else if (err) {
             raise_flag(flags, err);
             results[gid].edit_distance = RESULT_ERROR;
             results[gid].pos = err;
@@ -794,7 +798,11 @@ __global__ __launch_bounds__(BLOCK) void myers_band_kernel(
         const uint32_t err = decode_task(task, rv, g, max_text_len, 32u * rv.words32, t);
         read_idx = task.read_idx;
         ref_pos = task.ref_pos;
-        if (err) {
+        if (task.read_idx == WAMD_READ_NONE) {   // a slot without a task: skipped, no flag
+            results[gid].edit_distance = RESULT_ERROR;
+            results[gid].pos = 0;
+            valid = false;
+        } else if (err) {
             raise_flag(flags, err);
             results[gid].edit_distance = RESULT_ERROR;
             results[gid].pos = err;

@@ -990,6 +990,76 @@ int wamd_emit_lev_records_dev(wamd_ctx* ctx, uint32_t n, const wamd_dist_task* d
                                    d_scratch, pick(ctx, stream));
 }
 
+uint64_t wamd_finish_workspace_bytes(const wamd_reads* reads, uint32_t n_pairs)
+{
+    return reads ? finish_workspace_bytes(reads, n_pairs) : 0;
+}
+
+int wamd_finish_pairs_dev(wamd_ctx* ctx, const wamd_reads* reads, const wamd_finish_task* d_tasks, uint32_t n_pairs,
+                          const wamd_finish_params* params, wamd_finish_result* d_results, uint8_t* d_ext_cigars,
+                          uint32_t ext_stride, uint8_t* d_cigars, uint32_t cigar_stride, uint8_t* d_mdz,
+                          uint32_t mdz_stride, void* d_workspace, uint64_t workspace_bytes, void* stream)
+{
+    if (n_pairs == 0)
+        return WAMD_OK;
+    int rc = check_batch(ctx, reads, d_tasks, d_results, "wamd_finish_pairs_dev");
+    if (rc)
+        return rc;
+    if (!params || !d_ext_cigars || !d_cigars || !d_mdz || !d_workspace || (ext_stride & 3u) || ext_stride < 16 ||
+        ((uintptr_t)d_ext_cigars & 3u) || cigar_stride < 16 || mdz_stride < 16) {
+        set_error("wamd_finish_pairs_dev: missing buffer, or a stride too small / ext_stride not a multiple of 4");
+        return WAMD_ERR_INVALID_ARG;
+    }
+    return launch_finish_pairs(ctx, reads, d_tasks, n_pairs, params, d_results, d_ext_cigars, ext_stride, d_cigars,
+                               cigar_stride, d_mdz, mdz_stride, d_workspace, workspace_bytes, pick(ctx, stream));
+}
+
+int wamd_finish_pairs(wamd_ctx* ctx, const wamd_reads* reads, const wamd_finish_task* tasks, uint32_t n_pairs,
+                      const wamd_finish_params* params, wamd_finish_result* results, uint8_t* ext_cigars,
+                      uint32_t ext_stride, uint8_t* cigars, uint32_t cigar_stride, uint8_t* mdz, uint32_t mdz_stride)
+{
+    if (n_pairs == 0)
+        return WAMD_OK;
+    int rc = check_batch(ctx, reads, tasks, results, "wamd_finish_pairs");
+    if (rc)
+        return rc;
+    if (!params || !ext_cigars || !cigars || !mdz || n_pairs > 0x3fffffffu)
+        return WAMD_ERR_INVALID_ARG;
+    WAMD_HIP(hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> hold(ctx->host_mutex);
+    auto up = [](uint64_t x) { return (x + 255) / 256 * 256; };
+    const uint64_t n = 2ull * n_pairs;
+    const uint64_t tb = n * sizeof(wamd_finish_task), rb = n * sizeof(wamd_finish_result), eb = n * ext_stride,
+                   cb = n * cigar_stride, mb = n * mdz_stride, wb = finish_workspace_bytes(reads, n_pairs);
+    rc = ensure_stage(ctx, up(tb) + up(rb) + up(eb) + up(cb) + up(mb) + up(wb) + 256, 0);
+    if (rc)
+        return rc;
+    char* base = (char*)(((uintptr_t)ctx->d_stage + 255) & ~(uintptr_t)255);
+    auto* d_tasks = (wamd_finish_task*)base;
+    auto* d_res = (wamd_finish_result*)(base + up(tb));
+    auto* d_ext = (uint8_t*)(base + up(tb) + up(rb));
+    auto* d_cig = d_ext + up(eb);
+    auto* d_mdz = d_cig + up(cb);
+    void* d_ws = d_mdz + up(mb);
+    hipStream_t s = ctx->stream;
+    WAMD_HIP(hipMemcpyAsync(d_tasks, tasks, tb, hipMemcpyHostToDevice, s));
+    rc = wamd_finish_pairs_dev(ctx, reads, d_tasks, n_pairs, params, d_res, d_ext, ext_stride, d_cig, cigar_stride,
+                               d_mdz, mdz_stride, d_ws, wb, s);
+    if (rc)
+        return rc;
+    WAMD_HIP(hipMemcpyAsync(results, d_res, rb, hipMemcpyDeviceToHost, s));
+    WAMD_HIP(hipMemcpyAsync(ext_cigars, d_ext, eb, hipMemcpyDeviceToHost, s));
+    WAMD_HIP(hipMemcpyAsync(cigars, d_cig, cb, hipMemcpyDeviceToHost, s));
+    WAMD_HIP(hipMemcpyAsync(mdz, d_mdz, mb, hipMemcpyDeviceToHost, s));
+    uint32_t flags = 0;
+    rc = fetch_flags(ctx, s, &flags);
+    if (!rc && (flags & FLAG_CIGAR)) {
+        set_error("wamd_finish_pairs: an ext-CIGAR, CIGAR or MD:Z does not fit its stride");
+        return WAMD_ERR_INVALID_ARG;
+    }
+    return rc ? rc : flags_to_status(flags);
+}
+
 int wamd_emit_lev_records_static_dev(wamd_ctx* ctx, uint32_t n, const wamd_dist_task* d_tasks,
                                      const wamd_dist_result* d_results, const uint32_t* d_record_pos,
                                      const uint8_t* d_direction, uint8_t* d_records, uint32_t* d_count, void* stream)

@@ -172,6 +172,12 @@ int launch_emit_lev_records(wamd_ctx* ctx, uint32_t n, const wamd_dist_task* d_t
                             const uint8_t* d_direction, uint8_t* d_records, uint32_t* d_count, void* d_scratch,
                             hipStream_t s);
 
+uint64_t finish_workspace_bytes(const wamd_reads* r, uint32_t n_pairs);
+int launch_finish_pairs(wamd_ctx* ctx, const wamd_reads* r, const wamd_finish_task* d_tasks, uint32_t n_pairs,
+                        const wamd_finish_params* prm, wamd_finish_result* d_results, uint8_t* d_ext, uint32_t ext_stride,
+                        uint8_t* d_cigars, uint32_t cigar_stride, uint8_t* d_mdz, uint32_t mdz_stride, void* d_ws,
+                        uint64_t ws_bytes, hipStream_t s);
+
 int records_static_init(int device);   // with `device` current; once per device
 int launch_emit_lev_records_static(wamd_ctx* ctx, uint32_t n, const wamd_dist_task* d_tasks,
                                    const wamd_dist_result* d_results, const uint32_t* d_record_pos,
