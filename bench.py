@@ -31,18 +31,66 @@ from whisper_amd import api, gather, synth  # noqa: E402
 
 M, K_ERR = 150, 12
 W = M + 2 * K_ERR
-# Algorithmic VALU work of one S1 task (DESIGN.md "distance kernel"): per text column the
-# recurrence takes 10 instructions per 32-bit dword of the bit-vector (and, add-with-carry,
-# 3 x bitop3, or, 2 x and, 2 x funnel shift) and the score / minimum / tie-break / early-exit
-# bookkeeping 20, over the W + 1 - wn columns LevMyers256 iterates (LevMyers256.hpp:138).
 DWORDS = (M - 1) // 32 + 1
 N_COLS = W + 1 - (M - 1) // 64
-LANE_OPS_PER_TASK = N_COLS * (DWORDS * 10 + 20)
+# The op model of `roofline` is THE KERNEL'S OWN INSTRUCTION COUNT per lane and text column,
+# i.e. `frac` is an issue-slot utilisation of the 2-cycle VALU peak, not a distance from an algorithmic optimum:
+#   exact mode   myers_distance_kernel: 10 per 32-bit dword of the bit-vector + 20 of bookkeeping, over the
+#                W + 1 - wn columns LevMyers256 iterates (LevMyers256.hpp:138)
+#   accepted-only myers_band_kernel<2>: 2 dwords x 9 + 6 per sliding column, 2 x 10 + 24 per fixed column
+# SURVEY 8(d)'s figure for the same task (40 lane-ops per 64-bit word-column + 8: 175 x 128 = 22 400) is reported
+# beside it as `survey_8d`; on gfx950 it is not a lower bound (v_bitop3 and carry chains halve it), so its
+# fraction can exceed 1.
+LANE_OPS_EXACT = N_COLS * (DWORDS * 10 + 20)
+BAND_FS = (N_COLS + K_ERR - 64 + 7) // 8 * 8
+LANE_OPS_BAND = BAND_FS * 24 + (N_COLS - BAND_FS) * 44
+LANE_OPS_SURVEY_8D = (W + 1) * (((M - 1) // 64 + 1) * 40 + 8)
 # algorithmic bytes per task: 2-bit read + 2-bit window + 16 B task + 4 B result
 BYTES_PER_TASK = (M + 3) // 4 + (W + 3 + 3) // 4 + 16 + 4
 # MI355X: 256 CUs x 4 SIMD x 32 lanes/clk x 2.4 GHz (MI355X_MICROARCH.md: SIMD-32, 2400 MHz)
 PEAK_VALU_LANEOPS = 256 * 4 * 32 * 2.4e9
 PEAK_HBM = 8.0e12
+
+
+def roof_valu(units, ops_per_unit, ms, kernel=None):
+    a = units * ops_per_unit / (ms * 1e-3)
+    r = {"bound": "valu", "achieved": a / 1e12, "peak": PEAK_VALU_LANEOPS / 1e12,
+         "unit": "T lane-op/s (32-bit integer VALU)", "frac": a / PEAK_VALU_LANEOPS, "traffic": None,
+         "model": "kernel instruction count: %d lane-ops per unit" % ops_per_unit}
+    if kernel:
+        r["kernel"] = kernel
+    return r
+
+
+def roof_hbm(units, bytes_per_unit, ms, kernel=None):
+    a = units * bytes_per_unit / (ms * 1e-3)
+    r = {"bound": "hbm", "achieved": a / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": a / PEAK_HBM,
+         "traffic": None, "algorithmic_bytes_per_unit": bytes_per_unit}
+    if kernel:
+        r["kernel"] = kernel
+    return r
+
+
+def measured_counters():
+    """Per-kernel PMC figures of the committed profile of this tree, if any (profiles/round2_counters.json):
+    HBM bytes per unit and VALU instructions per unit, keyed by the extras / roofline tag."""
+    f = os.path.join(ROOT, "profiles", "round2_counters.json")
+    try:
+        return json.load(open(f))
+    except Exception:
+        return {}
+
+
+def host_info():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"cpu_model": model, "os_cpu_count": os.cpu_count()}
 
 
 def env_int(name, default):
@@ -66,24 +114,38 @@ def build_workload(device, n_tasks, genome_symbols, seed, true_frac=0.5):
         lens.cpu().numpy().astype(np.uint32), tasks
 
 
+CANDIDATES_PER_READ = 4   # c: SURVEY 3.4 implies 4-8 SA entries per anchor on a repetitive genome
+
+
 def cpu_baseline(packed_host, ref_size, blob, off, lens, tasks, sample, threads):
-    """Reference (or port) on the host cores, bounded sample of the same tasks."""
+    """Reference (or port) on the host cores, bounded sample of the same tasks.  The step's workload has one read
+    per candidate, so `value` charges the CPU one preprocess() per candidate; the reference preprocesses once per
+    read (mapping_core_sa.cpp:212-213).  preprocess() is therefore also timed alone and the rate a candidate sees
+    when its read's table is shared by c = CANDIDATES_PER_READ candidates is reported next to it."""
     from oracle import bindings
     t = tasks[:sample]
+    info = host_info()
     if bindings.have_reference():
         try:
             ref = bindings.Reference()
-            ref.distance(packed_host, ref_size, blob, off, lens, 0, t[:4096], -1, max_query_len=255,
-                         max_text_len=M + 2 * K_ERR + 2, nthreads=threads)
+            kw = dict(max_query_len=255, max_text_len=M + 2 * K_ERR + 2, nthreads=threads)
+            ref.distance(packed_host, ref_size, blob, off, lens, 0, t[:4096], -1, **kw)
             t0 = time.perf_counter()
-            rc, res = ref.distance(packed_host, ref_size, blob, off, lens, 0, t, -1,
-                                   max_query_len=255, max_text_len=M + 2 * K_ERR + 2,
-                                   nthreads=threads)
+            rc, res = ref.distance(packed_host, ref_size, blob, off, lens, 0, t, -1, **kw)
             dt = time.perf_counter() - t0
             assert rc == 0
+            n_pre = int(t["read_idx"].max()) + 1
+            t0 = time.perf_counter()
+            ref.preprocess_only(blob, off, lens[:n_pre], 0, **kw)
+            dt_pre = time.perf_counter() - t0
+            dp_only = len(t) / max(dt - dt_pre, 1e-9)
+            c = CANDIDATES_PER_READ
+            at_c = len(t) / (max(dt - dt_pre, 1e-9) + dt_pre / c)
             return dict(value=len(t) / dt, unit="candidates/s", cores=threads, kind="reference",
                         sample="first %d of the step's S1 tasks, LevMyers256<avx2> preprocess + "
-                               "dynamicProgramming per task, %d threads, %.2f s" % (len(t), threads, dt)), res
+                               "dynamicProgramming per task, %d threads, %.2f s" % (len(t), threads, dt),
+                        preprocess_reads_per_s=n_pre / dt_pre, dynamic_programming_only_per_s=dp_only,
+                        candidates_per_read_c=c, value_at_c_candidates_per_read=at_c, host=info), res
         except Exception as e:  # e.g. no AVX2 on this host
             sys.stderr.write("reference baseline unavailable (%s); timing the port\n" % e)
     from concurrent.futures import ThreadPoolExecutor
@@ -96,20 +158,76 @@ def cpu_baseline(packed_host, ref_size, blob, off, lens, tasks, sample, threads)
     dt = time.perf_counter() - t0
     return dict(value=len(t) / dt, unit="candidates/s", cores=threads, kind="port",
                 sample="first %d of the step's S1 tasks, scalar C restatement, %d threads, %.2f s"
-                       % (len(t), threads, dt)), np.concatenate(parts)
+                       % (len(t), threads, dt), host=info), np.concatenate(parts)
+
+
+def boundary_costs(ctx, device, blob, off, lens, tasks, n):
+    """What the boundary costs when it hands over HOST buffers (never `value`): the upload of the reads
+    (wamd_reads_upload: H2D + the prepare kernels, per read and orientation pair), the synchronous host-pointer
+    call, and a two-stream pipeline of the _dev entry point over pinned buffers (H2D of 16 B tasks, kernel, D2H of
+    8 B results overlapped chunk by chunk)."""
+    out = {}
+    t0 = time.perf_counter()
+    reads = ctx.upload_reads(blob, off, lens, api.READS_NIBBLE, orientations=3)
+    ctx.synchronize()
+    up = time.perf_counter() - t0
+    out["reads_upload_ms"] = up * 1e3
+    out["reads_upload_ns_per_read"] = up / len(lens) * 1e9
+    ctx.dynamic_programming(reads, tasks[:1 << 16], -1)          # staging buffers grow once
+    t0 = time.perf_counter()
+    res = ctx.dynamic_programming(reads, tasks, -1)
+    dt = time.perf_counter() - t0
+    out["host_pointer_call_candidates_per_s"] = n / dt
+    # pipeline: pinned host tasks / results, chunks alternate between two streams
+    h_tasks = torch.from_numpy(tasks.view(np.uint8).reshape(n, 16)).pin_memory()
+    h_res = torch.empty((n, 8), dtype=torch.uint8).pin_memory()
+    n_chunks = 16
+    bounds = np.linspace(0, n, n_chunks + 1).astype(np.int64)
+    cmax = int(np.diff(bounds).max())
+    streams = [torch.cuda.Stream(device=device) for _ in range(2)]
+    d_t = [torch.empty((cmax, 16), dtype=torch.uint8, device=device) for _ in range(2)]
+    d_r = [torch.empty((cmax, 8), dtype=torch.uint8, device=device) for _ in range(2)]
+
+    def run():
+        for ci in range(n_chunks):
+            a, b = int(bounds[ci]), int(bounds[ci + 1])
+            st = streams[ci & 1]
+            with torch.cuda.stream(st):
+                d_t[ci & 1][: b - a].copy_(h_tasks[a:b], non_blocking=True)
+                ctx.dynamic_programming_dev(reads, d_t[ci & 1], b - a, d_r[ci & 1], last_symbol=-1, stream=st.cuda_stream)
+                h_res[a:b].copy_(d_r[ci & 1][: b - a], non_blocking=True)
+        for st in streams:
+            st.synchronize()
+
+    run()
+    t0 = time.perf_counter()
+    run()
+    dt = time.perf_counter() - t0
+    out["host_to_host_two_streams_candidates_per_s"] = n / dt
+    out["host_to_host_matches_sync_call"] = bool((h_res.numpy().view(api.DIST_RESULT).reshape(-1) == res).all())
+    out["bytes_over_pcie_per_candidate"] = 24
+    reads.free()
+    return out
 
 
 def run_extras(ctx, device, genome_symbols, stream, n_small):
-    """Secondary shapes of SURVEY 8d on the same resident genome: one line per kernel family,
-    timed with HIP events on the context's stream (3 launches after one warm-up)."""
+    """Secondary shapes of SURVEY 8d and the rows next to the verifier on the same resident genome: one entry per
+    kernel family, timed with HIP events on the context's stream (3 launches after one warm-up), each with the
+    roofline that bounds it.  Algorithmic bytes per unit are SURVEY 8(d)'s accounting: 2-bit read + 2-bit window +
+    task + result (+ the ext-CIGAR bytes a record scan reads and writes)."""
     codes = synth.make_genome(genome_symbols, seed=0xC0FFEE, device=device)
+    G = codes.numel()
     out = {}
 
-    def timed(fn, reps=3):
+    def timed(fn, reps=3, prep=None):
+        if prep:
+            prep()
         fn()
         ctx.synchronize()
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
         for a, b in evs:
+            if prep:
+                prep()
             a.record(stream)
             fn()
             b.record(stream)
@@ -123,18 +241,25 @@ def run_extras(ctx, device, genome_symbols, stream, n_small):
         blob, off, lens = synth.pack_reads(rd_codes, enc)
         return blob.cpu().numpy(), off.cpu().numpy().astype(np.uint64), lens.cpu().numpy().astype(np.uint32)
 
+    def dev_bytes(a):
+        return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).to(device)
+
+    def q(x):          # 2-bit bytes of x symbols
+        return (x + 3) // 4
+
     # S2: LevDiag, m = 150, k = 5, anchor = segment 2 of stage 5 (mapping_core_sa.cpp:239)
     n = n_small
     fl, fr = synth.stage_segments(150, 5)[2]
     rd = synth.make_reads(codes, n, 150, 5, 77, rc_frac=0.0, protect=(fl, fr), chunk=1 << 17)
     reads = ctx.upload_reads(*host(rd["codes"], 0), api.READS_NIBBLE, orientations=1)
     t = synth.levdiag_tasks(rd, 5, fl, fr)
-    d_t = torch.from_numpy(t.view(np.uint8)).to(device)
+    d_t = dev_bytes(t)
     d_r = torch.zeros(n, dtype=torch.int32, device=device)
     ms = timed(lambda: ctx.lev_diag_dev(reads, d_t, n, d_r))
     acc = float((d_r.cpu().numpy().view(np.uint32) <= 5).mean())
     out["S2_levdiag"] = {"shape": "CEditDist::LevDiag m=150 k=5 anchor [%d,%d)" % (fl, fr), "tasks": n,
-                         "kernel_ms": ms, "candidates_per_s": n / ms * 1e3, "accepted_fraction": acc}
+                         "kernel_ms": ms, "candidates_per_s": n / ms * 1e3, "accepted_fraction": acc,
+                         "roofline": roof_hbm(n, q(150) + q(150 + 2 * 5 + 1) + 16 + 4, ms, "levdiag_kernel<22,256>")}
     reads.free()
     del d_t, d_r
 
@@ -145,13 +270,14 @@ def run_extras(ctx, device, genome_symbols, stream, n_small):
     tc["pattern_len"] = 150
     tc["fixed_left"], tc["fixed_right"] = fl, fr
     tc["dir_gen_flag"] = 1
-    d_tc = torch.from_numpy(tc.view(np.uint8)).to(device)
+    d_tc = dev_bytes(tc)
     d_rc = torch.zeros(n, dtype=torch.int32, device=device)
     reads = ctx.upload_reads(*host(rd["codes"], 0), api.READS_NIBBLE, orientations=1)
     ms = timed(lambda: ctx.cf_filter_dev(reads, d_tc, n, d_rc))
     out["C_cf_filter"] = {"shape": "CF pre-filter m=150 anchor [%d,%d), pass iff L1 <= 20" % (fl, fr), "tasks": n,
                           "kernel_ms": ms, "candidates_per_s": n / ms * 1e3,
-                          "pass_fraction": float((d_rc.cpu().numpy().view(np.uint32) <= 20).mean())}
+                          "pass_fraction": float((d_rc.cpu().numpy().view(np.uint32) <= 20).mean()),
+                          "roofline": roof_hbm(n, 2 * q(150) + 16 + 4, ms, "cf_filter_kernel")}
     reads.free()
     del d_tc, d_rc
 
@@ -159,19 +285,36 @@ def run_extras(ctx, device, genome_symbols, stream, n_small):
     rd = synth.make_reads(codes, n, 250, 17, 78, chunk=1 << 16)
     reads = ctx.upload_reads(*host(rd["codes"], 0), api.READS_NIBBLE, orientations=3)
     t = synth.distance_tasks(rd, 250, 17)
-    d_t = torch.from_numpy(t.view(np.uint8)).to(device)
+    d_t = dev_bytes(t)
     d_r = torch.zeros(n * 2, dtype=torch.int32, device=device)
     ctx.set_max_text_len(16384)
     ms = timed(lambda: ctx.dynamic_programming_dev(reads, d_t, n, d_r, last_symbol=-1))
+    cols5 = 284 + 1 - 3
     out["S5_distance_250bp"] = {"shape": "LevMyers256 distance m=250 k=17 W=284", "tasks": n, "kernel_ms": ms,
-                                "candidates_per_s": n / ms * 1e3}
+                                "candidates_per_s": n / ms * 1e3,
+                                "roofline": roof_valu(n, cols5 * (8 * 10 + 20), ms, "myers_distance_kernel<8,256>")}
     ctx.set_distance_mode(api.DISTANCE_ACCEPTED_ONLY)
     ms = timed(lambda: ctx.dynamic_programming_dev(reads, d_t, n, d_r, last_symbol=-1))
     ctx.set_distance_mode(api.DISTANCE_EXACT)
+    fs5 = (cols5 + 17 - 96 + 7) // 8 * 8
     out["S5_accepted_only"] = {"shape": "S5 in WAMD_DISTANCE_ACCEPTED_ONLY mode (96-row band)", "tasks": n,
-                               "kernel_ms": ms, "candidates_per_s": n / ms * 1e3}
+                               "kernel_ms": ms, "candidates_per_s": n / ms * 1e3,
+                               "roofline": roof_valu(n, fs5 * (3 * 9 + 6) + (cols5 - fs5) * (3 * 10 + 24), ms,
+                                                     "myers_band_kernel<3,128> (after <2,128> deferred everything)")}
+    # K: the accepted candidates of this batch as 12-byte mapping records in task order (results.cpp:161-173)
+    d_pos = torch.from_numpy((t["ref_pos"] + 17).astype(np.uint32).view(np.int32)).to(device)
+    d_dir = torch.ones(n, dtype=torch.uint8, device=device)
+    d_rec = torch.zeros((n, 12), dtype=torch.uint8, device=device)
+    d_cnt = torch.zeros(1, dtype=torch.int32, device=device)
+    ctx.dynamic_programming_dev(reads, d_t, n, d_r, last_symbol=-1)
+    ms = timed(lambda: ctx.emit_lev_records_static_dev(n, d_t, d_r, d_pos, d_dir, d_rec, d_cnt))
+    n_acc = int(d_cnt.item())
+    out["K_emit_lev_records"] = {"shape": "accepted candidates -> 12-byte records in task order (count, scan, write)",
+                                 "tasks": n, "records": n_acc, "kernel_ms": ms, "candidates_per_s": n / ms * 1e3,
+                                 "roofline": roof_hbm(n, 2 * (16 + 8) + (4 + 1 + 12) * n_acc / n, ms,
+                                                      "records_count + records_scan + records_write")}
     reads.free()
-    del d_t, d_r
+    del d_t, d_r, d_pos, d_dir, d_rec, d_cnt
 
     # S4: fill_cigar_with_lev: distance + traceback + ext-CIGAR + refinement, m = 150, W = 177
     na = n // 4
@@ -179,7 +322,7 @@ def run_extras(ctx, device, genome_symbols, stream, n_small):
     reads = ctx.upload_reads(*host(rd["codes"], 1), api.READS_ASCII, orientations=3)
     t = synth.distance_tasks(rd, 150, 13, W=177)
     t["ref_pos"] = (rd["p"] - 13).cpu().numpy().astype(np.uint32)
-    d_t = torch.from_numpy(t.view(np.uint8)).to(device)
+    d_t = dev_bytes(t)
     stride = 512
     d_r = torch.zeros(na * api.ALIGN_RESULT.itemsize, dtype=torch.uint8, device=device)
     d_c = torch.zeros(na * stride, dtype=torch.uint8, device=device)
@@ -187,11 +330,105 @@ def run_extras(ctx, device, genome_symbols, stream, n_small):
     d_w = torch.zeros(wsb, dtype=torch.uint8, device=device)
     ms = timed(lambda: ctx.align_dev(reads, d_t, na, d_r, d_c, stride, d_w, wsb, last_symbol=0, refine=1))
     res = d_r.cpu().numpy().view(api.ALIGN_RESULT)
+    clen = float(res["cigar_len"][res["ok"] == 1].mean())
     out["S4_align"] = {"shape": "dynamicProgramming + getExtCigar + refine_ext_cigar m=150 k=13 W=177", "tasks": na,
                        "total_ms": ms, "alignments_per_s": na / ms * 1e3, "ok_fraction": float(res["ok"].mean()),
-                       "workspace_bytes": wsb}
+                       "workspace_bytes": wsb, "mean_ext_cigar_bytes": clen,
+                       "roofline": roof_hbm(na, q(150) + q(180) + 16 + 40 + clen, ms,
+                                            "myers_distance + align_classify + align_traceback x2")}
     reads.free()
-    del d_t, d_r, d_c, d_w
+    del d_t, d_r, d_w
+
+    # Rows B, L, X on the ext-CIGARs S4 just produced, as fill_cigar_with_lev leaves the records
+    # (sam_matching.cpp:737-746): every fourth read hangs over an end of its chromosome, pairs are made of
+    # neighbouring slots with the reverse read on the left
+    rec = np.zeros(na, api.CLIP_RECORD)
+    rec["score"] = res["affine_score"]
+    rec["ref_seq_pos"] = 1000 + res["begin_pos"].astype(np.int64)
+    rec["ref_length"] = np.where(res["ok"] == 1, res["end_pos"] - res["begin_pos"], 0)
+    rec["err_edit_distance"] = np.where(res["ok"] == 1, res["edit_distance"], 0)
+    ti = np.zeros(na, api.CLIP_ILLEGAL_TASK)
+    ti["read_length"] = 150
+    okr = res["ok"] == 1
+    hang = (np.arange(na) % 4 == 0) & okr
+    rec["ref_seq_pos"][hang & (np.arange(na) % 8 == 0)] = -7
+    ti["ref_size"] = np.where(hang & (np.arange(na) % 8 == 4), rec["ref_seq_pos"] + 120, 1 << 30)
+    tp = np.zeros(na // 2, api.CLIP_PAIR_TASK)
+    tp["ref_seq_id"][:, 0] = 1
+    tp["ref_seq_id"][:, 1] = np.where(okr[0::2] & okr[1::2], 1, 2)     # a pair with an unaligned read is left alone
+    tp["read_length"] = 150
+    tp["direct"][:, 1] = 1
+    rec_pairs = rec.copy()
+    rec_pairs["ref_seq_pos"][0::2] = 5000
+    rec_pairs["ref_seq_pos"][1::2] = 5000 + (np.arange(na // 2) % 100)
+    d_rec0, d_recp0, d_cig0 = dev_bytes(rec), dev_bytes(rec_pairs), d_c.clone()
+    d_rec, d_ti, d_tp = torch.empty_like(d_rec0), dev_bytes(ti), dev_bytes(tp)
+    scan = 2 * (clen + 32)          # an ext-CIGAR and its record, read and written back
+
+    def fresh(src):
+        def go():
+            with torch.cuda.stream(stream):
+                d_rec.copy_(src, non_blocking=True)
+                d_c.copy_(d_cig0, non_blocking=True)
+        return go
+
+    ms = timed(lambda: ctx.clip_illegal_dev(na, d_ti, d_rec, d_c, stride), prep=fresh(d_rec0))
+    out["L_clip_illegal"] = {"shape": "clipIllegalPositions on S4's ext-CIGARs, 1 in 4 over a chromosome end",
+                             "records": na, "kernel_ms": ms, "records_per_s": na / ms * 1e3,
+                             "roofline": roof_hbm(na, scan + 8, ms, "clip_illegal_kernel")}
+    ms = timed(lambda: ctx.clip_boundary_dev(na, d_rec, d_c, stride), prep=fresh(d_rec0))
+    out["B_clip_boundary"] = {"shape": "clipBoundaryPositions on S4's ext-CIGARs", "records": na, "kernel_ms": ms,
+                              "records_per_s": na / ms * 1e3, "roofline": roof_hbm(na, scan, ms, "clip_boundary_kernel")}
+    ms = timed(lambda: ctx.clip_overlapping_pairs_dev(na // 2, d_tp, d_rec, d_c, stride), prep=fresh(d_recp0))
+    out["L_clip_overlapping_pairs"] = {"shape": "clipOverlappingPairs, reverse read left of its mate by 0..99", "pairs": na // 2,
+                                       "kernel_ms": ms, "pairs_per_s": na // 2 / ms * 1e3,
+                                       "roofline": roof_hbm(na // 2, 2 * scan + 16, ms, "clip_pairs_kernel")}
+    d_sc = torch.zeros(na * 336, dtype=torch.uint8, device=device)
+    d_sm = torch.zeros(na * 336, dtype=torch.uint8, device=device)
+    d_sl = torch.zeros(na * 16, dtype=torch.uint8, device=device)
+    fresh(d_rec0)()
+    ms = timed(lambda: ctx.sam_cigar_dev(na, d_c, stride, d_sc, 336, d_sm, 336, d_sl))
+    sl = d_sl.cpu().numpy().view(api.SAM_CIGAR_LEN)
+    out["X_sam_cigar"] = {"shape": "extract_cigar_and_mdz on S4's ext-CIGARs", "records": na, "kernel_ms": ms,
+                          "records_per_s": na / ms * 1e3,
+                          "roofline": roof_hbm(na, clen + float(sl["cigar_len"].mean() + sl["mdz_len"].mean()) + 16, ms,
+                                               "sam_cigar_kernel")}
+    del d_rec0, d_recp0, d_cig0, d_rec, d_ti, d_tp, d_sc, d_sm, d_sl, d_c
+
+    # The same rows as ONE call on mapping records (sam.cpp:1871-1900, 1992-2007): pairs of neighbouring reads,
+    # lev records carrying the distance S4 found, perfect matches where it is 0
+    np_pairs = na // 2
+    ft = np.zeros(na, api.FINISH_TASK)
+    ft["read_idx"] = np.arange(na, dtype=np.uint32)
+    is_rc = rd["is_rc"].cpu().numpy()
+    p0 = rd["p"].cpu().numpy().astype(np.int64)
+    ft["direct"] = ~is_rc
+    ft["pos"] = np.where(is_rc, p0 + 149, p0)
+    ft["err_edit_distance"] = np.where(res["ok"] == 1, res["edit_distance"], 13)
+    ft["ref_seq_pos"] = p0 + 1
+    ft["ref_size"] = G
+    d_ft = dev_bytes(ft)
+    d_fr = torch.zeros(na * api.FINISH_RESULT.itemsize, dtype=torch.uint8, device=device)
+    d_fe = torch.zeros(na * 352, dtype=torch.uint8, device=device)
+    d_fc = torch.zeros(na * 352, dtype=torch.uint8, device=device)
+    d_fm = torch.zeros(na * 352, dtype=torch.uint8, device=device)
+    reads_fin = ctx.upload_reads(*host(rd["codes"], 1), api.READS_ASCII, orientations=3)
+    fwb = ctx.finish_workspace_bytes(reads_fin, np_pairs)
+    d_fw = torch.zeros(fwb + 256, dtype=torch.uint8, device=device)
+    padw = (-d_fw.data_ptr()) % 256
+    prm = api.default_finish_params(14)
+    ms = timed(lambda: ctx.finish_pairs_dev(reads_fin, d_ft, np_pairs, d_fr, d_fe, 352, d_fc, 352, d_fm, 352, d_fw[padw:],
+                                            fwb, params=prm))
+    fres = d_fr.cpu().numpy().view(api.FINISH_RESULT)
+    out["N1_finish_pairs"] = {"shape": "mapping records -> fill_cigar -> clipIllegal / Boundary / OverlappingPairs -> CIGAR + MD:Z, "
+                                       "m=150 flank=14, one call, nothing leaves the device", "pairs": np_pairs,
+                              "total_ms": ms, "reads_per_s": na / ms * 1e3, "ok_fraction": float(fres["ok"].mean()),
+                              "perfect_fraction": float((fres["method"] < 2).mean()),
+                              "roofline": roof_hbm(na, 64 + 48 + q(150) + q(180) + float(fres["ext_cigar_len"].mean()) +
+                                                   float(fres["cigar_len"].mean() + fres["mdz_len"].mean()), ms,
+                                                   "finish_prepare + align + indel_ext_cigar + finish_merge + clip_* + sam_cigar + finish_final")}
+    reads_fin.free()
+    del d_ft, d_fr, d_fe, d_fc, d_fm, d_fw
 
     # S3 / S6: mate rescue with traceback - long windows, k' = 2 * floor(0.09 m) (W = mu + 7 sigma + 2k')
     def rescue(tag, m, k, W, seed, count):
@@ -200,7 +437,7 @@ def run_extras(ctx, device, genome_symbols, stream, n_small):
         t_ = synth.distance_tasks(rd_, m, k, W=W)
         off_ = np.random.default_rng(seed).integers(k, W - m - k, count)      # the mate sits anywhere in the window
         t_["ref_pos"] = (rd_["p"].cpu().numpy() - off_).astype(np.uint32)
-        d_t_ = torch.from_numpy(t_.view(np.uint8)).to(device)
+        d_t_ = dev_bytes(t_)
         stride_ = 4 * ((2 * (m + k) + 8 + 3) // 4)
         d_r_ = torch.zeros(count * api.ALIGN_RESULT.itemsize, dtype=torch.uint8, device=device)
         d_c_ = torch.zeros(count * stride_, dtype=torch.uint8, device=device)
@@ -208,9 +445,14 @@ def run_extras(ctx, device, genome_symbols, stream, n_small):
         d_w_ = torch.zeros(wsb_, dtype=torch.uint8, device=device)
         ms_ = timed(lambda: ctx.align_dev(reads_, d_t_, count, d_r_, d_c_, stride_, d_w_, wsb_, last_symbol=0, refine=1))
         res_ = d_r_.cpu().numpy().view(api.ALIGN_RESULT)
+        cols_ = W + 1 - (m - 1) // 64
+        dw_ = (m - 1) // 32 + 1
         out[tag] = {"shape": "mate rescue: dynamicProgramming + getExtCigar m=%d k=%d W=%d" % (m, k, W), "tasks": count,
                     "total_ms": ms_, "alignments_per_s": count / ms_ * 1e3, "ok_fraction": float(res_["ok"].mean()),
-                    "mean_edit_distance": float(res_["edit_distance"][res_["ok"] == 1].mean())}
+                    "mean_edit_distance": float(res_["edit_distance"][res_["ok"] == 1].mean()),
+                    "roofline": roof_valu(count, cols_ * (dw_ * 10 + 20), ms_,
+                                          "myers_distance_kernel<%d> over the whole window, then the traceback "
+                                          "(its work is not in the model)" % dw_)}
         reads_.free()
 
     rescue("S3_rescue_150bp", 150, 26, 660, 83, na // 4)
@@ -221,11 +463,14 @@ def run_extras(ctx, device, genome_symbols, stream, n_small):
         rd = synth.make_reads(codes, na, m, k, 85 + m, chunk=1 << 16)
         reads = ctx.upload_reads(*host(rd["codes"], 0), api.READS_NIBBLE, orientations=3)
         t = synth.distance_tasks(rd, m, k)
-        d_t = torch.from_numpy(t.view(np.uint8)).to(device)
+        d_t = dev_bytes(t)
         d_r = torch.zeros(na * 2, dtype=torch.int32, device=device)
         ms = timed(lambda: ctx.dynamic_programming_dev(reads, d_t, na, d_r, last_symbol=-1))
+        cols_ = (m + 2 * k + 1 - (m - 1) // 64) if m < 256 else m + 2 * k
+        dw_ = (m - 1) // 32 + 1
         out[tag] = {"shape": "distance m=%d k=%d W=%d" % (m, k, m + 2 * k), "tasks": na, "kernel_ms": ms,
-                    "candidates_per_s": na / ms * 1e3}
+                    "candidates_per_s": na / ms * 1e3,
+                    "roofline": roof_valu(na, cols_ * (dw_ * 10 + 20), ms, "myers_distance_kernel<%d>" % dw_)}
         reads.free()
         del d_t, d_r
 
@@ -235,14 +480,41 @@ def run_extras(ctx, device, genome_symbols, stream, n_small):
     t = np.zeros(na, api.INDEL_TASK)
     for k_, v in fields.items():
         t[k_] = v
-    d_t = torch.from_numpy(t.view(np.uint8)).to(device)
+    d_t = dev_bytes(t)
     d_r = torch.zeros(na * api.MAPPING.itemsize, dtype=torch.uint8, device=device)
-    ms = timed(lambda: ctx.indel_match_dev(reads, d_t, na, d_r))
+    prm_i = api.default_indel_params()
+    prm_i.max_indel_bound = 50
+    ms = timed(lambda: ctx.indel_match_dev(reads, d_t, na, d_r, params=prm_i))
     res = d_r.cpu().numpy().view(api.MAPPING)
     out["S8_indel_match"] = {"shape": "CIndelMatching::Match m=150 max_indel=50 k=12", "tasks": na, "kernel_ms": ms,
-                             "candidates_per_s": na / ms * 1e3, "found_fraction": float((res["found"] != 0).mean())}
+                             "candidates_per_s": na / ms * 1e3, "found_fraction": float((res["found"] != 0).mean()),
+                             "roofline": roof_hbm(na, q(150) + q(250) + 16 + 40, ms, "indel_match_kernel<true>")}
+    # K: candidate_mapping_t::serialize of what Match found (results.cpp:161-217)
+    d_dir = torch.ones(na, dtype=torch.uint8, device=device)
+    d_wire = torch.zeros(na * 12, dtype=torch.uint8, device=device)
+    d_sz = torch.zeros(na, dtype=torch.uint8, device=device)
+    ms = timed(lambda: ctx.serialize_mappings_dev(na, d_r, d_dir, d_wire, d_sz))
+    out["K_serialize"] = {"shape": "candidate_mapping_t::serialize of S8's results", "records": na, "kernel_ms": ms,
+                          "records_per_s": na / ms * 1e3, "roofline": roof_hbm(na, 40 + 1 + 12 + 1, ms, "serialize_kernel")}
+    # G: GetExtCigarNew of the found mappings (fill_cigar_with_indel_matching, sam_matching.cpp:824-852)
+    idx = np.nonzero(res["found"])[0]
+    ct = np.zeros(len(idx), api.INDEL_CIGAR_TASK)
+    ct["read_idx"] = t["read_idx"][idx]
+    ct["examined_start_pos"] = res["pos"][idx]
+    for f in ("type", "matching_len1", "matching_len2", "indel_len1", "indel_len2", "clipping_len"):
+        ct[f] = res[f][idx]
+    ng = len(idx)
+    d_ct = dev_bytes(ct)
+    d_cr = torch.zeros(ng * api.INDEL_CIGAR_RESULT.itemsize, dtype=torch.uint8, device=device)
+    d_cc = torch.zeros(ng * 512, dtype=torch.uint8, device=device)
+    ms = timed(lambda: ctx.indel_ext_cigar_dev(reads, d_ct, ng, d_cr, d_cc, 512))
+    cres = d_cr.cpu().numpy().view(api.INDEL_CIGAR_RESULT)
+    out["G_indel_ext_cigar"] = {"shape": "GetExtCigarNew of S8's found mappings", "records": ng, "kernel_ms": ms,
+                                "records_per_s": ng / ms * 1e3, "ok_fraction": float(cres["ok"].mean()),
+                                "roofline": roof_hbm(ng, 40 + q(150) + q(200) + 32 + float(cres["cigar_len"].mean()), ms,
+                                                     "indel_ext_cigar_kernel")}
     reads.free()
-    del d_t, d_r
+    del d_t, d_r, d_dir, d_wire, d_sz, d_ct, d_cr, d_cc
 
     # row S: the hashing mate rescue, m = 150, W = 660 (mu + 7 sigma + 2k' of a 400 +- 30 library)
     ns = na // 4
@@ -251,15 +523,27 @@ def run_extras(ctx, device, genome_symbols, stream, n_small):
     t = np.zeros(ns, api.SOFTCLIP_TASK)
     for k_, v in fields.items():
         t[k_] = v
-    d_t = torch.from_numpy(t.view(np.uint8)).to(device)
+    d_t = dev_bytes(t)
     d_r = torch.zeros(ns * api.SOFTCLIP_RESULT.itemsize, dtype=torch.uint8, device=device)
     d_c = torch.zeros(ns * 384, dtype=torch.uint8, device=device)
     ms = timed(lambda: ctx.softclip_match_dev(reads, d_t, ns, d_r, d_c, 384, 660))
     res = d_r.cpu().numpy().view(api.SOFTCLIP_RESULT)
     out["S_softclip_match"] = {"shape": "CSoftClipping::match + getExtCigar m=150 W=660", "tasks": ns, "kernel_ms": ms,
                                "candidates_per_s": ns / ms * 1e3, "found_fraction": float((res["found"] == 1).mean()),
-                               "indel_fraction": float((res["del_size"] != 0).mean())}
+                               "indel_fraction": float((res["del_size"] != 0).mean()),
+                               "roofline": roof_hbm(ns, q(150) + q(660 + 150) + 16 + 48 + 150, ms, "softclip_match_kernel")}
     reads.free()
+    # per-kernel HBM traffic / VALU instructions from the committed PMC profile of this tree, where there is one
+    meas = measured_counters()
+    for tag, e in out.items():
+        m_ = meas.get(tag)
+        if m_ and "roofline" in e:
+            units = e.get("tasks") or e.get("records") or e.get("pairs")
+            if "hbm_bytes_per_unit" in m_:
+                e["roofline"]["traffic"] = m_["hbm_bytes_per_unit"] * units
+            if "valu_insts_per_unit" in m_ and e["roofline"]["bound"] == "valu":
+                e["roofline"]["measured_valu_frac"] = (m_["valu_insts_per_unit"] * units /
+                                                       (e.get("kernel_ms", e.get("total_ms")) * 1e-3) / PEAK_VALU_LANEOPS)
     return out
 
 
@@ -279,7 +563,24 @@ def main():
                          "the headline is measured in the default, exact mode)")
     ap.add_argument("--true-frac", type=float, default=0.5,
                     help="fraction of candidates planted at their locus (S1 = 0.5; other values are experiments)")
+    ap.add_argument("--no-boundary", action="store_true", help="skip the host-buffer (PCIe-inclusive) measurements")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, as a CHILD process, before
+    # anything here has touched the GPU, and relay the one JSON line rank 0 prints
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        child = subprocess.run(cmd, stdout=subprocess.PIPE)
+        sys.stdout.write(child.stdout.decode())
+        sys.stdout.flush()
+        raise SystemExit(child.returncode)
 
     # stdout carries the one JSON line and nothing else: libraries that write to file descriptor 1
     # (RCCL prints its version banner there at the first collective) are sent to stderr
@@ -290,8 +591,8 @@ def main():
     rank = env_int("RANK", 0)
     world = env_int("WORLD_SIZE", 1)
     local = env_int("LOCAL_RANK", 0)
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        sys.stderr.write("bench.py: --gpus %d needs torch.distributed.run; running 1 rank\n" % args.gpus)
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the verification path has no CPU fallback")
     torch.cuda.set_device(local)
@@ -444,15 +745,12 @@ def main():
         same = bool((bres[~rej] == res[~rej]).all() and (bres[rej, 0] == K_ERR + 1).all() and (bres[rej, 1] == 0).all())
         bms = float(np.mean([a.elapsed_time(b) for a, b in bev]))
         banded = {"shape": "S1 in WAMD_DISTANCE_ACCEPTED_ONLY mode: 64-row band, %d sliding + %d fixed columns"
-                           % ((N_COLS + K_ERR - 64 + 7) // 8 * 8, N_COLS - (N_COLS + K_ERR - 64 + 7) // 8 * 8),
+                           % (BAND_FS, N_COLS - BAND_FS),
                   "tasks": n, "kernel_ms": bms, "candidates_per_s": n / bms * 1e3,
-                  "accepted_identical_rejected_clamped": same}
-        # algorithmic VALU work of the banded kernel: 2 dwords x 9 + 6 per sliding column,
-        # 2 x 10 + 24 per fixed column
-        fs = (N_COLS + K_ERR - 64 + 7) // 8 * 8
-        b_ops = n * (fs * 24 + (N_COLS - fs) * 44) / (bms * 1e-3)
-        banded["roofline"] = {"bound": "valu", "achieved": b_ops / 1e12, "peak": PEAK_VALU_LANEOPS / 1e12,
-                              "unit": "T lane-op/s (32-bit integer VALU)", "frac": b_ops / PEAK_VALU_LANEOPS}
+                  "accepted_identical_rejected_clamped": same,
+                  "roofline": roof_valu(n, LANE_OPS_BAND, bms, "myers_band_kernel<2,128>")}
+        banded["roofline"]["hbm"] = {"achieved": n * BYTES_PER_TASK / (bms * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9,
+                                     "unit": "GB/s", "frac": n * BYTES_PER_TASK / (bms * 1e-3) / PEAK_HBM}
 
     if rank == 0:
         value = n * world * args.steps / dt
@@ -467,7 +765,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u64",
+            "dtype": "u32",
             "data": "synthetic",
             "config": {
                 "workload": "S1: LevMyers256 distance verification, 150 bp reads, k = 12, W = 174 "
@@ -482,26 +780,21 @@ def main():
             },
             "gcups": value * M * N_COLS / 1e9,
         }
-        a_ops = n * LANE_OPS_PER_TASK / (kernel_ms * 1e-3)
-        out["roofline"] = {
-            "bound": "valu",
-            "kernel": "myers_distance_kernel<%d,256>" % DWORDS,
-            "achieved": a_ops / 1e12,
-            "peak": PEAK_VALU_LANEOPS / 1e12,
-            "unit": "T lane-op/s (32-bit integer VALU)",
-            "frac": a_ops / PEAK_VALU_LANEOPS,
-            "kernel_ms": kernel_ms,
-            "traffic": None,
-            "hbm": {"achieved": n * BYTES_PER_TASK / (kernel_ms * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9,
-                    "unit": "GB/s", "frac": n * BYTES_PER_TASK / (kernel_ms * 1e-3) / PEAK_HBM},
-        }
-        tj = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tj):
-            try:
-                t = json.load(open(tj))
-                out["roofline"]["traffic"] = t["hbm_bytes_per_task"] * n
-            except Exception:
-                pass
+        exact = args.distance_mode == "exact"
+        meas = measured_counters().get("S1_exact" if exact else "S1_accepted_only", {})
+        out["roofline"] = roof_valu(n, LANE_OPS_EXACT if exact else LANE_OPS_BAND, kernel_ms,
+                                    "myers_distance_kernel<%d,256>" % DWORDS if exact else "myers_band_kernel<2,128>")
+        out["roofline"]["kernel_ms"] = kernel_ms
+        out["roofline"]["survey_8d"] = {"lane_ops_per_task": LANE_OPS_SURVEY_8D,
+                                        "frac": n * LANE_OPS_SURVEY_8D / (kernel_ms * 1e-3) / PEAK_VALU_LANEOPS,
+                                        "note": "SURVEY 8(d)'s count for the same task; not a lower bound on gfx950"}
+        out["roofline"]["hbm"] = {"achieved": n * BYTES_PER_TASK / (kernel_ms * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9,
+                                  "unit": "GB/s", "frac": n * BYTES_PER_TASK / (kernel_ms * 1e-3) / PEAK_HBM,
+                                  "algorithmic_bytes_per_task": BYTES_PER_TASK}
+        if "hbm_bytes_per_unit" in meas:
+            out["roofline"]["traffic"] = meas["hbm_bytes_per_unit"] * n
+        if "valu_insts_per_unit" in meas:
+            out["roofline"]["measured_valu_frac"] = meas["valu_insts_per_unit"] * n / (kernel_ms * 1e-3) / PEAK_VALU_LANEOPS
         if not args.no_cpu_baseline:
             threads = max(1, min(16, os.cpu_count() or 1))
             base, cpu_res = cpu_baseline(packed.cpu().numpy(), ref_size, blob, off, lens, tasks,
@@ -514,6 +807,8 @@ def main():
             out["cpu_baseline"] = base
             if not same:
                 out["parity_error"] = "GPU and CPU results differ on the baseline sample"
+        if not args.no_boundary and world == 1:
+            out["boundary"] = boundary_costs(ctx, device, blob, off, lens, tasks, n)
         if not args.no_extras and world == 1:
             del d_tasks, d_results, d_results_alt, res_bufs, last_buf, d_records, d_scratch, d_rec_pos, d_dir, d_count
             reads.free()
@@ -523,6 +818,8 @@ def main():
             out["extras"]["S1_accepted_only"] = banded
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
+        if out.get("parity_error"):
+            raise SystemExit(1)
     if dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -475,3 +475,12 @@ def _r_finish_pairs(self, genome, ref_size, desc, reads, offsets, lens, read_idx
 
 Oracle.finish_pairs = _o_finish_pairs
 Reference.finish_pairs = _r_finish_pairs
+
+
+def _r_preprocess_only(self, reads, offsets, lens, encoding, max_query_len=255, max_text_len=180, nthreads=1):
+    """LevMyers::preprocess once per read and nothing else (timing aid of bench.py's cpu_baseline)."""
+    return self.lib.ref_preprocess_batch(_p(reads), _p(offsets), _p(lens), C.c_uint32(len(lens)), C.c_int(encoding),
+                                         C.c_uint32(max_query_len), C.c_uint32(max_text_len), C.c_int(nthreads))
+
+
+Reference.preprocess_only = _r_preprocess_only

@@ -901,3 +901,23 @@ REF_API int ref_finish_pairs_batch(const uint8_t* genome, uint32_t ref_size, con
     }
     return 0;
 }
+
+
+/* preprocess() alone, once per read (mapping_core_sa.cpp:212-213): lets the baseline say what a
+ * candidate costs when its read's table is shared by c candidates. */
+REF_API int ref_preprocess_batch(const uint8_t* reads, const uint64_t* offsets, const uint32_t* lens, uint32_t n_reads,
+                                 int encoding, uint32_t max_query_len, uint32_t max_text_len, int nthreads)
+{
+    uint8_t dummy[64] = {0};
+    parallel_for(n_reads, nthreads, [&](int, uint32_t b, uint32_t e) {
+        Verifiers v(max_query_len, max_text_len, 0, dummy, 64, 0);
+        for (uint32_t i = b; i < e; ++i) {
+            LevMyers* lm = v.pick(WAMD_VARIANT_AUTO, lens[i]);
+            if (encoding == WAMD_READS_NIBBLE)
+                lm->preprocess(const_cast<uint8_t*>(reads + offsets[i]), lens[i], genome_t::direct);
+            else
+                lm->preprocessRawSeq(const_cast<uint8_t*>(reads + offsets[i]), lens[i], genome_t::direct);
+        }
+    });
+    return 0;
+}

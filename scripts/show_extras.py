@@ -1,10 +1,13 @@
-"""Debug aid: prints the secondary-shape timings of the bench line in gpurun_out/b.json."""
+"""Debug aid: prints the timings and rooflines of a bench line (default gpurun_out/b.json)."""
 import json
 import sys
 
-d = json.load(open(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/b.json"))
+d = json.loads(open(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/b.json").read().strip().splitlines()[-1])
 print("S1 %.3f ms/step, %.3g candidates/s, roofline.frac %.3f" % (d["ms_per_step"], d["value"], d["roofline"]["frac"]))
 for k, v in d.get("extras", {}).items():
     ms = v.get("kernel_ms", v.get("total_ms"))
-    rate = v.get("candidates_per_s", v.get("alignments_per_s"))
-    print("%-20s %8.3f ms  %.4g /s  (%d tasks)" % (k, ms, rate, v["tasks"]))
+    units = v.get("tasks") or v.get("records") or v.get("pairs")
+    r = v.get("roofline", {})
+    print("%-26s %8.3f ms  %10.4g units/s  %-5s frac %.3f" % (k, ms, units / ms * 1e3, r.get("bound", "-"), r.get("frac", 0)))
+for k, v in d.get("boundary", {}).items():
+    print("boundary.%-45s %s" % (k, v))

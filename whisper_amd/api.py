@@ -417,6 +417,32 @@ class Context:
         _check(lib().wamd_levdiag_dev(self.h, reads.h, _ptr(d_tasks), C.c_uint32(n),
                                       _ptr(d_results), C.c_void_p(stream or 0)))
 
+    def indel_ext_cigar_dev(self, reads, d_tasks, n, d_results, d_cigars, cigar_stride, stream=None):
+        _check(lib().wamd_indel_ext_cigar_dev(self.h, reads.h, _ptr(d_tasks), C.c_uint32(n), _ptr(d_results),
+                                              _ptr(d_cigars), C.c_uint32(cigar_stride), C.c_void_p(stream or 0)))
+
+    def clip_boundary_dev(self, n, d_records, d_cigars, cigar_stride, stream=None):
+        _check(lib().wamd_clip_boundary_dev(self.h, C.c_uint32(n), _ptr(d_records), _ptr(d_cigars),
+                                            C.c_uint32(cigar_stride), C.c_void_p(stream or 0)))
+
+    def clip_illegal_dev(self, n, d_tasks, d_records, d_cigars, cigar_stride, stream=None):
+        _check(lib().wamd_clip_illegal_dev(self.h, C.c_uint32(n), _ptr(d_tasks), _ptr(d_records), _ptr(d_cigars),
+                                           C.c_uint32(cigar_stride), C.c_void_p(stream or 0)))
+
+    def clip_overlapping_pairs_dev(self, n_pairs, d_tasks, d_records, d_cigars, cigar_stride, stream=None):
+        _check(lib().wamd_clip_overlapping_pairs_dev(self.h, C.c_uint32(n_pairs), _ptr(d_tasks), _ptr(d_records),
+                                                     _ptr(d_cigars), C.c_uint32(cigar_stride), C.c_void_p(stream or 0)))
+
+    def sam_cigar_dev(self, n, d_ext, ext_stride, d_cigars, cigar_stride, d_mdz, mdz_stride, d_lens, d_bin=None,
+                      bin_stride=0, stream=None):
+        _check(lib().wamd_sam_cigar_dev(self.h, C.c_uint32(n), _ptr(d_ext), C.c_uint32(ext_stride), _ptr(d_cigars),
+                                        C.c_uint32(cigar_stride), _ptr(d_mdz), C.c_uint32(mdz_stride), _ptr(d_bin),
+                                        C.c_uint32(bin_stride), _ptr(d_lens), C.c_void_p(stream or 0)))
+
+    def serialize_mappings_dev(self, n, d_mappings, d_direction, d_out, d_sizes, stream=None):
+        _check(lib().wamd_serialize_mappings_dev(self.h, C.c_uint32(n), _ptr(d_mappings), _ptr(d_direction), _ptr(d_out),
+                                                 _ptr(d_sizes), C.c_void_p(stream or 0)))
+
     def records_scratch_bytes(self, n):
         return int(lib().wamd_records_scratch_bytes(C.c_uint32(n)))
 
