@@ -564,6 +564,10 @@ def main():
     ap.add_argument("--true-frac", type=float, default=0.5,
                     help="fraction of candidates planted at their locus (S1 = 0.5; other values are experiments)")
     ap.add_argument("--no-boundary", action="store_true", help="skip the host-buffer (PCIe-inclusive) measurements")
+    ap.add_argument("--gather", choices=("torch", "cabi"), default="torch",
+                    help="N > 1: the record gather through torch.distributed (RCCL behind it; pipelined behind the next "
+                         "bin) or through the library's own C-ABI (wamd_gather_records_dev over librccl, what the "
+                         "C++ host calls)")
     args = ap.parse_args()
 
     # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, as a CHILD process, before
@@ -649,10 +653,26 @@ def main():
     pend = [None] * n_buf
     bins_done = [0]
 
+    comm = d_gathered = None
+    if multi and args.gather == "cabi":
+        ids = [api.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        comm = api.Comm(ctx, rank, world, ids[0])
+        d_gathered = torch.zeros((n * world if rank == 0 else 1, gather.RECORD_BYTES), dtype=torch.uint8, device=device)
+
+    class _Done:
+        def result(self):
+            return None
+
     def start_gather(b):
         with torch.cuda.stream(side_g):
             side_g.wait_event(emitted[b])
-            pend[b] = gather.gather_records(d_records[b], d_count[b], dst=0, async_op=True, copy=False)
+            if comm is not None:      # waits for the counts (one read-back), then enqueues the sends / receives
+                comm.gather_records_dev(d_records[b], d_count[b], n, d_gathered, root=0, stream=side_g.cuda_stream)
+                side_g.synchronize()
+                pend[b] = _Done()
+            else:
+                pend[b] = gather.gather_records(d_records[b], d_count[b], dst=0, async_op=True, copy=False)
 
     def exchange_step():
         k = bins_done[0]
@@ -776,7 +796,7 @@ def main():
                 "distance_mode": args.distance_mode,
                 "accepted_fraction": accepted / n,
                 "parallelism": "bins sharded over %d GPU(s), no data-path collective; "
-                               "accepted records gathered to rank 0 over RCCL" % world,
+                               "accepted records gathered to rank 0 over RCCL (%s)" % (world, args.gather),
             },
             "gcups": value * M * N_COLS / 1e9,
         }
@@ -820,6 +840,8 @@ def main():
         json_out.flush()
         if out.get("parity_error"):
             raise SystemExit(1)
+    if comm is not None:
+        comm.destroy()
     if dist:
         dist.barrier()
         dist.destroy_process_group()

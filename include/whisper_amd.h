@@ -641,6 +641,38 @@ WAMD_API int wamd_finish_pairs_dev(wamd_ctx* ctx, const wamd_reads* reads, const
                                    uint8_t* d_cigars, uint32_t cigar_stride, uint8_t* d_mdz, uint32_t mdz_stride,
                                    void* d_workspace, uint64_t workspace_bytes, void* stream);
 
+/* ---- gathering the mapping records of all GPUs (the path's only exchange step) -------- *
+ * No counterpart in the reference, whose worker threads push records into one process-wide
+ * CMappingResultsCollector (mapper/results.h:55-159; mapping_core.cpp:980-997).  With the read
+ * bins of a stage sharded over the GPUs of a node (the per-stage workers of mapper.cpp:1847-1862,
+ * one group per GPU), every GPU ends a bin with a block of records in its own HBM; this call
+ * brings the blocks to the GPU of `root` - the rank that writes result groups / SAM - over
+ * RCCL point-to-point sends on xGMI, packed in rank order.
+ *   one process per GPU:      rank 0 calls wamd_comm_get_unique_id and hands the 128 bytes to the
+ *                             other ranks by whatever channel the host has; every rank calls
+ *                             wamd_comm_create, then wamd_gather_records_dev per bin;
+ *   one process, all GPUs:    wamd_comm_create_all over the node's contexts, then
+ *                             wamd_gather_records_all (every rank's calls inside one RCCL group,
+ *                             so one host thread cannot deadlock itself).
+ * d_records: this rank's records (record_bytes each: 12 for wamd_emit_lev_records_dev), *d_count of
+ * them (a device word, as the emit call leaves it); capacity: the most any rank can hold (sizes
+ * d_out on the root: n_ranks * capacity records at most are written, contiguously);
+ * counts_out: n_ranks HOST words, every rank's count, on every rank.  The call waits for the
+ * counts (one small read-back per bin), then enqueues the transfers on `stream` and returns.
+ * librccl is opened on first use; without it these calls fail with WAMD_ERR_NO_DEVICE. */
+typedef struct wamd_comm wamd_comm;
+#define WAMD_COMM_ID_BYTES 128
+WAMD_API int wamd_comm_get_unique_id(uint8_t* id /* WAMD_COMM_ID_BYTES */);
+WAMD_API int wamd_comm_create(wamd_ctx* ctx, int rank, int n_ranks, const uint8_t* id, wamd_comm** out);
+WAMD_API int wamd_comm_create_all(wamd_ctx* const* ctxs, int n, wamd_comm** out /* n handles */);
+WAMD_API int wamd_comm_destroy(wamd_comm* comm);
+WAMD_API int wamd_gather_records_dev(wamd_comm* comm, const uint8_t* d_records, const uint32_t* d_count,
+                                     uint32_t record_bytes, uint32_t capacity, int root, uint8_t* d_out,
+                                     uint32_t* counts_out, void* stream);
+WAMD_API int wamd_gather_records_all(wamd_comm* const* comms, int n, const uint8_t* const* d_records,
+                                     const uint32_t* const* d_count, uint32_t record_bytes, uint32_t capacity,
+                                     int root, uint8_t* d_out, uint32_t* counts_out, void* const* streams);
+
 /* The same emission for callers that cannot allocate device memory or bring a scratch
  * buffer: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.
  * No counterpart in the reference.  The block counts of the record scan live in a static

@@ -114,6 +114,8 @@ EXPORTS = [
     "wamd_softclip_match_dev", "wamd_serialize_mappings",
     "wamd_serialize_mappings_dev", "wamd_sam_cigar", "wamd_sam_cigar_dev", "wamd_records_scratch_bytes", "wamd_emit_lev_records_dev",
     "wamd_emit_lev_records_static_dev", "wamd_finish_workspace_bytes", "wamd_finish_pairs", "wamd_finish_pairs_dev",
+    "wamd_comm_get_unique_id", "wamd_comm_create", "wamd_comm_create_all", "wamd_comm_destroy",
+    "wamd_gather_records_dev", "wamd_gather_records_all",
 ]
 
 
@@ -481,3 +483,35 @@ def device_count():
 
 def version():
     return lib().wamd_version().decode()
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through the C-ABI: 128 bytes rank 0 hands to the other ranks."""
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    _check(lib().wamd_comm_get_unique_id(buf))
+    return bytes(buf)
+
+
+class Comm:
+    """One rank's end of the record gather (wamd_comm_create)."""
+
+    def __init__(self, ctx, rank, n_ranks, unique_id):
+        self.ctx, self.rank, self.n_ranks = ctx, rank, n_ranks
+        self.h = C.c_void_p()
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        _check(lib().wamd_comm_create(ctx.h, C.c_int(rank), C.c_int(n_ranks), buf, C.byref(self.h)))
+
+    def gather_records_dev(self, d_records, d_count, capacity, d_out, root=0, record_bytes=12, stream=None):
+        counts = np.zeros(self.n_ranks, np.uint32)
+        _check(lib().wamd_gather_records_dev(self.h, _ptr(d_records), _ptr(d_count), C.c_uint32(record_bytes),
+                                             C.c_uint32(capacity), C.c_int(root), _ptr(d_out), _ptr(counts),
+                                             C.c_void_p(stream or 0)))
+        return counts
+
+    def destroy(self):
+        if self.h:
+            lib().wamd_comm_destroy(self.h)
+            self.h = C.c_void_p()
