@@ -641,6 +641,55 @@ WAMD_API int wamd_finish_pairs_dev(wamd_ctx* ctx, const wamd_reads* reads, const
                                    uint8_t* d_cigars, uint32_t cigar_stride, uint8_t* d_mdz, uint32_t mdz_stride,
                                    void* d_workspace, uint64_t workspace_bytes, void* stream);
 
+/* ---- from verified candidates to the bytes of a result group ---------------------------- *
+ * One suffix-array candidate after its verifiers have answered, as the loop of
+ * search_in_unknown_range_dir_and_rc holds it at mapping_core_sa.cpp:241-344 (the known-range and
+ * malicious-group loops are the same): cur_match of dynamicProgramming / LevDiag, the position and
+ * strand a lev hit is recorded with (:243 sa - CUR_OFFSET, :298 ref_size - (sa - CUR_OFFSET) - 1),
+ * and whether CIndelMatching::Match ran for it (sensitive mode, :258-272 / :310-326). */
+typedef struct wamd_commit_task {
+    uint32_t lev_pos;
+    uint32_t lev_errors;           /* > max_mismatches: no lev mapping                       */
+    uint16_t max_mismatches;
+    uint16_t pattern_len;          /* rc strand: Match's pos += pattern_len - 1 (:320)        */
+    uint8_t direct;
+    uint8_t has_indel;
+    uint16_t reserved;
+} wamd_commit_task;
+
+/* candidate_mapping of every task: the lev mapping if cur_match <= max_mismatches, Match's
+ * mapping (d_indel[i], as wamd_indel_match left it; may be NULL when no task has one) with its
+ * strand fix-up, candidate_mapping_t::better of the two (results.cpp:376-387), kept only when its
+ * penalty <= max_mismatches (:338); otherwise found = 0 / type = WAMD_MAP_NONE. */
+WAMD_API int wamd_commit_candidates_dev(wamd_ctx* ctx, uint32_t n, const wamd_commit_task* d_tasks,
+                                        const wamd_mapping* d_indel, wamd_mapping* d_committed, void* stream);
+
+/* CParams fields of CMappingResultsCollector / CMappingsHeapGatherer (results.cpp:484-503, 393-405). */
+typedef struct wamd_group_params {
+    uint32_t id_bytes;             /* BITS2BYTES(id_bits_total)                               */
+    uint32_t mapping_counter_size; /* mapper/params.h:128: 4                                  */
+    uint32_t max_no_mappings;      /* heap size: the best of at most this many per read       */
+    uint32_t reserved;
+} wamd_group_params;
+
+/* The bytes CMappingResultsCollector::Push (results.cpp:546-598) leaves in a group buffer for the
+ * reads of one bin, in bin order: per read with at least one kept mapping its id (id_bytes,
+ * big-endian), the mapping count (mapping_counter_size bytes) and the serialized records
+ * (results.cpp:161-217) in the order the heap gatherer hands them over (mapping_core.cpp:976-997:
+ * pushed dir candidates first, then rc; popped from the back of the heap's array - the replay of
+ * std::push_heap / pop_heap keeps that order byte for byte).  Tasks of read r are
+ * d_read_first[r] .. d_read_first[r + 1] - 1 (n_reads + 1 entries), in the loop's order.
+ * *d_out_bytes receives the group's size; d_read_off (may be NULL) the offset of every read's
+ * block; a group beyond out_capacity raises flag bit 6.  d_workspace:
+ * wamd_result_groups_workspace_bytes(n_tasks, n_reads) bytes. */
+WAMD_API uint64_t wamd_result_groups_workspace_bytes(uint32_t n_tasks, uint32_t n_reads);
+WAMD_API int wamd_emit_result_groups_dev(wamd_ctx* ctx, uint32_t n_tasks, const wamd_commit_task* d_tasks,
+                                         const wamd_mapping* d_committed, uint32_t n_reads,
+                                         const uint32_t* d_read_first, const uint64_t* d_read_ids,
+                                         const wamd_group_params* params, uint8_t* d_out, uint32_t out_capacity,
+                                         uint32_t* d_out_bytes, uint32_t* d_read_off, void* d_workspace,
+                                         void* stream);
+
 /* ---- gathering the mapping records of all GPUs (the path's only exchange step) -------- *
  * No counterpart in the reference, whose worker threads push records into one process-wide
  * CMappingResultsCollector (mapper/results.h:55-159; mapping_core.cpp:980-997).  With the read

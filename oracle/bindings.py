@@ -79,6 +79,15 @@ FINISH_RESULT = np.dtype([("score", "<f8"), ("pos", "<u4"), ("ref_seq_pos", "<i4
 assert FINISH_TASK.itemsize == 64 and FINISH_RESULT.itemsize == 48
 
 
+COMMIT_TASK = np.dtype([("lev_pos", "<u4"), ("lev_errors", "<u4"), ("max_mismatches", "<u2"), ("pattern_len", "<u2"),
+                        ("direct", "u1"), ("has_indel", "u1"), ("reserved", "<u2")])
+assert COMMIT_TASK.itemsize == 16
+
+
+class GroupParams(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("id_bytes", "mapping_counter_size", "max_no_mappings", "reserved")]
+
+
 class FinishParams(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("flank", "enable_short_indel_refinement", "enable_boundary_clipping",
                                           "enable_paired_clipping")]
@@ -484,3 +493,31 @@ def _r_preprocess_only(self, reads, offsets, lens, encoding, max_query_len=255, 
 
 
 Reference.preprocess_only = _r_preprocess_only
+
+
+# ---- verified candidates -> result-group bytes (mapping_core_sa.cpp:241-344, mapping_core.cpp:976-997, results.cpp)
+def _commit(fn, tasks, indel):
+    t = np.ascontiguousarray(tasks, COMMIT_TASK)
+    out = np.zeros(len(t), MAPPING)
+    ind = None if indel is None else np.ascontiguousarray(indel, MAPPING)
+    rc = fn(C.c_uint32(len(t)), _p(t), _p(ind) if ind is not None else C.c_void_p(0), _p(out))
+    return rc, out
+
+
+def _groups(fn, tasks, committed, read_first, read_ids, params, capacity=None):
+    t = np.ascontiguousarray(tasks, COMMIT_TASK)
+    m = np.ascontiguousarray(committed, MAPPING)
+    rf = np.ascontiguousarray(read_first, np.uint32)
+    ids = np.ascontiguousarray(read_ids, np.uint64)
+    cap = capacity or (len(ids) * 16 + len(t) * 11 + 64)
+    out = np.zeros(cap, np.uint8)
+    nb = C.c_uint32(0)
+    rc = fn(C.c_uint32(len(t)), _p(t), _p(m), C.c_uint32(len(ids)), _p(rf), _p(ids), C.byref(params), _p(out),
+            C.c_uint32(cap), C.byref(nb))
+    return rc, out[:nb.value].copy()
+
+
+Oracle.commit = lambda self, tasks, indel=None: _commit(self.lib.wo_commit_batch, tasks, indel)
+Reference.commit = lambda self, tasks, indel=None: _commit(self.lib.ref_commit_batch, tasks, indel)
+Oracle.result_groups = lambda self, *a, **k: _groups(self.lib.wo_result_groups_batch, *a, **k)
+Reference.result_groups = lambda self, *a, **k: _groups(self.lib.ref_result_groups_batch, *a, **k)

@@ -921,3 +921,79 @@ REF_API int ref_preprocess_batch(const uint8_t* reads, const uint64_t* offsets, 
     });
     return 0;
 }
+
+
+/* ---- verified candidates -> bytes of a result group, with the reference's own objects -----------
+ * commit: candidate_mapping_t::construct<lev>, the strand fix-up of Match's mapping and
+ * candidate_mapping_t::better as in mapping_core_sa.cpp:241-344; then per read the two match_positions
+ * vectors -> CMappingsHeapGatherer::Push -> PopUnsorted -> CMappingResultsCollector::Push
+ * (mapping_core.cpp:976-997, results.cpp:409-452, 546-598).  The collector runs on unconstructed storage
+ * with one group buffer large enough never to be flushed. */
+#include "mapper/results.h"
+
+REF_API int ref_commit_batch(uint32_t n, const wamd_commit_task* tasks, const wamd_mapping* indel, wamd_mapping* out)
+{
+    for (uint32_t i = 0; i < n; ++i) {
+        const wamd_commit_task& t = tasks[i];
+        candidate_mapping_t cm;
+        const genome_t dir = t.direct ? genome_t::direct : genome_t::rev_comp;
+        if (t.lev_errors <= t.max_mismatches)
+            cm = candidate_mapping_t::construct<mapping_type_t::lev>(t.lev_pos, dir, t.lev_errors);
+        if (t.has_indel && indel && indel[i].found) {
+            candidate_mapping_t y;
+            from_pod(indel[i], y);
+            y.penalty = indel[i].penalty;
+            y.direction = dir;
+            if (!t.direct)
+                y.pos += t.pattern_len - 1;
+            cm = candidate_mapping_t::better(cm, y);
+        }
+        const bool keep = cm.type != mapping_type_t::none && cm.penalty <= t.max_mismatches;
+        if (!keep)
+            cm = candidate_mapping_t();
+        to_pod(cm, keep, out[i]);
+        out[i].penalty = keep ? (uint32_t)cm.penalty : 0;
+    }
+    return 0;
+}
+
+REF_API int ref_result_groups_batch(uint32_t n_tasks, const wamd_commit_task* tasks, const wamd_mapping* committed,
+                                    uint32_t n_reads, const uint32_t* read_first, const uint64_t* read_ids,
+                                    const wamd_group_params* prm, uint8_t* out, uint32_t out_capacity, uint32_t* out_bytes)
+{
+    alignas(CMappingResultsCollector) unsigned char raw[sizeof(CMappingResultsCollector)];
+    memset(raw, 0, sizeof(raw));
+    CMappingResultsCollector* col = reinterpret_cast<CMappingResultsCollector*>(raw);
+    uchar_t* bufs[1] = {out};
+    uint32_t sizes[1] = {0};
+    col->no_res_groups = 1;
+    col->res_group_size = 0xffffffffu;
+    col->group_bits = 56;              /* every id below 2^56 lands in group 0 */
+    col->id_bytes = prm->id_bytes;
+    col->mapping_counter_size = prm->mapping_counter_size;
+    col->buffer_reserve = 0;
+    col->buffers = bufs;
+    col->buffer_sizes = sizes;
+    col->prev_read_id = empty_read_id;
+    CMappingsHeapGatherer heap(prm->max_no_mappings);
+    for (uint32_t r = 0; r < n_reads; ++r) {
+        for (uint32_t i = read_first[r]; i < read_first[r + 1]; ++i) {
+            if (!committed[i].found)
+                continue;
+            candidate_mapping_t cm;
+            from_pod(committed[i], cm);
+            cm.penalty = committed[i].penalty;
+            cm.direction = tasks[i].direct ? genome_t::direct : genome_t::rev_comp;
+            heap.Push(cm);
+        }
+        while (!heap.Empty()) {
+            if ((uint64_t)sizes[0] + 32 > out_capacity)
+                return WAMD_ERR_CAPACITY;
+            auto x = heap.PopUnsorted();
+            col->Push(read_ids[r], x);
+        }
+    }
+    *out_bytes = sizes[0];
+    (void)n_tasks;
+    return 0;
+}

@@ -2494,3 +2494,124 @@ int wo_finish_pairs_batch(const uint8_t* genome, const uint8_t* reads, const uin
     free(query);
     return rc;
 }
+
+
+/* ---- verified candidates -> bytes of a result group -----------------------------------------------
+ * commit: mapping_core_sa.cpp:241-247 / 293-299 (lev mapping), 258-272 / 310-326 (Match's mapping and its
+ * strand fix-up), candidate_mapping_t::better (results.cpp:376-387), the penalty test of :338. */
+int wo_commit_batch(uint32_t n, const wamd_commit_task* tasks, const wamd_mapping* indel, wamd_mapping* out)
+{
+    for (uint32_t i = 0; i < n; ++i) {
+        const wamd_commit_task* t = &tasks[i];
+        wamd_mapping cm;
+        memset(&cm, 0, sizeof(cm));
+        cm.type = WAMD_MAP_NONE;
+        if (t->lev_errors <= t->max_mismatches) {
+            cm.type = WAMD_MAP_LEV;
+            cm.pos = t->lev_pos;
+            cm.no_mismatches = t->lev_errors;
+            cm.penalty = t->lev_errors;
+        }
+        if (t->has_indel && indel && indel[i].found) {
+            wamd_mapping y = indel[i];
+            if (!t->direct)
+                y.pos += t->pattern_len - 1u;
+            if (cm.type == WAMD_MAP_NONE) {
+                cm = y;
+            } else {   /* x < y ? x : y on (penalty, pos) */
+                const int x_lt_y = cm.penalty != y.penalty ? cm.penalty < y.penalty : cm.pos < y.pos;
+                if (!x_lt_y)
+                    cm = y;
+            }
+        }
+        if (cm.type != WAMD_MAP_NONE && cm.penalty > t->max_mismatches) {
+            memset(&cm, 0, sizeof(cm));
+            cm.type = WAMD_MAP_NONE;
+        }
+        cm.found = cm.type != WAMD_MAP_NONE;
+        if (!cm.found) {
+            memset(&cm, 0, sizeof(cm));
+            cm.type = WAMD_MAP_NONE;
+        }
+        out[i] = cm;
+    }
+    return 0;
+}
+
+static int rg_less(const wamd_mapping* m, uint32_t a, uint32_t b)   /* operator<, results.cpp:367-373 */
+{
+    return m[a].penalty != m[b].penalty ? m[a].penalty < m[b].penalty : m[a].pos < m[b].pos;
+}
+
+static void rg_push_heap(uint32_t* h, const wamd_mapping* m, uint32_t hole, uint32_t top, uint32_t value)
+{
+    while (hole > top) {   /* libstdc++ std::__push_heap */
+        const uint32_t parent = (hole - 1) / 2;
+        if (!rg_less(m, h[parent], value))
+            break;
+        h[hole] = h[parent];
+        hole = parent;
+    }
+    h[hole] = value;
+}
+
+/* mapping_core.cpp:976-997 with CMappingsHeapGatherer (results.cpp:409-452) and
+ * CMappingResultsCollector::Push (results.cpp:546-598), one group buffer, reads in bin order. */
+int wo_result_groups_batch(uint32_t n_tasks, const wamd_commit_task* tasks, const wamd_mapping* m, uint32_t n_reads,
+                           const uint32_t* read_first, const uint64_t* read_ids, const wamd_group_params* prm,
+                           uint8_t* out, uint32_t out_capacity, uint32_t* out_bytes)
+{
+    uint32_t* h = (uint32_t*)malloc(((size_t)n_tasks + 1) * sizeof(uint32_t));
+    uint32_t used = 0;
+    int rc = 0;
+    for (uint32_t r = 0; r < n_reads && !rc; ++r) {
+        uint32_t size = 0;
+        for (uint32_t i = read_first[r]; i < read_first[r + 1]; ++i) {
+            if (!m[i].found)
+                continue;
+            if (size < prm->max_no_mappings) {
+                ++size;
+                rg_push_heap(h, m, size - 1, 0, i);
+            } else if (rg_less(m, i, h[0])) {
+                /* std::pop_heap(first, last): value = last[-1]; last[-1] = first[0]; __adjust_heap(first, 0, len, value) */
+                const uint32_t len = size - 1, value = h[size - 1];
+                uint32_t hole = 0, child = 0;
+                h[size - 1] = h[0];
+                if (len > 0) {
+                    while (child < (len - 1) / 2) {
+                        child = 2 * (child + 1);
+                        if (rg_less(m, h[child], h[child - 1]))
+                            --child;
+                        h[hole] = h[child];
+                        hole = child;
+                    }
+                    if ((len & 1u) == 0 && child == (len - 2) / 2) {
+                        child = 2 * (child + 1);
+                        h[hole] = h[child - 1];
+                        hole = child - 1;
+                    }
+                    rg_push_heap(h, m, hole, 0, value);
+                }
+                h[size - 1] = i;
+                rg_push_heap(h, m, size - 1, 0, i);
+            }
+        }
+        if (!size)
+            continue;
+        if ((uint64_t)used + prm->id_bytes + prm->mapping_counter_size + 11ull * size > out_capacity) {
+            rc = WAMD_ERR_CAPACITY;
+            break;
+        }
+        for (uint32_t b = 0; b < prm->id_bytes; ++b)   /* StoreUInt, common/utils.cpp:431-453 */
+            out[used++] = (uint8_t)(read_ids[r] >> (8 * (prm->id_bytes - 1 - b)));
+        for (uint32_t b = 0; b < prm->mapping_counter_size; ++b) {
+            const uint32_t sh = 8 * (prm->mapping_counter_size - 1 - b);
+            out[used++] = (uint8_t)(sh < 32 ? size >> sh : 0);
+        }
+        for (uint32_t j = size; j-- > 0;)              /* PopUnsorted: v_mappings[--size] */
+            used += wo_serialize_mapping(&m[h[j]], tasks[h[j]].direct, out + used);
+    }
+    *out_bytes = used;
+    free(h);
+    return rc;
+}

@@ -166,6 +166,13 @@ int wo_softclip_batch(const uint8_t* genome, const uint8_t* reads, const uint64_
                       int encoding, const wamd_softclip_task* tasks, uint32_t n, const wamd_softclip_params* prm,
                       const wamd_scoring* sc, wamd_softclip_result* results, uint8_t* cigars, uint32_t cigar_stride);
 
+/* verified candidates -> candidate_mapping per task (mapping_core_sa.cpp:241-344) -> the bytes
+ * CMappingResultsCollector leaves in a group buffer (mapping_core.cpp:976-997, results.cpp:409-452, 546-598) */
+int wo_commit_batch(uint32_t n, const wamd_commit_task* tasks, const wamd_mapping* indel, wamd_mapping* out);
+int wo_result_groups_batch(uint32_t n_tasks, const wamd_commit_task* tasks, const wamd_mapping* committed,
+                           uint32_t n_reads, const uint32_t* read_first, const uint64_t* read_ids,
+                           const wamd_group_params* prm, uint8_t* out, uint32_t out_capacity, uint32_t* out_bytes);
+
 /* store_mapped_pair_reads' finish of the chosen pair: fill_cigar, the three clipping passes,
  * extract_cigar_and_mdz (sam.cpp:1871-1900, 1992-2007; sam_matching.cpp:667-852). */
 int wo_finish_pairs_batch(const uint8_t* genome, const uint8_t* reads, const uint64_t* offsets, const uint32_t* lens,

@@ -659,3 +659,66 @@ def same_finish_output(got, want, skip=()):
         for a, b, what in ((ge, we, "ext-CIGAR"), (gc, wc, "CIGAR"), (gm, wm, "MD:Z")):
             x, y = bytes(a[i]).split(b"\0")[0], bytes(b[i]).split(b"\0")[0]
             assert x == y, "%s of slot %d: %r != %r" % (what, i, x, y)
+
+
+def commit_workload(oracle, n_reads, seed, k=12, max_cand=14):
+    """Candidates as the SA loop holds them after verification (mapping_core_sa.cpp:241-344): per read a run of
+    direct-strand candidates, then reverse-strand ones; cur_match around the threshold, positions with ties, a
+    third of the candidates also carrying a CIndelMatching::Match result of any type."""
+    from oracle import bindings as ob
+    rng = np.random.default_rng(seed)
+    _, packed, (blob, off, lens), itasks = indel_workload(600, 150, seed + 1)
+    _, pool = oracle.indel_match(packed, blob, off, lens, 0, itasks, ob.default_indel_params(0.6))
+    pool = pool[pool["found"] == 1]
+    n_cand = rng.integers(0, max_cand + 1, n_reads)
+    n_cand[rng.random(n_reads) < 0.02] = 60            # a few reads with more candidates than a small heap holds
+    read_first = np.concatenate([[0], np.cumsum(n_cand)]).astype(np.uint32)
+    n = int(read_first[-1])
+    t = np.zeros(n, ob.COMMIT_TASK)
+    indel = np.zeros(n, ob.MAPPING)
+    t["max_mismatches"] = k
+    t["pattern_len"] = 150
+    t["lev_errors"] = rng.integers(0, k + 6, n)
+    base = rng.integers(20000, 30000, n_reads)
+    for r in range(n_reads):
+        lo, hi = read_first[r], read_first[r + 1]
+        c = hi - lo
+        t["lev_pos"][lo:hi] = base[r] + rng.integers(0, 6, c) * 7          # few distinct positions: ties on (penalty, pos)
+        n_dir = rng.integers(0, c + 1)
+        t["direct"][lo:lo + n_dir] = 1
+    has = rng.random(n) < 0.33
+    t["has_indel"] = has
+    pick = rng.integers(0, len(pool), n)
+    indel[has] = pool[pick[has]]
+    indel["found"][has & (rng.random(n) < 0.2)] = 0                        # Match ran and found nothing
+    indel["pos"][has] = t["lev_pos"][has] + rng.integers(-3, 4, int(has.sum()))
+    read_ids = (np.cumsum(rng.integers(1, 5, n_reads)) + (7 << 32)).astype(np.uint64)
+    return t, indel, read_first, read_ids
+
+
+def gpu_result_groups(ctx, tasks, indel, read_first, read_ids, id_bytes, max_no_mappings, capacity=None):
+    """commit + result-group emission through the _dev entry points on device tensors: (committed, bytes, read offsets)."""
+    import torch
+    from whisper_amd import api
+    dev = torch.device("cuda", 0)
+
+    def up(a):
+        return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev)
+
+    n, nr = len(tasks), len(read_ids)
+    d_t, d_i, d_rf, d_ids = up(tasks), up(indel), up(read_first.astype(np.uint32)), up(read_ids.astype(np.uint64))
+    d_c = torch.zeros(max(n, 1) * api.MAPPING.itemsize, dtype=torch.uint8, device=dev)
+    cap = capacity or (nr * 16 + n * 11 + 64)
+    d_out = torch.full((cap,), 0xEE, dtype=torch.uint8, device=dev)
+    d_nb = torch.zeros(1, dtype=torch.int32, device=dev)
+    d_off = torch.zeros(nr + 1, dtype=torch.int32, device=dev)
+    d_ws = torch.zeros(ctx.result_groups_workspace_bytes(n, nr), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    ctx.commit_candidates_dev(n, d_t, d_i, d_c)
+    ctx.emit_result_groups_dev(n, d_t, d_c, nr, d_rf, d_ids, api.GroupParams(id_bytes, 4, max_no_mappings, 0), d_out, cap,
+                               d_nb, d_off, d_ws)
+    ctx.synchronize()
+    flags = ctx.take_flags()
+    nb = int(d_nb.item())
+    return (d_c.cpu().numpy().view(api.MAPPING)[:n], d_out.cpu().numpy()[:min(nb, cap)], d_off.cpu().numpy()[:nr].view(np.uint32),
+            flags, d_out.cpu().numpy())

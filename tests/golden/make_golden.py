@@ -132,6 +132,23 @@ def make_finish(ref, codes, packed, ref_size):
               int(((res["left_clipping"] > 0) | (res["right_clipping"] > 0)).sum()))
 
 
+def make_groups(ref):
+    """Verified candidates -> committed mappings -> result-group bytes, by the reference's construct<lev>, better,
+    CMappingsHeapGatherer and CMappingResultsCollector::Push (oracle/ref_shim.cpp: ref_commit_batch,
+    ref_result_groups_batch)."""
+    orc = bindings.Oracle()
+    for name, seed, max_no, idb in (("groups_heap1024_id5", 8200, 1024, 5), ("groups_heap8_id4", 8201, 8, 4)):
+        t, indel, read_first, read_ids = common.commit_workload(orc, 1200, seed)
+        rc, committed = ref.commit(t, indel)
+        assert rc == 0
+        rc, data = ref.result_groups(t, committed, read_first, read_ids, bindings.GroupParams(idb, 4, max_no, 0))
+        assert rc == 0
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), kind="groups", tasks=t, indel=indel, read_first=read_first,
+                            read_ids=read_ids, id_bytes=idb, mapping_counter_size=4, max_no_mappings=max_no,
+                            committed=committed, group_bytes=data)
+        print(name, "kept", int(committed["found"].sum()), "of", len(t), "group bytes", len(data))
+
+
 def make_round2(ref, codes, packed, ref_size):
     """Shapes no round-1 fixture reached: LevDiag beyond 160 symbols (BASELINE configs[4] runs it in
     stages 1-4 at 250 bp; 300 / 600 bp for the two widest kernel instantiations), the long-indel
@@ -191,6 +208,7 @@ def make_round2(ref, codes, packed, ref_size):
                             results=res, passed=ok, cur_offset=cur_offset, max_diff=4 * k)
         print(name, "passed", int(ok.sum()), "of", n)
     make_finish(ref, codes, packed, ref_size)
+    make_groups(ref)
     seed += 1
     rd = synth.make_reads(codes, 600, 250, 7, seed)
     blob, off, lens = common.host_reads(rd, 0)
@@ -207,6 +225,9 @@ def main():
     codes = synth.make_genome(GENOME_SYMBOLS, seed=GENOME_SEED)
     packed = synth.pack_nibbles(codes).numpy()
     ref_size = codes.numel()
+    if len(sys.argv) > 1 and sys.argv[1] == "groups":
+        make_groups(ref)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "finish":
         make_finish(ref, codes, packed, ref_size)
         return

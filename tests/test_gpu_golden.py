@@ -159,3 +159,16 @@ def test_finish_pairs(ctx, name):
     # AS:i: is Double2PChar of the score (utils.h:276-286): one decimal, identical because the doubles are
     want, have = z["results"]["score"], got[0]["score"]
     assert [("%.1f" % v) for v in want] == [("%.1f" % v) for v in have]
+
+
+@pytest.mark.parametrize("name", gu.cases("groups"))
+def test_commit_and_result_groups(ctx, name):
+    """Verified candidates -> the bytes of a result group, against the reference's construct<lev> / better /
+    CMappingsHeapGatherer / CMappingResultsCollector::Push."""
+    import common
+    z = gu.load(name)
+    committed, data, offs, flags, _ = common.gpu_result_groups(ctx, z["tasks"], z["indel"], z["read_first"], z["read_ids"],
+                                                               int(z["id_bytes"]), int(z["max_no_mappings"]))
+    assert flags == 0
+    np.testing.assert_array_equal(committed, z["committed"])
+    assert bytes(data) == bytes(z["group_bytes"])

@@ -520,6 +520,32 @@ def test_finish_pairs_dev_stays_on_the_device(ctx, oracle):
     common.same_finish_output((res, d_ext.cpu().numpy(), d_cig.cpu().numpy(), d_mdz.cpu().numpy()), want)
 
 
+@pytest.mark.parametrize("seed,max_no_mappings,id_bytes", [(13, 1024, 5), (14, 8, 4), (15, 1, 8), (16, 3, 6), (17, 60, 3)])
+def test_commit_and_result_groups(ctx, oracle, seed, max_no_mappings, id_bytes):
+    """Rows K / (f)3: what rank 0 receives is what CMappingResultsCollector would hold - per-read header, lev and
+    non-lev records, in the heap gatherer's order - for 20 000 reads; plus the per-read offsets and the overflow flag."""
+    from oracle import bindings as ob
+    t, indel, read_first, read_ids = common.commit_workload(oracle, 20000, seed)
+    if id_bytes < 5:
+        read_ids = read_ids & np.uint64((1 << (8 * id_bytes)) - 1)
+    _, want_c = oracle.commit(t, indel)
+    rc, want = oracle.result_groups(t, want_c, read_first, read_ids, ob.GroupParams(id_bytes, 4, max_no_mappings, 0))
+    assert rc == 0
+    committed, data, offs, flags, _ = common.gpu_result_groups(ctx, t, indel, read_first, read_ids, id_bytes, max_no_mappings)
+    assert flags == 0
+    np.testing.assert_array_equal(committed, want_c)
+    assert len(data) == len(want) and bytes(data) == bytes(want)
+    # every read with a kept mapping starts with its id at the offset reported for it
+    kept = np.add.reduceat(np.concatenate([want_c["found"], [0]]), read_first[:-1].astype(np.int64)) * (np.diff(read_first) > 0)
+    for r in np.nonzero(kept)[0][:200]:
+        got_id = int.from_bytes(bytes(data[offs[r]:offs[r] + id_bytes]), "big")
+        assert got_id == int(read_ids[r]) & ((1 << (8 * id_bytes)) - 1)
+    # a buffer that cannot hold the group: flag, and nothing written past its end
+    _, _, _, flags, raw = common.gpu_result_groups(ctx, t, indel, read_first, read_ids, id_bytes, max_no_mappings,
+                                                   capacity=len(want) // 2)
+    assert flags & 64 and len(raw) == len(want) // 2
+
+
 def test_emit_lev_records(ctx, oracle):
     """Accepted candidates -> 12-byte mapping records in task order (wamd_emit_lev_records_dev)."""
     import torch

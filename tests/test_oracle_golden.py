@@ -166,3 +166,15 @@ def test_finish_pairs(oracle, name):
     # the descriptors themselves follow from the wire records and the chromosome table
     maps_dir = z["wire"][:, 4] >> 7
     assert ((z["tasks"]["direct"] == maps_dir)).all()
+
+
+@pytest.mark.parametrize("name", gu.cases("groups"))
+def test_commit_and_result_groups(oracle, name):
+    from oracle import bindings
+    z = gu.load(name)
+    rc, committed = oracle.commit(z["tasks"], z["indel"])
+    assert rc == 0
+    np.testing.assert_array_equal(committed, z["committed"])
+    prm = bindings.GroupParams(int(z["id_bytes"]), int(z["mapping_counter_size"]), int(z["max_no_mappings"]), 0)
+    rc, data = oracle.result_groups(z["tasks"], committed, z["read_first"], z["read_ids"], prm)
+    assert rc == 0 and bytes(data) == bytes(z["group_bytes"])

@@ -256,3 +256,21 @@ def test_finish_pairs_chain(oracle, reference, seed, m):
     assert (res["err_edit_distance"] != tasks["err_edit_distance"]).sum() > 50
     perfect_clipped = (res["method"] < 2) & ((res["left_clipping"] > 0) | (res["right_clipping"] > 0))
     assert perfect_clipped.sum() > 5            # a perfect match that a clipping pass gave an ext-CIGAR keeps "<len>M"
+
+
+@pytest.mark.parametrize("seed,max_no_mappings,id_bytes", [(3, 1024, 5), (4, 8, 4), (5, 1, 8), (6, 3, 6)])
+def test_commit_and_result_groups(oracle, reference, seed, max_no_mappings, id_bytes):
+    """Verified candidates -> candidate_mapping (construct<lev>, better) -> the heap gatherer's order -> the bytes
+    CMappingResultsCollector::Push leaves in a group buffer; the reference's own objects against the restatement."""
+    from oracle import bindings as ob
+    t, indel, read_first, read_ids = common.commit_workload(oracle, 3000, seed)
+    rc1, a = oracle.commit(t, indel)
+    rc2, b = reference.commit(t, indel)
+    assert rc1 == 0 and rc2 == 0
+    np.testing.assert_array_equal(a, b)
+    assert (a["type"] == 0).sum() > 3000 and ((a["type"] > 0) & (a["type"] < 8)).sum() > 1000 and (a["found"] == 0).sum() > 1000
+    prm = ob.GroupParams(id_bytes, 4, max_no_mappings, 0)
+    rc1, ga = oracle.result_groups(t, a, read_first, read_ids, prm)
+    rc2, gb = reference.result_groups(t, a, read_first, read_ids, prm)
+    assert rc1 == 0 and rc2 == 0 and len(ga) > 20000
+    assert bytes(ga) == bytes(gb)

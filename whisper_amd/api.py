@@ -87,6 +87,15 @@ FINISH_RESULT = np.dtype([("score", "<f8"), ("pos", "<u4"), ("ref_seq_pos", "<i4
 assert FINISH_TASK.itemsize == 64 and FINISH_RESULT.itemsize == 48
 
 
+COMMIT_TASK = np.dtype([("lev_pos", "<u4"), ("lev_errors", "<u4"), ("max_mismatches", "<u2"), ("pattern_len", "<u2"),
+                        ("direct", "u1"), ("has_indel", "u1"), ("reserved", "<u2")])
+assert COMMIT_TASK.itemsize == 16
+
+
+class GroupParams(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("id_bytes", "mapping_counter_size", "max_no_mappings", "reserved")]
+
+
 class FinishParams(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("flank", "enable_short_indel_refinement", "enable_boundary_clipping",
                                           "enable_paired_clipping")]
@@ -115,7 +124,8 @@ EXPORTS = [
     "wamd_serialize_mappings_dev", "wamd_sam_cigar", "wamd_sam_cigar_dev", "wamd_records_scratch_bytes", "wamd_emit_lev_records_dev",
     "wamd_emit_lev_records_static_dev", "wamd_finish_workspace_bytes", "wamd_finish_pairs", "wamd_finish_pairs_dev",
     "wamd_comm_get_unique_id", "wamd_comm_create", "wamd_comm_create_all", "wamd_comm_destroy",
-    "wamd_gather_records_dev", "wamd_gather_records_all",
+    "wamd_gather_records_dev", "wamd_gather_records_all", "wamd_commit_candidates_dev",
+    "wamd_result_groups_workspace_bytes", "wamd_emit_result_groups_dev",
 ]
 
 
@@ -159,6 +169,7 @@ def lib():
         L.wamd_reads_count.restype = C.c_uint32
         L.wamd_records_scratch_bytes.restype = C.c_uint64
         L.wamd_finish_workspace_bytes.restype = C.c_uint64
+        L.wamd_result_groups_workspace_bytes.restype = C.c_uint64
         _lib = L
     return _lib
 
@@ -372,6 +383,21 @@ class Context:
         _check(lib().wamd_sam_cigar(self.h, C.c_uint32(n), _ptr(ext), C.c_uint32(es), _ptr(cig), C.c_uint32(os_),
                                     _ptr(mdz), C.c_uint32(os_), _ptr(cbin), C.c_uint32(es + 4), _ptr(lens)))
         return cig, mdz, cbin, lens
+
+    def commit_candidates_dev(self, n, d_tasks, d_indel, d_committed, stream=None):
+        _check(lib().wamd_commit_candidates_dev(self.h, C.c_uint32(n), _ptr(d_tasks), _ptr(d_indel), _ptr(d_committed),
+                                                C.c_void_p(stream or 0)))
+
+    def result_groups_workspace_bytes(self, n_tasks, n_reads):
+        return int(lib().wamd_result_groups_workspace_bytes(C.c_uint32(n_tasks), C.c_uint32(n_reads)))
+
+    def emit_result_groups_dev(self, n_tasks, d_tasks, d_committed, n_reads, d_read_first, d_read_ids, params, d_out,
+                               out_capacity, d_out_bytes, d_read_off, d_ws, stream=None):
+        _check(lib().wamd_emit_result_groups_dev(self.h, C.c_uint32(n_tasks), _ptr(d_tasks), _ptr(d_committed),
+                                                 C.c_uint32(n_reads), _ptr(d_read_first), _ptr(d_read_ids),
+                                                 C.byref(params), _ptr(d_out), C.c_uint32(out_capacity),
+                                                 _ptr(d_out_bytes), _ptr(d_read_off), _ptr(d_ws),
+                                                 C.c_void_p(stream or 0)))
 
     def finish_pairs(self, reads, tasks, params=None, ext_stride=512):
         """store_mapped_pair_reads' finish of the chosen pairs (sam.cpp:1871-1900, 1992-2007): returns results,

@@ -990,6 +990,40 @@ int wamd_emit_lev_records_dev(wamd_ctx* ctx, uint32_t n, const wamd_dist_task* d
                                    d_scratch, pick(ctx, stream));
 }
 
+int wamd_commit_candidates_dev(wamd_ctx* ctx, uint32_t n, const wamd_commit_task* d_tasks, const wamd_mapping* d_indel,
+                               wamd_mapping* d_committed, void* stream)
+{
+    if (n == 0)
+        return WAMD_OK;
+    if (!ctx || !d_tasks || !d_committed)
+        return WAMD_ERR_INVALID_ARG;
+    return launch_commit(ctx, n, d_tasks, d_indel, d_committed, pick(ctx, stream));
+}
+
+uint64_t wamd_result_groups_workspace_bytes(uint32_t n_tasks, uint32_t n_reads)
+{
+    return result_groups_workspace_bytes(n_tasks, n_reads);
+}
+
+int wamd_emit_result_groups_dev(wamd_ctx* ctx, uint32_t n_tasks, const wamd_commit_task* d_tasks,
+                                const wamd_mapping* d_committed, uint32_t n_reads, const uint32_t* d_read_first,
+                                const uint64_t* d_read_ids, const wamd_group_params* params, uint8_t* d_out,
+                                uint32_t out_capacity, uint32_t* d_out_bytes, uint32_t* d_read_off, void* d_workspace,
+                                void* stream)
+{
+    if (!ctx || !d_out_bytes || !params)
+        return WAMD_ERR_INVALID_ARG;
+    if (n_reads == 0) {
+        WAMD_HIP(hipMemsetAsync(d_out_bytes, 0, sizeof(uint32_t), pick(ctx, stream)));
+        return WAMD_OK;
+    }
+    if (!d_tasks || !d_committed || !d_read_first || !d_read_ids || !d_out || !d_workspace ||
+        ((uintptr_t)d_workspace & 3u))
+        return WAMD_ERR_INVALID_ARG;
+    return launch_result_groups(ctx, n_tasks, d_tasks, d_committed, n_reads, d_read_first, d_read_ids, params, d_out,
+                                out_capacity, d_out_bytes, d_read_off, d_workspace, pick(ctx, stream));
+}
+
 uint64_t wamd_finish_workspace_bytes(const wamd_reads* reads, uint32_t n_pairs)
 {
     return reads ? finish_workspace_bytes(reads, n_pairs) : 0;

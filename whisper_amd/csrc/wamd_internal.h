@@ -178,6 +178,14 @@ int launch_finish_pairs(wamd_ctx* ctx, const wamd_reads* r, const wamd_finish_ta
                         uint8_t* d_cigars, uint32_t cigar_stride, uint8_t* d_mdz, uint32_t mdz_stride, void* d_ws,
                         uint64_t ws_bytes, hipStream_t s);
 
+uint64_t result_groups_workspace_bytes(uint32_t n_tasks, uint32_t n_reads);
+int launch_commit(wamd_ctx* ctx, uint32_t n, const wamd_commit_task* d_tasks, const wamd_mapping* d_indel,
+                  wamd_mapping* d_out, hipStream_t s);
+int launch_result_groups(wamd_ctx* ctx, uint32_t n_tasks, const wamd_commit_task* d_tasks, const wamd_mapping* d_committed,
+                         uint32_t n_reads, const uint32_t* d_read_first, const uint64_t* d_read_ids,
+                         const wamd_group_params* prm, uint8_t* d_out, uint32_t out_capacity, uint32_t* d_out_bytes,
+                         uint32_t* d_read_off, void* d_ws, hipStream_t s);
+
 int records_static_init(int device);   // with `device` current; once per device
 int launch_emit_lev_records_static(wamd_ctx* ctx, uint32_t n, const wamd_dist_task* d_tasks,
                                    const wamd_dist_result* d_results, const uint32_t* d_record_pos,
