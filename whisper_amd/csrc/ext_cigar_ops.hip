@@ -233,15 +233,9 @@ __global__ __launch_bounds__(256) void indel_ext_cigar_kernel(const uint8_t* __r
 
 __device__ __forceinline__ bool is_alpha(uint32_t c) { return ((c | 32u) - 'a') < 26u; }
 
-__global__ __launch_bounds__(256) void clip_boundary_kernel(uint32_t n, wamd_clip_record* __restrict__ records,
-                                                            uint8_t* __restrict__ cigars, uint32_t cigar_stride,
-                                                            wamd_scoring sc)
+// One record: the body of clipBoundaryPositions.  `ec` may point to global memory or to an LDS copy of the slot.
+__device__ void clip_boundary_one(wamd_clip_record& d, uint8_t* ec, uint32_t cigar_stride, const wamd_scoring& sc)
 {
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= n)
-        return;
-    wamd_clip_record d = records[gid];
-    uint8_t* ec = cigars + (uint64_t)gid * cigar_stride;
     d.no_clippings = 0;
 
     auto length = [&]() {
@@ -252,7 +246,6 @@ __global__ __launch_bounds__(256) void clip_boundary_kernel(uint32_t n, wamd_cli
     };
     if (d.err_edit_distance == 0) {
         d.cigar_len = length();
-        records[gid] = d;
         return;
     }
     int mini_pos = -1, maxi_pos = -1;
@@ -296,7 +289,6 @@ __global__ __launch_bounds__(256) void clip_boundary_kernel(uint32_t n, wamd_cli
     }
     if (mini_pos + 20 > maxi_pos) {
         d.cigar_len = length();
-        records[gid] = d;
         return;
     }
     int no_clippings = 0;
@@ -376,6 +368,17 @@ __global__ __launch_bounds__(256) void clip_boundary_kernel(uint32_t n, wamd_cli
     d.score = (0.0 > maxi ? 0.0 : maxi) - (0.0 < mini ? 0.0 : mini) + no_clippings * sc.clipping;
     d.no_clippings = (uint32_t)no_clippings;
     d.cigar_len = length();
+}
+
+__global__ __launch_bounds__(256) void clip_boundary_kernel(uint32_t n, wamd_clip_record* __restrict__ records,
+                                                            uint8_t* __restrict__ cigars, uint32_t cigar_stride,
+                                                            wamd_scoring sc)
+{
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n)
+        return;
+    wamd_clip_record d = records[gid];
+    clip_boundary_one(d, cigars + (uint64_t)gid * cigar_stride, cigar_stride, sc);
     records[gid] = d;
 }
 
@@ -391,17 +394,9 @@ __device__ __forceinline__ uint32_t bounded_len(const uint8_t* ec, uint32_t stri
     return l;
 }
 
-__global__ __launch_bounds__(256) void clip_illegal_kernel(uint32_t n, const wamd_clip_illegal_task* __restrict__ tasks,
-                                                           wamd_clip_record* __restrict__ records,
-                                                           uint8_t* __restrict__ cigars, uint32_t stride,
-                                                           wamd_scoring sc, uint32_t* __restrict__ flags)
+__device__ void clip_illegal_one(wamd_clip_record& d, const wamd_clip_illegal_task& t, uint8_t* ec, uint32_t stride,
+                                 const wamd_scoring& sc, uint32_t* flags)
 {
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= n)
-        return;
-    wamd_clip_record d = records[gid];
-    const wamd_clip_illegal_task t = tasks[gid];
-    uint8_t* ec = cigars + (uint64_t)gid * stride;
     const int32_t ref_size = t.ref_size;
     const int32_t mapping_last = d.ref_seq_pos + (int32_t)d.ref_length - 1;   // 596
     const int read_length = t.read_length;
@@ -414,7 +409,6 @@ __global__ __launch_bounds__(256) void clip_illegal_kernel(uint32_t n, const wam
         to_right = mapping_last - ref_size;
     if (!to_left && !to_right) {
         d.cigar_len = bounded_len(ec, stride);
-        records[gid] = d;
         return;
     }
     if ((uint32_t)read_length + 1 > stride) {
@@ -512,6 +506,18 @@ __global__ __launch_bounds__(256) void clip_illegal_kernel(uint32_t n, const wam
         raise_flag(flags, FLAG_ARG);
     d.score = score;
     d.cigar_len = out;
+}
+
+__global__ __launch_bounds__(256) void clip_illegal_kernel(uint32_t n, const wamd_clip_illegal_task* __restrict__ tasks,
+                                                           wamd_clip_record* __restrict__ records,
+                                                           uint8_t* __restrict__ cigars, uint32_t stride,
+                                                           wamd_scoring sc, uint32_t* __restrict__ flags)
+{
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n)
+        return;
+    wamd_clip_record d = records[gid];
+    clip_illegal_one(d, tasks[gid], cigars + (uint64_t)gid * stride, stride, sc, flags);
     records[gid] = d;
 }
 
@@ -614,17 +620,10 @@ __device__ bool clip_right(wamd_clip_record& d, uint8_t* ec, uint32_t stride, in
     return true;
 }
 
-__global__ __launch_bounds__(256) void clip_pairs_kernel(uint32_t n_pairs, const wamd_clip_pair_task* __restrict__ tasks,
-                                                         wamd_clip_record* __restrict__ records,
-                                                         uint8_t* __restrict__ cigars, uint32_t stride,
-                                                         uint32_t* __restrict__ flags)
+__device__ void clip_pair_one(const wamd_clip_pair_task& t, wamd_clip_record (&rec)[2], uint8_t* ec0, uint8_t* ec1,
+                              uint32_t stride, uint32_t* flags)
 {
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= n_pairs)
-        return;
-    const wamd_clip_pair_task t = tasks[gid];
-    wamd_clip_record rec[2] = {records[2 * (uint64_t)gid], records[2 * (uint64_t)gid + 1]};
-    uint8_t* ec[2] = {cigars + 2 * (uint64_t)gid * stride, cigars + (2 * (uint64_t)gid + 1) * stride};
+    uint8_t* ec[2] = {ec0, ec1};
     rec[0].no_clippings = rec[1].no_clippings = 0;
     bool touched = false;
     if (t.ref_seq_id[0] == t.ref_seq_id[1] && !rec[0].left_clipping && !rec[0].right_clipping &&
@@ -673,6 +672,19 @@ __global__ __launch_bounds__(256) void clip_pairs_kernel(uint32_t n_pairs, const
     (void)touched;
     rec[0].cigar_len = bounded_len(ec[0], stride);
     rec[1].cigar_len = bounded_len(ec[1], stride);
+}
+
+__global__ __launch_bounds__(256) void clip_pairs_kernel(uint32_t n_pairs, const wamd_clip_pair_task* __restrict__ tasks,
+                                                         wamd_clip_record* __restrict__ records,
+                                                         uint8_t* __restrict__ cigars, uint32_t stride,
+                                                         uint32_t* __restrict__ flags)
+{
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n_pairs)
+        return;
+    wamd_clip_record rec[2] = {records[2 * (uint64_t)gid], records[2 * (uint64_t)gid + 1]};
+    clip_pair_one(tasks[gid], rec, cigars + 2 * (uint64_t)gid * stride, cigars + (2 * (uint64_t)gid + 1) * stride, stride,
+                  flags);
     records[2 * (uint64_t)gid] = rec[0];
     records[2 * (uint64_t)gid + 1] = rec[1];
 }
@@ -943,21 +955,11 @@ __device__ __forceinline__ uint32_t put_decimal(uint8_t* dst, uint32_t v)
     return n;
 }
 
-__global__ __launch_bounds__(256) void sam_cigar_kernel(uint32_t n, const uint8_t* __restrict__ ext_cigars,
-                                                        uint32_t ext_stride, uint8_t* __restrict__ cigars,
-                                                        uint32_t cigar_stride, uint8_t* __restrict__ mdz,
-                                                        uint32_t mdz_stride, uint32_t* __restrict__ cigar_bin,
-                                                        uint32_t bin_stride, wamd_sam_cigar_len* __restrict__ lens,
-                                                        uint32_t* __restrict__ flags)
+__device__ wamd_sam_cigar_len sam_cigar_one(const uint8_t* ext, uint32_t ext_stride, uint8_t* cg, uint32_t cigar_stride,
+                                            uint8_t* md, uint32_t mdz_stride, uint32_t* cb, uint32_t bin_stride,
+                                            uint32_t* flags)
 {
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= n)
-        return;
     enum { Match, Mismatch, Insertion, Deletion, Begin, End, Clipping };
-    const uint8_t* ext = ext_cigars + (uint64_t)gid * ext_stride;
-    uint8_t* cg = cigars + (uint64_t)gid * cigar_stride;
-    uint8_t* md = mdz + (uint64_t)gid * mdz_stride;
-    uint32_t* cb = cigar_bin ? cigar_bin + (uint64_t)gid * bin_stride : nullptr;
     uint32_t e = 0, c = 0, d = 0, b = 0;       // cursors: ext-CIGAR, CIGAR text, MD:Z, BAM operations
     uint32_t counters[7] = {0, 0, 0, 0, 0, 0, 0};
     uint32_t run_m = 0, run_md = 0;            // cnt_match_mismatch, cnt_match_ignoring_insert
@@ -1038,7 +1040,117 @@ __global__ __launch_bounds__(256) void sam_cigar_kernel(uint32_t n, const uint8_
     l.mdz_len = d;
     l.cigar_bin_len = b;
     l.reserved = overflow ? 1u : 0u;
-    lens[gid] = l;
+    return l;
+}
+
+__global__ __launch_bounds__(256) void sam_cigar_kernel(uint32_t n, const uint8_t* __restrict__ ext_cigars,
+                                                        uint32_t ext_stride, uint8_t* __restrict__ cigars,
+                                                        uint32_t cigar_stride, uint8_t* __restrict__ mdz,
+                                                        uint32_t mdz_stride, uint32_t* __restrict__ cigar_bin,
+                                                        uint32_t bin_stride, wamd_sam_cigar_len* __restrict__ lens,
+                                                        uint32_t* __restrict__ flags)
+{
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n)
+        return;
+    lens[gid] = sam_cigar_one(ext_cigars + (uint64_t)gid * ext_stride, ext_stride, cigars + (uint64_t)gid * cigar_stride,
+                              cigar_stride, mdz + (uint64_t)gid * mdz_stride, mdz_stride,
+                              cigar_bin ? cigar_bin + (uint64_t)gid * bin_stride : nullptr, bin_stride, flags);
+}
+
+// ---- rows L, B, L, X behind one another on an LDS copy of the ext-CIGARs --------------------------
+// clipIllegalPositions, clipBoundaryPositions, clipOverlappingPairs and extract_cigar_and_mdz
+// (sam.cpp:1889-1900, 2002-2007) for 64 consecutive slots (32 pairs) per wave.  The wave copies its
+// slots from global memory into LDS with coalesced loads (the slots are contiguous), every lane then runs
+// the four routines on its own copy - the per-record state machines above, unchanged, so the bytes they
+// produce are the same - and the wave writes the slots back once.  A lane's copy starts at an odd dword
+// stride, so lanes reading the same offset of their strings hit different banks.  Records travel
+// between the two lanes of a pair by shuffles.
+__global__ __launch_bounds__(64) void post_passes_kernel(uint32_t n, const wamd_clip_illegal_task* __restrict__ it,
+                                                         const wamd_clip_pair_task* __restrict__ pt,
+                                                         wamd_clip_record* __restrict__ records, uint8_t* __restrict__ ext,
+                                                         uint32_t ext_stride, uint32_t lds_dw, wamd_scoring sc,
+                                                         int do_boundary, int do_pairs, uint8_t* __restrict__ cigars,
+                                                         uint32_t cigar_stride, uint8_t* __restrict__ mdz,
+                                                         uint32_t mdz_stride, wamd_sam_cigar_len* __restrict__ lens,
+                                                         uint32_t* __restrict__ flags)
+{
+    extern __shared__ uint32_t post_lds[];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t base = blockIdx.x * 64;
+    const uint32_t here = n - base < 64u ? n - base : 64u;   // slots of this wave (n is even: pairs stay together)
+    const uint32_t dw = ext_stride / 4;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(ext + (uint64_t)base * ext_stride);
+    for (uint32_t i = lane; i < here * dw; i += 64)
+        post_lds[(i / dw) * lds_dw + i % dw] = src[i];
+    __syncthreads();
+    const uint32_t slot = base + lane;
+    const bool live = lane < here;
+    uint8_t* ec = reinterpret_cast<uint8_t*>(post_lds + lane * lds_dw);
+    wamd_clip_record d{};
+    if (live) {
+        d = records[slot];
+        clip_illegal_one(d, it[slot], ec, ext_stride, sc, flags);
+        if (do_boundary)
+            clip_boundary_one(d, ec, ext_stride, sc);
+    }
+    __syncthreads();   // every lane's string is as its own passes left it before a partner touches it
+    if (do_pairs) {
+        // the even lane of a pair takes its partner's record, clips both strings, hands the record back
+        uint32_t w[8], v[8];
+        memcpy(w, &d, 32);
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            v[q] = (uint32_t)__shfl_down((int)w[q], 1);
+        wamd_clip_record rec[2];
+        rec[0] = d;
+        memcpy(&rec[1], v, 32);
+        if (live && !(lane & 1u) && lane + 1 < here)
+            clip_pair_one(pt[slot >> 1], rec, ec, ec + 4 * lds_dw, ext_stride, flags);
+        memcpy(w, &rec[1], 32);
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            v[q] = (uint32_t)__shfl_up((int)w[q], 1);
+        if (lane & 1u)
+            memcpy(&d, v, 32);
+        else
+            d = rec[0];
+        __syncthreads();
+    }
+    if (live) {
+        lens[slot] = sam_cigar_one(ec, ext_stride, cigars + (uint64_t)slot * cigar_stride, cigar_stride,
+                                   mdz + (uint64_t)slot * mdz_stride, mdz_stride, nullptr, 0, flags);
+        records[slot] = d;
+    }
+    __syncthreads();
+    uint32_t* dst = reinterpret_cast<uint32_t*>(ext + (uint64_t)base * ext_stride);
+    for (uint32_t i = lane; i < here * dw; i += 64)
+        dst[i] = post_lds[(i / dw) * lds_dw + i % dw];
+}
+
+// the fused form when the slots fit LDS (64 KB per wave: ext_stride up to 1000), else the four kernels in turn
+int launch_post_passes(wamd_ctx* ctx, uint32_t n, const wamd_clip_illegal_task* d_it, const wamd_clip_pair_task* d_pt,
+                       wamd_clip_record* d_rec, uint8_t* d_ext, uint32_t ext_stride, int do_boundary, int do_pairs,
+                       uint8_t* d_cigars, uint32_t cigar_stride, uint8_t* d_mdz, uint32_t mdz_stride,
+                       wamd_sam_cigar_len* d_lens, hipStream_t s)
+{
+    WAMD_HIP(hipSetDevice(ctx->device));
+    if ((ext_stride & 3u) == 0 && ext_stride <= 1000 && ((uintptr_t)d_ext & 3u) == 0 && (n & 1u) == 0) {
+        const uint32_t lds_dw = (ext_stride / 4) | 1u;   // odd: conflict-free per-lane strings
+        hipLaunchKernelGGL(post_passes_kernel, dim3((n + 63) / 64), dim3(64), (size_t)64 * lds_dw * 4, s, n, d_it, d_pt,
+                           d_rec, d_ext, ext_stride, lds_dw, ctx->scoring, do_boundary, do_pairs, d_cigars, cigar_stride,
+                           d_mdz, mdz_stride, d_lens, ctx->d_flags);
+        WAMD_HIP(hipGetLastError());
+        return WAMD_OK;
+    }
+    int rc = launch_clip_illegal(ctx, n, d_it, d_rec, d_ext, ext_stride, s);
+    if (!rc && do_boundary)
+        rc = launch_clip_boundary(ctx, n, d_rec, d_ext, ext_stride, s);
+    if (!rc && do_pairs)
+        rc = launch_clip_pairs(ctx, n / 2, d_pt, d_rec, d_ext, ext_stride, s);
+    if (!rc)
+        rc = launch_sam_cigar(ctx, n, d_ext, ext_stride, d_cigars, cigar_stride, d_mdz, mdz_stride, nullptr, 0, d_lens, s);
+    return rc;
 }
 
 int launch_sam_cigar(wamd_ctx* ctx, uint32_t n, const uint8_t* d_ext, uint32_t ext_stride, uint8_t* d_cigars,

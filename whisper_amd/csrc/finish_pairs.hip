@@ -299,13 +299,8 @@ int launch_finish_pairs(wamd_ctx* ctx, const wamd_reads* r, const wamd_finish_ta
     hipLaunchKernelGGL(finish_merge_kernel, dim3(blocks), dim3(256), 0, s, rv, d_tasks, n, prm->flank,
                        ctx->scoring.match, w.ar, w.cr, w.rec, w.it, w.pt, d_results, d_ext, ext_stride);
     WAMD_HIP(hipGetLastError());
-    rc = launch_clip_illegal(ctx, n, w.it, w.rec, d_ext, ext_stride, s);
-    if (!rc && prm->enable_boundary_clipping)
-        rc = launch_clip_boundary(ctx, n, w.rec, d_ext, ext_stride, s);
-    if (!rc && prm->enable_paired_clipping)
-        rc = launch_clip_pairs(ctx, n_pairs, w.pt, w.rec, d_ext, ext_stride, s);
-    if (!rc)
-        rc = launch_sam_cigar(ctx, n, d_ext, ext_stride, d_cigars, cigar_stride, d_mdz, mdz_stride, nullptr, 0, w.lens, s);
+    rc = launch_post_passes(ctx, n, w.it, w.pt, w.rec, d_ext, ext_stride, prm->enable_boundary_clipping != 0,
+                            prm->enable_paired_clipping != 0, d_cigars, cigar_stride, d_mdz, mdz_stride, w.lens, s);
     if (rc)
         return rc;
     hipLaunchKernelGGL(finish_final_kernel, dim3(blocks), dim3(256), 0, s, rv, d_tasks, n, w.rec, w.lens, d_results,
