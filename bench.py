@@ -259,7 +259,9 @@ def run_extras(ctx, device, genome_symbols, stream, n_small):
     acc = float((d_r.cpu().numpy().view(np.uint32) <= 5).mean())
     out["S2_levdiag"] = {"shape": "CEditDist::LevDiag m=150 k=5 anchor [%d,%d)" % (fl, fr), "tasks": n,
                          "kernel_ms": ms, "candidates_per_s": n / ms * 1e3, "accepted_fraction": acc,
-                         "roofline": roof_hbm(n, q(150) + q(150 + 2 * 5 + 1) + 16 + 4, ms, "levdiag_kernel<22,256>")}
+                         # per column of either side's band: 6 ops of match vector, 9 of recurrence, 2 of score
+                         "roofline": roof_valu(n, ((fl + 5) + (150 - fr + 5)) * 17, ms, "levdiag_band_kernel<5,128>"),
+                         "hbm_bytes_per_candidate": 80 + q(150 + 2 * 5 + 1) + 16 + 4}
     reads.free()
     del d_t, d_r
 

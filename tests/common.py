@@ -57,6 +57,40 @@ def levdiag_workload(m, k, fl, fr, n, seed, cur_offset=0, gen=None):
     return codes, packed, (blob, off, lens), tasks
 
 
+def levdiag_odd_workload(n, seed):
+    """LevDiag tasks the stage segments never produce (see test_levdiag_odd_shapes)."""
+    from whisper_amd import api
+    import torch
+    codes, packed = genome()
+    g = torch.Generator().manual_seed(seed)
+    n_pos = torch.nonzero(codes[20000:900000] > 3).reshape(-1) + 20000
+    assert n_pos.numel() > 100
+    reads_codes, tasks = [], []
+    for i in range(n):
+        m = int(torch.randint(24, 161, (1,), generator=g))
+        k = i % 7
+        fl = int(torch.randint(0, m + 1, (1,), generator=g)) if i % 5 else 0
+        fr = min(m, fl + int(torch.randint(0, 31, (1,), generator=g)))
+        if i % 11 == 0:
+            fr = m
+        if i % 4 == 0:    # on an N run
+            p = int(n_pos[int(torch.randint(0, n_pos.numel(), (1,), generator=g))]) - int(torch.randint(0, m, (1,), generator=g))
+        else:
+            p = int(torch.randint(20000, 900000, (1,), generator=g))
+        r = codes[p:p + m].clone()
+        for _ in range(int(torch.randint(0, k + 2, (1,), generator=g))):
+            z = int(torch.randint(0, m, (1,), generator=g))
+            if not (fl <= z < fr) and int(r[z]) < 4:
+                r[z] = (int(r[z]) + 1) & 3
+        if i % 8 < 4:
+            r[r > 3] = 4
+        reads_codes.append(r)
+        tasks.append((i, p, fl, fr, k, 1))
+    blob, off, lens = mixed_reads(reads_codes, 0)
+    tasks = np.array(tasks, api.LEVDIAG_TASK)
+    return codes, packed, (blob, off, lens), tasks
+
+
 stage_segments = synth.stage_segments
 
 

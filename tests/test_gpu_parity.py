@@ -164,6 +164,24 @@ def test_levdiag_mixed_lengths(ctx, oracle):
     np.testing.assert_array_equal(got, want)
 
 
+def test_levdiag_odd_shapes(ctx, oracle):
+    """What the stage segments never produce, task by task in one batch: anchors shorter than k (down to empty: the
+    banded kernel's phantom-row build), no prefix / no suffix, sides of k rows or fewer, k = 0, loci on the genome's
+    N runs with reads that carry N as 4 (never equal to the genome's 5) or as 5 (equal: the lanes the banded kernel
+    hands to the run-extension kernel)."""
+    codes, packed, (blob, off, lens), tasks = common.levdiag_odd_workload(6000, 4242)
+    rc, want = oracle.levdiag(packed, codes.numel(), 0, blob, off, lens, tasks)
+    assert rc == 0
+    reads = ctx.upload_reads(blob, off, lens, 0, orientations=1)
+    got = ctx.lev_diag(reads, tasks)
+    reads.free()
+    ok = want <= tasks["max_mismatches"]
+    assert ok.sum() > 1500 and (~ok).sum() > 500
+    on_n = np.arange(len(tasks)) % 4 == 0
+    assert (ok & on_n).sum() > 100
+    np.testing.assert_array_equal(got, want)
+
+
 @pytest.mark.parametrize("k", [2, 4, 6])
 def test_levdiag_low_complexity(oracle, k):
     """Tandem repeats: many equally good alignments, anchors that extend far, runs that end

@@ -41,6 +41,15 @@ def test_levdiag(oracle, reference, k):
         np.testing.assert_array_equal(a, b)
 
 
+def test_levdiag_odd_shapes(oracle, reference):
+    """Short and empty anchors, missing sides, k = 0, N runs facing reads with equal and unequal N codes."""
+    codes, packed, (blob, off, lens), tasks = common.levdiag_odd_workload(6000, 4242)
+    _, a = oracle.levdiag(packed, codes.numel(), 0, blob, off, lens, tasks)
+    _, b = reference.levdiag(packed, codes.numel(), 0, blob, off, lens, tasks)
+    assert (a <= tasks["max_mismatches"]).sum() > 1500
+    np.testing.assert_array_equal(a, b)
+
+
 @pytest.mark.parametrize("m,ks", [(250, (1, 2, 3, 4)), (300, (4, 6)), (600, (3, 6)), (1000, (6,))])
 def test_levdiag_long_reads(oracle, reference, m, ks):
     """The shapes of the GPU test of the same name (reads beyond 160 symbols; 250 bp = BASELINE configs[4])."""
