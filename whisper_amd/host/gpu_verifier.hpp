@@ -25,6 +25,10 @@ namespace whisper_amd {
 using uchar_t = unsigned char;
 using ref_pos_t = uint32_t;
 enum class genome_t { direct, rev_comp };   // common/defs.h:79
+// Orientation arguments are templates: inside the reference the call sites pass the reference's own
+// ::genome_t (same enumerators), stand-alone callers pass whisper_amd::genome_t.
+template <class G>
+inline bool is_rev_comp(G orientation) { return orientation == G::rev_comp; }
 
 inline void check(int rc, const char* what)
 {
@@ -76,13 +80,14 @@ public:
     // are.  genome_t::rev_comp makes dynamicProgramming() verify the reverse complement of `seq`
     // (what LevMyers::preprocess does with it, LevMyers64.cpp:184-194); no mapping-stage call site
     // asks for that.
-    bool preprocess(const uchar_t* seq, uint32_t seq_len, genome_t orientation)
+    template <class G>
+    bool preprocess(const uchar_t* seq, uint32_t seq_len, G orientation)
     {
         offsets_.push_back(blob_.size());
         lens_.push_back(seq_len);
         blob_.insert(blob_.end(), seq, seq + (seq_len + 1) / 2);
         cur_read_ = (uint32_t)lens_.size() - 1;
-        cur_flags_ = orientation == genome_t::rev_comp ? WAMD_TASK_FLAG_REV_COMP : 0;
+        cur_flags_ = is_rev_comp(orientation) ? WAMD_TASK_FLAG_REV_COMP : 0;
         need_rc_ = need_rc_ || cur_flags_ != 0;
         return true;
     }
@@ -116,6 +121,13 @@ public:
         lev_tasks_.push_back(t);
         return lev_tasks_.size() - 1;
     }
+    // the reference's own argument list (edit_dist.h:50-51): pattern / len name the read of the last preprocess()
+    size_t LevDiag(const uchar_t* /*pattern_ptr*/, uint32_t /*pattern_len*/, uint32_t position_in_text, uint32_t fixed_left,
+                   uint32_t fixed_right, uint32_t max_mismatches, bool dir_gen_flag)
+    {
+        return LevDiag(position_in_text, fixed_left, fixed_right, max_mismatches, dir_gen_flag);
+    }
+    size_t pendingReads() const { return lens_.size(); }
 
     // Verifies everything enqueued since the last flush (one bin of one stage is the natural
     // unit: results never influence which candidates are enumerated).
@@ -176,13 +188,14 @@ class GpuLevMyersAligner {
 public:
     GpuLevMyersAligner(GpuReference& ref, uint32_t max_cigar_len) : ref_(ref), stride_((max_cigar_len + 3) / 4 * 4) {}
 
-    bool preprocessRawSeq(const uchar_t* seq, uint32_t seq_len, genome_t orientation)
+    template <class G>
+    bool preprocessRawSeq(const uchar_t* seq, uint32_t seq_len, G orientation)
     {
         offsets_.push_back(blob_.size());
         lens_.push_back(seq_len);
         blob_.insert(blob_.end(), seq, seq + seq_len);
         cur_read_ = (uint32_t)lens_.size() - 1;
-        cur_flags_ = orientation == genome_t::rev_comp ? WAMD_TASK_FLAG_REV_COMP : 0;
+        cur_flags_ = is_rev_comp(orientation) ? WAMD_TASK_FLAG_REV_COMP : 0;
         return true;
     }
     size_t dynamicProgramming(ref_pos_t ref_pos, uint32_t max_distance_in_ref, uint32_t max_mate_edit_distance)
@@ -227,6 +240,191 @@ private:
     std::vector<uint32_t> lens_;
     std::vector<wamd_dist_task> tasks_;
     std::vector<wamd_align_result> results_;
+    std::vector<uchar_t> cigars_;
+    uint32_t cur_read_ = 0;
+    uint32_t cur_flags_ = 0;
+};
+
+// Mirrors CIndelMatching (mapper/indels.h:277-286) for the sensitive-mode matcher of the mapping stages
+// (mapper/mapping_core_sa.cpp:258-272, 310-326): Preprocess + Match enqueue, flush() runs wamd_indel_match,
+// result(ticket, candidate_mapping) fills the reference's candidate_mapping_t (common/types.h:224-318) the way
+// Match leaves it - direction and the rc position fix-up stay with the caller, as in the reference.
+class GpuIndelMatching {
+public:
+    GpuIndelMatching(GpuReference& ref, const wamd_indel_params& params) : ref_(ref), params_(params) {}
+
+    template <class G>
+    bool Preprocess(const uchar_t* seq, uint32_t seq_len, G orientation)   // nibble-packed read (indels.cpp:125-160)
+    {
+        return add_read(seq, (seq_len + 1) / 2, seq_len, WAMD_READS_NIBBLE, is_rev_comp(orientation));
+    }
+    template <class G>
+    bool PreprocessRawSeq(const uchar_t* seq, uint32_t seq_len, G orientation)   // one ASCII symbol per byte
+    {
+        return add_read(seq, seq_len, seq_len, WAMD_READS_ASCII, is_rev_comp(orientation));
+    }
+    // Match(ref_pos, max_indel_size, fixed_segment_pos, fixed_segment_size, max_no_mismatches, candidate_mapping)
+    size_t Match(ref_pos_t ref_pos, uint32_t max_indel_size, uint32_t fixed_segment_pos, uint32_t fixed_segment_size,
+                 uint32_t max_no_mismatches)
+    {
+        wamd_indel_task t{};
+        t.read_idx = cur_read_;
+        t.ref_pos = ref_pos;
+        t.max_indel_size = (uint16_t)max_indel_size;
+        t.fixed_segment_pos = (uint16_t)fixed_segment_pos;
+        t.fixed_segment_size = (uint16_t)fixed_segment_size;
+        t.max_no_mismatches = (uint8_t)max_no_mismatches;
+        t.flags = (uint8_t)cur_flags_;
+        tasks_.push_back(t);
+        return tasks_.size() - 1;
+    }
+    void flush()
+    {
+        results_.assign(tasks_.size(), wamd_mapping{});
+        if (tasks_.empty()) {
+            clear();
+            return;
+        }
+        offsets_.push_back(blob_.size());
+        wamd_reads* reads = nullptr;
+        check(wamd_reads_upload(ref_.ctx(), blob_.data(), offsets_.data(), lens_.data(), (uint32_t)lens_.size(), encoding_,
+                                need_rc_ ? 3 : 1, &reads), "wamd_reads_upload");
+        const int rc = wamd_indel_match(ref_.ctx(), reads, tasks_.data(), (uint32_t)tasks_.size(), &params_, results_.data());
+        wamd_reads_free(reads);
+        clear();
+        check(rc, "wamd_indel_match");
+    }
+    const wamd_mapping& result(size_t ticket) const { return results_.at(ticket); }
+    // Match's bool and out-parameter; M is the reference's candidate_mapping_t, T its mapping_type_t
+    template <class M>
+    bool result(size_t ticket, M& candidate_mapping) const
+    {
+        const wamd_mapping& r = results_.at(ticket);
+        if (!r.found)
+            return false;
+        candidate_mapping.type = static_cast<decltype(candidate_mapping.type)>(r.type);
+        candidate_mapping.pos = r.pos;
+        candidate_mapping.no_mismatches = r.no_mismatches;
+        candidate_mapping.matching_len1 = r.matching_len1;
+        candidate_mapping.matching_len2 = r.matching_len2;
+        candidate_mapping.indel_len1 = r.indel_len1;
+        candidate_mapping.indel_len2 = r.indel_len2;
+        candidate_mapping.clipping_len = r.clipping_len;
+        candidate_mapping.penalty = r.penalty;
+        return true;
+    }
+
+private:
+    bool add_read(const uchar_t* seq, size_t bytes, uint32_t seq_len, int encoding, bool rc)
+    {
+        if (!lens_.empty() && encoding != encoding_)
+            throw std::runtime_error("GpuIndelMatching: one encoding per batch");
+        encoding_ = encoding;
+        offsets_.push_back(blob_.size());
+        lens_.push_back(seq_len);
+        blob_.insert(blob_.end(), seq, seq + bytes);
+        cur_read_ = (uint32_t)lens_.size() - 1;
+        cur_flags_ = rc ? WAMD_TASK_FLAG_REV_COMP : 0;
+        need_rc_ = need_rc_ || rc;
+        return true;
+    }
+    void clear()
+    {
+        blob_.clear();
+        offsets_.clear();
+        lens_.clear();
+        tasks_.clear();
+        need_rc_ = false;
+    }
+    GpuReference& ref_;
+    wamd_indel_params params_;
+    std::vector<uchar_t> blob_;
+    std::vector<uint64_t> offsets_;
+    std::vector<uint32_t> lens_;
+    std::vector<wamd_indel_task> tasks_;
+    std::vector<wamd_mapping> results_;
+    int encoding_ = WAMD_READS_NIBBLE;
+    uint32_t cur_read_ = 0;
+    uint32_t cur_flags_ = 0;
+    bool need_rc_ = false;
+};
+
+// Mirrors CSoftClipping's rescue use (mapper/soft_clipping.h:122-137; sam_matching.cpp:556-575, 771-797):
+// preprocessRawSeq + match enqueue, flush() runs wamd_softclip_match (match and getExtCigar in one go),
+// result(ticket) holds match's out-parameters, extCigar(ticket) / result(ticket).affine_score getExtCigar's.
+class GpuSoftClipping {
+public:
+    GpuSoftClipping(GpuReference& ref, const wamd_softclip_params& params, uint32_t max_cigar_len)
+        : ref_(ref), params_(params), stride_((max_cigar_len + 4) / 4 * 4) {}
+
+    template <class G>
+    bool preprocessRawSeq(const uchar_t* seq, uint32_t seq_len, G orientation)
+    {
+        offsets_.push_back(blob_.size());
+        lens_.push_back(seq_len);
+        blob_.insert(blob_.end(), seq, seq + seq_len);
+        cur_read_ = (uint32_t)lens_.size() - 1;
+        cur_flags_ = is_rev_comp(orientation) ? WAMD_TASK_FLAG_REV_COMP : 0;
+        return true;
+    }
+    // match(ref_pos, max_distance_in_ref, min_exact_len, pos, left_clipping, ..., no_mismatches)
+    size_t match(ref_pos_t ref_pos, uint32_t max_distance_in_ref, uint32_t min_exact_len)
+    {
+        wamd_softclip_task t{};
+        t.read_idx = cur_read_;
+        t.ref_pos = ref_pos;
+        t.max_distance_in_ref = max_distance_in_ref;
+        t.min_exact_len = (uint16_t)min_exact_len;
+        t.flags = (uint8_t)cur_flags_;
+        tasks_.push_back(t);
+        return tasks_.size() - 1;
+    }
+    void flush()
+    {
+        results_.assign(tasks_.size(), wamd_softclip_result{});
+        cigars_.assign(tasks_.size() * (size_t)stride_, 0);
+        if (!tasks_.empty()) {
+            offsets_.push_back(blob_.size());
+            wamd_reads* reads = nullptr;
+            check(wamd_reads_upload(ref_.ctx(), blob_.data(), offsets_.data(), lens_.data(), (uint32_t)lens_.size(),
+                                    WAMD_READS_ASCII, 3, &reads), "wamd_reads_upload");
+            const int rc = wamd_softclip_match(ref_.ctx(), reads, tasks_.data(), (uint32_t)tasks_.size(), &params_,
+                                               results_.data(), cigars_.data(), stride_);
+            wamd_reads_free(reads);
+            params_.fresh_object = 0;   // the reference's object keeps its touched cells from call to call
+            blob_.clear();
+            offsets_.clear();
+            lens_.clear();
+            tasks_.clear();
+            check(rc, "wamd_softclip_match");
+        }
+    }
+    // match's bool and out-parameters
+    bool result(size_t ticket, ref_pos_t& pos, uint32_t& left_clipping, uint32_t& right_clipping, uint32_t& left_match,
+                uint32_t& right_match, int32_t& del_size, uint32_t& no_mismatches) const
+    {
+        const wamd_softclip_result& r = results_.at(ticket);
+        pos = r.pos;
+        left_clipping = r.left_clipping;
+        right_clipping = r.right_clipping;
+        left_match = r.left_match;
+        right_match = r.right_match;
+        del_size = r.del_size;
+        no_mismatches = r.no_mismatches;
+        return r.found != 0;
+    }
+    const wamd_softclip_result& result(size_t ticket) const { return results_.at(ticket); }
+    const uchar_t* extCigar(size_t ticket) const { return cigars_.data() + ticket * (size_t)stride_; }
+
+private:
+    GpuReference& ref_;
+    wamd_softclip_params params_;
+    uint32_t stride_;
+    std::vector<uchar_t> blob_;
+    std::vector<uint64_t> offsets_;
+    std::vector<uint32_t> lens_;
+    std::vector<wamd_softclip_task> tasks_;
+    std::vector<wamd_softclip_result> results_;
     std::vector<uchar_t> cigars_;
     uint32_t cur_read_ = 0;
     uint32_t cur_flags_ = 0;

@@ -1,7 +1,8 @@
 // replay_batch.cpp - drives the C++ mirror classes (gpu_verifier.hpp) the way the reference's
 // loops would: per read preprocess(), per candidate dynamicProgramming()/LevDiag(), one flush.
 // Input / output are flat binary files written and checked by tests/test_host_mirror.py.
-//   replay_batch <in.bin> <out.bin>
+//   replay_batch <in.bin> <out.bin> [--accepted-only]
+//   replay_batch --rescue <in.bin> <out.bin>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -20,8 +21,70 @@ template <class T> static std::vector<T> read_vec(std::ifstream& f)
     return v;
 }
 
+// replay_batch --rescue <in.bin> <out.bin>: the sensitive-mode matcher and the hashing rescue through their
+// mirrors, one Preprocess / preprocessRawSeq per read and one Match / match per candidate, one flush each.
+static int replay_rescue(const char* in, const char* out)
+{
+    std::ifstream f(in, std::ios::binary);
+    uint32_t hdr[4];   // ref_size, cur_offset, cigar stride of the rescue, unused
+    f.read((char*)hdr, sizeof(hdr));
+    auto genome = read_vec<uchar_t>(f);
+    auto ip = read_vec<wamd_indel_params>(f);
+    auto iblob = read_vec<uchar_t>(f);           // nibble-packed reads of the matcher
+    auto ioff = read_vec<uint64_t>(f);           // n + 1 offsets
+    auto ilen = read_vec<uint32_t>(f);
+    auto itasks = read_vec<wamd_indel_task>(f);  // sorted by read
+    auto sp = read_vec<wamd_softclip_params>(f);
+    auto sblob = read_vec<uchar_t>(f);           // ASCII reads of the rescue
+    auto soff = read_vec<uint64_t>(f);
+    auto slen = read_vec<uint32_t>(f);
+    auto stasks = read_vec<wamd_softclip_task>(f);
+
+    GpuReference ref(0, genome.data(), genome.size(), hdr[0], hdr[1]);
+    ref.setMaxTextLen(16384);   // sam.cpp:190
+    GpuIndelMatching im(ref, ip.at(0));
+    std::vector<size_t> it(itasks.size());
+    size_t k = 0;
+    for (uint32_t r = 0; r < ilen.size(); ++r) {
+        im.Preprocess(iblob.data() + ioff[r], ilen[r], genome_t::direct);
+        for (; k < itasks.size() && itasks[k].read_idx == r; ++k)
+            it[k] = im.Match(itasks[k].ref_pos, itasks[k].max_indel_size, itasks[k].fixed_segment_pos,
+                             itasks[k].fixed_segment_size, itasks[k].max_no_mismatches);
+    }
+    im.flush();
+    GpuSoftClipping sc(ref, sp.at(0), hdr[2] - 1);
+    std::vector<size_t> st(stasks.size());
+    k = 0;
+    for (uint32_t r = 0; r < slen.size(); ++r) {
+        // the task's flag is the orientation the reference passes to preprocessRawSeq (sam_matching.cpp:556)
+        for (; k < stasks.size() && stasks[k].read_idx == r; ++k) {
+            sc.preprocessRawSeq(sblob.data() + soff[r], slen[r],
+                                (stasks[k].flags & WAMD_TASK_FLAG_REV_COMP) ? genome_t::rev_comp : genome_t::direct);
+            st[k] = sc.match(stasks[k].ref_pos, stasks[k].max_distance_in_ref, stasks[k].min_exact_len);
+        }
+    }
+    sc.flush();
+    std::ofstream o(out, std::ios::binary);
+    for (size_t i = 0; i < itasks.size(); ++i)
+        o.write((const char*)&im.result(it[i]), sizeof(wamd_mapping));
+    for (size_t i = 0; i < stasks.size(); ++i)
+        o.write((const char*)&sc.result(st[i]), sizeof(wamd_softclip_result));
+    for (size_t i = 0; i < stasks.size(); ++i)
+        o.write((const char*)sc.extCigar(st[i]), hdr[2]);
+    std::cout << "replayed " << itasks.size() << " Match and " << stasks.size() << " match calls\n";
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
+    if (argc == 4 && std::string(argv[1]) == "--rescue") {
+        try {
+            return replay_rescue(argv[2], argv[3]);
+        } catch (const std::exception& e) {
+            std::cerr << "error: " << e.what() << "\n";
+            return 1;
+        }
+    }
     if (argc != 3 && !(argc == 4 && std::string(argv[3]) == "--accepted-only")) {
         std::cerr << "usage: replay_batch <in.bin> <out.bin> [--accepted-only]\n";
         return 2;
