@@ -23,6 +23,15 @@
 // extension compares 512 symbols per step, the split search of the approximate indel is a
 // wave scan over mismatch differences.  Blocks are persistent: the table is cleared through
 // the insertion log, as the reference does.
+//
+// One window per wave means wave-uniform code: what it costs is instructions, 63 of 64 lanes idle.  Three
+// shortcuts keep the serial parts short without touching their outcome (round 2: 6.75 -> 2.9 ms per 2^18
+// windows of 660 symbols):
+//   * insertion: a batch of 64 entries sits down at once when their cells are empty and distinct, else it is
+//     redone in order, probing LDS only for entries whose cell was taken;
+//   * hits whose chain holds one entry that agrees with the text on fewer than min_exact_len symbols are
+//     dropped by their own lanes before the serial loop (serving them changes nothing);
+//   * the hits of a read's own diagonal that only move the diagonal's mark are retired a stretch at a time.
 #include "wamd_internal.h"
 
 namespace wamd {
@@ -184,13 +193,39 @@ __global__ __launch_bounds__(64) void softclip_match_kernel(GenomeView g, ReadsV
         // ---- preprocess: insert every 20-mer in order, linear probing (139-231) ----------
         // (the wave's DS operations execute in program order, so a probe sees every earlier insert
         // without a barrier; the hashed cells of 64 consecutive 20-mers sit one per lane)
+        // A batch of 64 consecutive 20-mers first tries to sit down all at once: when every hashed cell is empty
+        // and no two of them are the same cell, linear probing in order puts each entry in its own cell (64
+        // entries for one LDS round trip; at 131 entries in 8192 cells about every other batch).  Otherwise the
+        // batch is undone and inserted one by one - still without a round trip per entry while an entry's cell
+        // was empty before the batch and no earlier entry of the batch ended up in it.
         for (uint32_t ib = HASH_LEN - 1; ib < m; ib += 64) {
-            const uint32_t mine = ib + lane < m ? (key_low(L.query, ib + lane) * 0x5555u) & ht_mask : 0u;
             const uint32_t cnt = min(64u, m - ib);
+            const bool valid = lane < cnt;
+            const uint32_t mine = valid ? (key_low(L.query, ib + lane) * 0x5555u) & ht_mask : 0u;
+            const uint32_t value = ib + lane - (HASH_LEN - 1);
+            uint32_t pre = EMPTY;
+            if (valid) {
+                pre = L.table[mine];
+                L.table[mine] = (CELL)value;
+            }
+            // (volatile: the compiler must not assume a lane reads back what it has just stored)
+            const bool lost = valid && (pre != EMPTY || const_cast<volatile CELL*>(L.table)[mine] != (CELL)value);
+            if (!__any(lost)) {
+                if (valid)
+                    L.cell[ib + lane] = (uint16_t)mine;
+                continue;
+            }
+            if (valid)
+                L.table[mine] = (CELL)pre;   // every writer of a cell saw the same earlier content
+            uint32_t fin = 0xffffffffu;   // lane u: where entry u of this batch went
             for (uint32_t u = 0; u < cnt; ++u) {
                 uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)u);
-                while (L.table[p] != EMPTY)
-                    p = (p + 1) & ht_mask;
+                const uint32_t before = (uint32_t)__builtin_amdgcn_readlane((int)pre, (int)u);
+                if (before != EMPTY || __any(fin == p)) {
+                    while (L.table[p] != EMPTY)
+                        p = (p + 1) & ht_mask;
+                }
+                fin = lane == u ? p : fin;
                 if (lane == 0) {
                     L.table[p] = (CELL)(ib + u - (HASH_LEN - 1));
                     L.cell[ib + u] = (uint16_t)p;
@@ -224,9 +259,87 @@ __global__ __launch_bounds__(64) void softclip_match_kernel(GenomeView g, ReadsV
                 cell_q0 = L.table[first_cell];
                 cell_q1 = L.table[first_cell + 1 >= ht_size ? 0u : first_cell + 1];
             }
-            uint64_t pending = __ballot(cell_q0 != EMPTY);
+            // A chain of one entry whose read position and this text position agree on fewer than min_exact_len
+            // symbols changes nothing when it is served (nothing below happens under that length): such hits -
+            // the 20-mers that merely share their last eight symbols with a 20-mer of the read - drop out here,
+            // all lanes comparing their own at once.
+            bool dud = false;
+            if (cell_q0 != EMPTY && cell_q1 == EMPTY && min_exact <= 64u) {
+                const uint32_t q = cell_q0, pt = j - (HASH_LEN - 1);
+                if (m - q < min_exact) {
+                    dud = true;
+                } else {
+                    for (uint32_t o = 0; o < min_exact && !dud; o += 8) {
+                        uint32_t diff = sym8(L.query, q + o) ^ gp8(pt + o);
+                        if (min_exact - o < 8)
+                            diff &= (1u << (4 * (min_exact - o))) - 1u;
+                        dud = diff != 0;
+                    }
+                }
+            }
+            uint64_t pending = __ballot(cell_q0 != EMPTY && !dud);
             while (pending) {
                 const int src = __builtin_ctzll(pending);
+                // ---- hits that change nothing but the diagonal's mark, a whole stretch at once -------------
+                // A read that matches its window produces one hit per text position on one diagonal, all
+                // inside the run the first of them found.  Served one by one, such a hit (not the read's
+                // first 20-mer, no longer than the best so far, and - when the run ends with the read and a
+                // left-boundary run is remembered - neither completing an indel nor due for the approximate
+                // search) only moves checked_pos_left of its diagonal, every other hit.  The lanes decide that
+                // for their own hit in parallel; the leading stretch of such lanes is retired arithmetically.
+                if (run_front <= W) {
+                    const uint32_t q = cell_q0;
+                    bool plain = ((pending >> lane) & 1ull) && cell_q1 == EMPTY && q != 0 && q >= run_q && q < run_end &&
+                                 j - (HASH_LEN - 1) - q == run_front;
+                    const int32_t len = (int32_t)(run_end - q);
+                    const bool to_end = run_end == m && left_exact_len > 0;
+                    int32_t text_dist = 0;
+                    if (plain && len >= (int32_t)min_exact) {
+                        plain = len <= best_score;
+                        if (to_end) {
+                            text_dist = (int32_t)(run_front + run_end) - left_text_pos;
+                            plain = plain && left_exact_len + len < (int32_t)m && left_exact_len + len != text_dist;
+                        }
+                    }
+                    const uint64_t pm = __ballot(plain) >> src;
+                    uint32_t cnt = pm == ~0ull ? 64u - (uint32_t)src : (uint32_t)__builtin_ctzll(~pm);
+                    if (cnt) {
+                        const uint32_t qa = (uint32_t)__builtin_amdgcn_readlane((int)cell_q0, src);
+                        // hits long enough to leave a mark: qa .. lim
+                        const uint32_t qb = qa + cnt - 1;
+                        const bool marks = run_end >= min_exact && qa <= run_end - min_exact;
+                        bool ok = true;
+                        if (marks && to_end) {   // the approximate search must not be due (358-360)
+                            const int32_t td = (int32_t)(run_front + run_end) - left_text_pos;
+                            const int32_t indel_len = abs(td - (int32_t)m);
+                            if (indel_len >= (int32_t)prm.min_approx_indel_len && indel_len <= (int32_t)prm.max_approx_indel_len &&
+                                !((L.checked_right[run_front >> 5] >> (run_front & 31)) & 1u))
+                                ok = false;
+                        }
+                        if (ok) {
+                            if (marks) {
+                                const uint32_t lim = min(qb, run_end - min_exact);
+                                if (run_front != cl_front) {
+                                    cl_front = run_front;
+                                    cl_val = L.checked_left[run_front];
+                                }
+                                const uint32_t cl = cl_val == EMPTY16 ? (1u << 30) : cl_val;
+                                const uint32_t s0 = cl + 1 != qa ? qa : qa + 1;   // the first hit that is served
+                                if (s0 <= lim) {
+                                    const uint32_t last = s0 + ((lim - s0) & ~1u);
+                                    cl_val = last;
+                                    if (lane == 0) {
+                                        L.checked_left[run_front] = (uint16_t)last;
+                                        if (to_end)   // 445
+                                            L.checked_right[run_front >> 5] |= 1u << (run_front & 31);
+                                    }
+                                }
+                            }
+                            pending = cnt >= 64u - (uint32_t)src ? 0ull : pending & ~(((1ull << cnt) - 1ull) << src);
+                            continue;
+                        }
+                    }
+                }
                 pending &= pending - 1;
                 const uint32_t jh = jb + (uint32_t)src;
                 uint32_t ht_pos = (uint32_t)__builtin_amdgcn_readlane((int)first_cell, src);
