@@ -563,7 +563,7 @@ __device__ __forceinline__ void levdiag_band_body(const GenomeView& g, const Rea
     uint32_t read_odd = 0;   // bit c: the read holds code c >= 4
     {
         const uint32_t slot = (uint32_t)(rv.slot_direct < 0 ? 0 : rv.slot_direct);
-        const uint4* src = reinterpret_cast<const uint4*>(rv.pm32) + ((uint64_t)read_idx * rv.n_orient + slot) * rv.words32;
+        const uint4* src = reinterpret_cast<const uint4*>(rv.pm32) + ((uint64_t)read_idx * rv.n_orient + slot) * rv.pm32_stride;
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) {
             uint4 v = make_uint4(0u, 0u, 0u, 0u);   // rows A, C, G, T of dword j - LDB_PAD

@@ -44,15 +44,19 @@ struct NibStream {
     int64_t origin_dw;
     int32_t n_dw;
     uint32_t stride;
-    uint32_t cur;
-    int64_t cur_dw;
+    uint32_t cur, nxt;
+    int64_t cur_dw, nxt_dw;
     bool packed;   // dwords as they lie in memory (two symbols per byte, even one high): swap on load
+    __device__ __forceinline__ uint32_t fetch(int64_t dw) const
+    {
+        int64_t d = dw - origin_dw;
+        d = d < 0 ? 0 : (d >= n_dw ? n_dw - 1 : d);
+        return base[d * stride];
+    }
     __device__ __forceinline__ void load()
     {
-        int64_t d = (idx >> 3) - origin_dw;
-        d = d < 0 ? 0 : (d >= n_dw ? n_dw - 1 : d);
         cur_dw = idx >> 3;
-        const uint32_t v = base[d * stride];
+        const uint32_t v = fetch(cur_dw);
         cur = packed ? nibble_swap(v) : v;
     }
     __device__ __forceinline__ void init(const uint32_t* b, uint32_t stride_, int64_t origin, int32_t n, int64_t start,
@@ -64,12 +68,24 @@ struct NibStream {
         origin_dw = origin;
         n_dw = n;
         idx = start;
+        nxt_dw = INT64_MIN;
+        nxt = 0;
         load();
     }
     __device__ __forceinline__ uint32_t get(int step)
     {
-        if ((idx >> 3) != cur_dw)
-            load();
+        if ((idx >> 3) != cur_dw) {
+            if (packed && (idx >> 3) == nxt_dw) {   // the dword asked for eight symbols ago
+                cur = nibble_swap(nxt);
+                cur_dw = nxt_dw;
+            } else {
+                load();
+            }
+            if (packed) {   // straight from memory: the following dword is requested now, used eight symbols on
+                nxt_dw = cur_dw + (step > 0 ? 1 : -1);
+                nxt = fetch(nxt_dw);
+            }
+        }
         const uint32_t s = (cur >> (4 * (uint32_t)(idx & 7))) & 15u;
         idx += step;
         return s;
@@ -374,7 +390,7 @@ __global__ __launch_bounds__(BLOCK, (PHASE == 1 && NW <= 4 ? WAMD_WALK_WAVES : 1
             const int32_t Zf = (int32_t)s_col + (int32_t)m - 2 - (int32_t)ed - (int32_t)end_pos - 16 - (int32_t)delay;
             {
                 const uint32_t slot = valid ? (uint32_t)(rev ? rv.slot_rc : rv.slot_direct) : 0;
-                const uint32_t* src = rv.pm32 + ((uint64_t)read_idx * rv.n_orient + slot) * 4 * rv.words32;
+                const uint32_t* src = rv.pm32 + ((uint64_t)read_idx * rv.n_orient + slot) * 4 * rv.pm32_stride;
                 if (valid)
                     presence = rv.meta[(uint64_t)read_idx * rv.n_orient + slot] & 0xffffu;
                 // pm32 is top-aligned: read row r is bit r + pad, the bits below are ones (phantom rows)
@@ -959,7 +975,7 @@ __global__ __launch_bounds__(BLOCK, (PHASE == 1 && NW <= 4 ? WAMD_WALK_WAVES : 1
             rf.init(st_read, BLOCK, 0, rd_n, rev ? (int64_t)m - 1 : 0);
         gf.init(st_gen, BLOCK, g_origin, gd_n, (int64_t)ref_pos + begin_pos);
         uint32_t hist = 0, ref_hist = 0;
-        uint32_t pw = 0;
+        uint32_t pw = 0, pw_next = 0;
 #ifdef WAMD_EXP_NO_REPLAY
         valid = false;
 #endif
@@ -967,8 +983,13 @@ __global__ __launch_bounds__(BLOCK, (PHASE == 1 && NW <= 4 ? WAMD_WALK_WAVES : 1
         for (uint32_t k = 0; __any(k < total); ++k) {
             if (k < total) {
                 const uint32_t st = total - 1 - k;   // steps were recorded end to start
-                if (k == 0 || (st & 15u) == 15u)
+                if (k == 0) {
                     pw = path[(uint64_t)(st / 16) * BLOCK + tid];
+                    pw_next = st >= 16 ? path[(uint64_t)(st / 16 - 1) * BLOCK + tid] : 0u;
+                } else if ((st & 15u) == 15u) {   // the dword asked for sixteen steps ago; ask for the one after it
+                    pw = pw_next;
+                    pw_next = st >= 16 ? path[(uint64_t)(st / 16 - 1) * BLOCK + tid] : 0u;
+                }
                 const uint32_t dir = (pw >> (2 * (st & 15u))) & 3u;
                 uint32_t op, b0, b1 = 0;
                 if (dir == DIR_D) {
@@ -1089,14 +1110,17 @@ static AlignLayout align_layout(const wamd_reads* r, uint32_t n)
         L.slot_bytes_max = per_block[c] > L.slot_bytes_max ? per_block[c] : L.slot_bytes_max;
     }
     const uint32_t need_blocks = (n + L.block - 1) / L.block;
-    const uint32_t cap_blocks = 256 * 16;   // sixteen waves per CU
+    const uint32_t cap_blocks = 256 * 32;   // twice the sixteen waves per CU that are resident: finished waves are replaced at once
     L.blocks = need_blocks < cap_blocks ? need_blocks : cap_blocks;
     if (L.blocks == 0)
         L.blocks = 1;
-    // the region serves the classes one after the other: all blocks of the banded class, and at
-    // least 2048 blocks (eight waves per CU) of the 64-row class when the batch has that many
+    // the region serves the classes one after the other: all blocks of the banded class, and blocks of the
+    // 64-row class (ed 15 .. 30) - 2048 of them (eight waves per CU) where such distances are the workload
+    // (reads above 160 symbols: the 250 bp high-error configuration), 256 (one wave per CU) for Illumina 150 bp
+    // reads, where they are stragglers: what a task then costs the caller is about 200 B instead of 840 B
     uint64_t region = (uint64_t)L.blocks * per_block[0];
-    const uint64_t wide = (uint64_t)(need_blocks < 2048u ? (need_blocks ? need_blocks : 1u) : 2048u) * per_block[1];
+    const uint32_t wide_blocks = m > 160 ? 2048u : 256u;
+    const uint64_t wide = (uint64_t)(need_blocks < wide_blocks ? (need_blocks ? need_blocks : 1u) : wide_blocks) * per_block[1];
     region = region < wide ? wide : region;
     if (region < L.slot_bytes_max)
         region = L.slot_bytes_max;

@@ -594,7 +594,7 @@ __global__ __launch_bounds__(BLOCK) WAMD_KATTR void myers_distance_kernel(
     {
         const uint32_t slot = valid ? (uint32_t)(t.rev ? rv.slot_rc : rv.slot_direct) : 0;
         const uint32_t pad = NW - rv.words32;   // launcher: NW >= words32
-        const uint4* src = reinterpret_cast<const uint4*>(rv.pm32) + ((uint64_t)read_idx * rv.n_orient + slot) * rv.words32;
+        const uint4* src = reinterpret_cast<const uint4*>(rv.pm32) + ((uint64_t)read_idx * rv.n_orient + slot) * rv.pm32_stride;
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
             uint4 v = make_uint4(~0u, ~0u, ~0u, ~0u);   // dwords below the batch's own vectors: phantom rows
@@ -852,7 +852,7 @@ __global__ __launch_bounds__(BLOCK) void myers_band_kernel(
     const uint32_t W32 = rv.words32;
     {
         const uint32_t slot = valid ? (uint32_t)(t.rev ? rv.slot_rc : rv.slot_direct) : 0;
-        const uint4* src = reinterpret_cast<const uint4*>(rv.pm32) + ((uint64_t)read_idx * rv.n_orient + slot) * W32;
+        const uint4* src = reinterpret_cast<const uint4*>(rv.pm32) + ((uint64_t)read_idx * rv.n_orient + slot) * rv.pm32_stride;
         for (uint32_t d = 0; d < W32; ++d) {
             uint4 v = make_uint4(~0u, ~0u, ~0u, ~0u);
             if (valid)

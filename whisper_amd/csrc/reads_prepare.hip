@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void pattern_vectors32_kernel(ReadsView rv, ui
         row[3] |= squeeze((acgt & b0 & b1) | ph) << g0;
     }
     // [dword][A,C,G,T]: the verification kernels fetch a dword of all four rows with one 16-byte load
-    uint4* dst = reinterpret_cast<uint4*>(pm32) + (uint64_t)(read * (uint64_t)rv.n_orient + slot) * rv.words32 + j;
+    uint4* dst = reinterpret_cast<uint4*>(pm32) + (uint64_t)(read * (uint64_t)rv.n_orient + slot) * rv.pm32_stride + j;
     *dst = make_uint4(row[0], row[1], row[2], row[3]);
 }
 

@@ -146,6 +146,7 @@ wamd::ReadsView wamd_reads::view() const
     v.n = n;
     v.words = words;
     v.words32 = words32;
+    v.pm32_stride = pm32_stride;
     v.n_orient = (orientations == 3) ? 2 : 1;
     v.slot_direct = (orientations & 1) ? 0 : -1;
     v.slot_rc = (orientations & 2) ? ((orientations & 1) ? 1 : 0) : -1;
@@ -373,6 +374,7 @@ int wamd_reads_upload(wamd_ctx* ctx, const uint8_t* data, const uint64_t* offset
     r->max_len = max_len;
     r->words = max_len ? (max_len - 1) / 64 + 1 : 1;
     r->words32 = max_len ? (max_len - 1) / 32 + 1 : 1;
+    r->pm32_stride = r->words32 <= 4 ? (r->words32 <= 2 ? r->words32 : 4u) : (r->words32 + 7u) / 8u * 8u;
     r->codes_bytes = acc;
     const uint32_t n_orient = orientations == 3 ? 2 : 1;
     int rc = WAMD_OK;
@@ -382,7 +384,7 @@ int wamd_reads_upload(wamd_ctx* ctx, const uint8_t* data, const uint64_t* offset
         hipError_t e;
         hipStream_t s = ctx->stream;
         const uint64_t pm_bytes = (uint64_t)n * n_orient * 4 * r->words * sizeof(uint64_t);
-        const uint64_t pm32_bytes = (uint64_t)n * n_orient * 4 * r->words32 * sizeof(uint32_t);
+        const uint64_t pm32_bytes = (uint64_t)n * n_orient * 4 * r->pm32_stride * sizeof(uint32_t);
         if ((e = hipMalloc(&r->d_codes, acc + 64)) != hipSuccess ||
             (e = hipMalloc(&r->d_code_off, ((size_t)n + 1) * sizeof(uint64_t))) != hipSuccess ||
             (e = hipMalloc(&r->d_lens, ((size_t)n + 1) * sizeof(uint32_t))) != hipSuccess ||

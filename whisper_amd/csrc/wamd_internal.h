@@ -50,6 +50,8 @@ struct ReadsView {
     uint32_t n;
     uint32_t words;        // 64-bit words per bit-vector in this batch (max over reads)
     uint32_t words32;      // dwords per top-aligned bit-vector (ceil(max_len / 32))
+    uint32_t pm32_stride;  // 16-byte units from one (read, slot)'s pm32 rows to the next: words32 rounded up so
+                           // that a row set never straddles a 128-byte line (4, 8, then multiples of 8)
     uint32_t n_orient;     // 1 or 2 slots per read
     int32_t slot_direct;   // slot index of the direct orientation, -1 if absent
     int32_t slot_rc;
@@ -104,6 +106,7 @@ struct wamd_reads {
     uint64_t* d_pm;
     uint32_t* d_pm32;
     uint32_t words32;
+    uint32_t pm32_stride;
     uint32_t* d_meta;
     uint64_t codes_bytes;
     // the 64-bit pattern vectors are only read by the traceback's wide classes: built by the first
