@@ -81,6 +81,26 @@ def measured_counters():
         return {}
 
 
+# ---- profile markers -------------------------------------------------------------------------------------------
+# `--profile-markers` brackets every timed region with two tiny float64 fill kernels of distinct sizes, so that a
+# rocprofv3 counter pass (which cannot carry marker traces together with --pmc on this pool) can still be cut into
+# "the dispatches of S2", "of S4", ...: scripts/summarize_extras.py ranks the FillFunctor<double> dispatches by grid
+# size (rank 2i = begin of region i, 2i + 1 = its end; the regions in the order of MARKS["tags"]).
+MARKS = {"on": False, "tags": [], "reps": {}, "units": {}}
+
+
+def mark(tag, begin, stream, device, reps=None, units=None):
+    if not MARKS["on"]:
+        return
+    if begin:
+        MARKS["tags"].append(tag)
+        MARKS["reps"][tag] = reps
+        MARKS["units"][tag] = units
+    i = 2 * MARKS["tags"].index(tag) + (0 if begin else 1)
+    with torch.cuda.stream(stream):
+        torch.empty((i + 1) * 65536, dtype=torch.float64, device=device).fill_(1.0)
+
+
 def host_info():
     model = "unknown"
     try:
@@ -219,18 +239,22 @@ def run_extras(ctx, device, genome_symbols, stream, n_small):
     G = codes.numel()
     out = {}
 
-    def timed(fn, reps=3, prep=None):
+    def timed(fn, reps=3, prep=None, tag=None, units=None):
         if prep:
             prep()
         fn()
         ctx.synchronize()
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        if tag:
+            mark(tag, True, stream, device, reps, units)
         for a, b in evs:
             if prep:
                 prep()
             a.record(stream)
             fn()
             b.record(stream)
+        if tag:
+            mark(tag, False, stream, device)
         ctx.synchronize()
         f = ctx.take_flags()
         if f:
@@ -255,7 +279,7 @@ def run_extras(ctx, device, genome_symbols, stream, n_small):
     t = synth.levdiag_tasks(rd, 5, fl, fr)
     d_t = dev_bytes(t)
     d_r = torch.zeros(n, dtype=torch.int32, device=device)
-    ms = timed(lambda: ctx.lev_diag_dev(reads, d_t, n, d_r))
+    ms = timed(lambda: ctx.lev_diag_dev(reads, d_t, n, d_r), tag="S2_levdiag", units=n)
     acc = float((d_r.cpu().numpy().view(np.uint32) <= 5).mean())
     out["S2_levdiag"] = {"shape": "CEditDist::LevDiag m=150 k=5 anchor [%d,%d)" % (fl, fr), "tasks": n,
                          "kernel_ms": ms, "candidates_per_s": n / ms * 1e3, "accepted_fraction": acc,
@@ -275,7 +299,7 @@ def run_extras(ctx, device, genome_symbols, stream, n_small):
     d_tc = dev_bytes(tc)
     d_rc = torch.zeros(n, dtype=torch.int32, device=device)
     reads = ctx.upload_reads(*host(rd["codes"], 0), api.READS_NIBBLE, orientations=1)
-    ms = timed(lambda: ctx.cf_filter_dev(reads, d_tc, n, d_rc))
+    ms = timed(lambda: ctx.cf_filter_dev(reads, d_tc, n, d_rc), tag="C_cf_filter", units=n)
     out["C_cf_filter"] = {"shape": "CF pre-filter m=150 anchor [%d,%d), pass iff L1 <= 20" % (fl, fr), "tasks": n,
                           "kernel_ms": ms, "candidates_per_s": n / ms * 1e3,
                           "pass_fraction": float((d_rc.cpu().numpy().view(np.uint32) <= 20).mean()),
@@ -290,13 +314,13 @@ def run_extras(ctx, device, genome_symbols, stream, n_small):
     d_t = dev_bytes(t)
     d_r = torch.zeros(n * 2, dtype=torch.int32, device=device)
     ctx.set_max_text_len(16384)
-    ms = timed(lambda: ctx.dynamic_programming_dev(reads, d_t, n, d_r, last_symbol=-1))
+    ms = timed(lambda: ctx.dynamic_programming_dev(reads, d_t, n, d_r, last_symbol=-1), tag="S5_distance_250bp", units=n)
     cols5 = 284 + 1 - 3
     out["S5_distance_250bp"] = {"shape": "LevMyers256 distance m=250 k=17 W=284", "tasks": n, "kernel_ms": ms,
                                 "candidates_per_s": n / ms * 1e3,
                                 "roofline": roof_valu(n, cols5 * (8 * 10 + 20), ms, "myers_distance_kernel<8,256>")}
     ctx.set_distance_mode(api.DISTANCE_ACCEPTED_ONLY)
-    ms = timed(lambda: ctx.dynamic_programming_dev(reads, d_t, n, d_r, last_symbol=-1))
+    ms = timed(lambda: ctx.dynamic_programming_dev(reads, d_t, n, d_r, last_symbol=-1), tag="S5_accepted_only", units=n)
     ctx.set_distance_mode(api.DISTANCE_EXACT)
     fs5 = (cols5 + 17 - 96 + 7) // 8 * 8
     out["S5_accepted_only"] = {"shape": "S5 in WAMD_DISTANCE_ACCEPTED_ONLY mode (96-row band)", "tasks": n,
@@ -309,7 +333,7 @@ def run_extras(ctx, device, genome_symbols, stream, n_small):
     d_rec = torch.zeros((n, 12), dtype=torch.uint8, device=device)
     d_cnt = torch.zeros(1, dtype=torch.int32, device=device)
     ctx.dynamic_programming_dev(reads, d_t, n, d_r, last_symbol=-1)
-    ms = timed(lambda: ctx.emit_lev_records_static_dev(n, d_t, d_r, d_pos, d_dir, d_rec, d_cnt))
+    ms = timed(lambda: ctx.emit_lev_records_static_dev(n, d_t, d_r, d_pos, d_dir, d_rec, d_cnt), tag="K_emit_lev_records", units=n)
     n_acc = int(d_cnt.item())
     out["K_emit_lev_records"] = {"shape": "accepted candidates -> 12-byte records in task order (count, scan, write)",
                                  "tasks": n, "records": n_acc, "kernel_ms": ms, "candidates_per_s": n / ms * 1e3,
@@ -330,7 +354,7 @@ def run_extras(ctx, device, genome_symbols, stream, n_small):
     d_c = torch.zeros(na * stride, dtype=torch.uint8, device=device)
     wsb = ctx.align_workspace_bytes(reads, na)
     d_w = torch.zeros(wsb, dtype=torch.uint8, device=device)
-    ms = timed(lambda: ctx.align_dev(reads, d_t, na, d_r, d_c, stride, d_w, wsb, last_symbol=0, refine=1))
+    ms = timed(lambda: ctx.align_dev(reads, d_t, na, d_r, d_c, stride, d_w, wsb, last_symbol=0, refine=1), tag="S4_align", units=na)
     res = d_r.cpu().numpy().view(api.ALIGN_RESULT)
     clen = float(res["cigar_len"][res["ok"] == 1].mean())
     out["S4_align"] = {"shape": "dynamicProgramming + getExtCigar + refine_ext_cigar m=150 k=13 W=177", "tasks": na,
@@ -374,14 +398,15 @@ def run_extras(ctx, device, genome_symbols, stream, n_small):
                 d_c.copy_(d_cig0, non_blocking=True)
         return go
 
-    ms = timed(lambda: ctx.clip_illegal_dev(na, d_ti, d_rec, d_c, stride), prep=fresh(d_rec0))
+    ms = timed(lambda: ctx.clip_illegal_dev(na, d_ti, d_rec, d_c, stride), prep=fresh(d_rec0), tag="L_clip_illegal", units=na)
     out["L_clip_illegal"] = {"shape": "clipIllegalPositions on S4's ext-CIGARs, 1 in 4 over a chromosome end",
                              "records": na, "kernel_ms": ms, "records_per_s": na / ms * 1e3,
                              "roofline": roof_hbm(na, scan + 8, ms, "clip_illegal_kernel")}
-    ms = timed(lambda: ctx.clip_boundary_dev(na, d_rec, d_c, stride), prep=fresh(d_rec0))
+    ms = timed(lambda: ctx.clip_boundary_dev(na, d_rec, d_c, stride), prep=fresh(d_rec0), tag="B_clip_boundary", units=na)
     out["B_clip_boundary"] = {"shape": "clipBoundaryPositions on S4's ext-CIGARs", "records": na, "kernel_ms": ms,
                               "records_per_s": na / ms * 1e3, "roofline": roof_hbm(na, scan, ms, "clip_boundary_kernel")}
-    ms = timed(lambda: ctx.clip_overlapping_pairs_dev(na // 2, d_tp, d_rec, d_c, stride), prep=fresh(d_recp0))
+    ms = timed(lambda: ctx.clip_overlapping_pairs_dev(na // 2, d_tp, d_rec, d_c, stride), prep=fresh(d_recp0),
+               tag="L_clip_overlapping_pairs", units=na // 2)
     out["L_clip_overlapping_pairs"] = {"shape": "clipOverlappingPairs, reverse read left of its mate by 0..99", "pairs": na // 2,
                                        "kernel_ms": ms, "pairs_per_s": na // 2 / ms * 1e3,
                                        "roofline": roof_hbm(na // 2, 2 * scan + 16, ms, "clip_pairs_kernel")}
@@ -389,7 +414,7 @@ def run_extras(ctx, device, genome_symbols, stream, n_small):
     d_sm = torch.zeros(na * 336, dtype=torch.uint8, device=device)
     d_sl = torch.zeros(na * 16, dtype=torch.uint8, device=device)
     fresh(d_rec0)()
-    ms = timed(lambda: ctx.sam_cigar_dev(na, d_c, stride, d_sc, 336, d_sm, 336, d_sl))
+    ms = timed(lambda: ctx.sam_cigar_dev(na, d_c, stride, d_sc, 336, d_sm, 336, d_sl), tag="X_sam_cigar", units=na)
     sl = d_sl.cpu().numpy().view(api.SAM_CIGAR_LEN)
     out["X_sam_cigar"] = {"shape": "extract_cigar_and_mdz on S4's ext-CIGARs", "records": na, "kernel_ms": ms,
                           "records_per_s": na / ms * 1e3,
@@ -420,7 +445,7 @@ def run_extras(ctx, device, genome_symbols, stream, n_small):
     padw = (-d_fw.data_ptr()) % 256
     prm = api.default_finish_params(14)
     ms = timed(lambda: ctx.finish_pairs_dev(reads_fin, d_ft, np_pairs, d_fr, d_fe, 352, d_fc, 352, d_fm, 352, d_fw[padw:],
-                                            fwb, params=prm))
+                                            fwb, params=prm), tag="N1_finish_pairs", units=np_pairs)
     fres = d_fr.cpu().numpy().view(api.FINISH_RESULT)
     out["N1_finish_pairs"] = {"shape": "mapping records -> fill_cigar -> clipIllegal / Boundary / OverlappingPairs -> CIGAR + MD:Z, "
                                        "m=150 flank=14, one call, nothing leaves the device", "pairs": np_pairs,
@@ -443,9 +468,10 @@ def run_extras(ctx, device, genome_symbols, stream, n_small):
         stride_ = 4 * ((2 * (m + k) + 8 + 3) // 4)
         d_r_ = torch.zeros(count * api.ALIGN_RESULT.itemsize, dtype=torch.uint8, device=device)
         d_c_ = torch.zeros(count * stride_, dtype=torch.uint8, device=device)
-        wsb_ = ctx.align_workspace_bytes(reads_, count)
+        wsb_ = ctx.align_workspace_bytes(reads_, count, max_ed=k)
         d_w_ = torch.zeros(wsb_, dtype=torch.uint8, device=device)
-        ms_ = timed(lambda: ctx.align_dev(reads_, d_t_, count, d_r_, d_c_, stride_, d_w_, wsb_, last_symbol=0, refine=1))
+        ms_ = timed(lambda: ctx.align_dev(reads_, d_t_, count, d_r_, d_c_, stride_, d_w_, wsb_, last_symbol=0, refine=1),
+                    tag=tag, units=count)
         res_ = d_r_.cpu().numpy().view(api.ALIGN_RESULT)
         cols_ = W + 1 - (m - 1) // 64
         dw_ = (m - 1) // 32 + 1
@@ -467,7 +493,7 @@ def run_extras(ctx, device, genome_symbols, stream, n_small):
         t = synth.distance_tasks(rd, m, k)
         d_t = dev_bytes(t)
         d_r = torch.zeros(na * 2, dtype=torch.int32, device=device)
-        ms = timed(lambda: ctx.dynamic_programming_dev(reads, d_t, na, d_r, last_symbol=-1))
+        ms = timed(lambda: ctx.dynamic_programming_dev(reads, d_t, na, d_r, last_symbol=-1), tag=tag, units=na)
         cols_ = (m + 2 * k + 1 - (m - 1) // 64) if m < 256 else m + 2 * k
         dw_ = (m - 1) // 32 + 1
         out[tag] = {"shape": "distance m=%d k=%d W=%d" % (m, k, m + 2 * k), "tasks": na, "kernel_ms": ms,
@@ -486,7 +512,7 @@ def run_extras(ctx, device, genome_symbols, stream, n_small):
     d_r = torch.zeros(na * api.MAPPING.itemsize, dtype=torch.uint8, device=device)
     prm_i = api.default_indel_params()
     prm_i.max_indel_bound = 50
-    ms = timed(lambda: ctx.indel_match_dev(reads, d_t, na, d_r, params=prm_i))
+    ms = timed(lambda: ctx.indel_match_dev(reads, d_t, na, d_r, params=prm_i), tag="S8_indel_match", units=na)
     res = d_r.cpu().numpy().view(api.MAPPING)
     out["S8_indel_match"] = {"shape": "CIndelMatching::Match m=150 max_indel=50 k=12", "tasks": na, "kernel_ms": ms,
                              "candidates_per_s": na / ms * 1e3, "found_fraction": float((res["found"] != 0).mean()),
@@ -495,7 +521,7 @@ def run_extras(ctx, device, genome_symbols, stream, n_small):
     d_dir = torch.ones(na, dtype=torch.uint8, device=device)
     d_wire = torch.zeros(na * 12, dtype=torch.uint8, device=device)
     d_sz = torch.zeros(na, dtype=torch.uint8, device=device)
-    ms = timed(lambda: ctx.serialize_mappings_dev(na, d_r, d_dir, d_wire, d_sz))
+    ms = timed(lambda: ctx.serialize_mappings_dev(na, d_r, d_dir, d_wire, d_sz), tag="K_serialize", units=na)
     out["K_serialize"] = {"shape": "candidate_mapping_t::serialize of S8's results", "records": na, "kernel_ms": ms,
                           "records_per_s": na / ms * 1e3, "roofline": roof_hbm(na, 40 + 1 + 12 + 1, ms, "serialize_kernel")}
     # G: GetExtCigarNew of the found mappings (fill_cigar_with_indel_matching, sam_matching.cpp:824-852)
@@ -509,7 +535,7 @@ def run_extras(ctx, device, genome_symbols, stream, n_small):
     d_ct = dev_bytes(ct)
     d_cr = torch.zeros(ng * api.INDEL_CIGAR_RESULT.itemsize, dtype=torch.uint8, device=device)
     d_cc = torch.zeros(ng * 512, dtype=torch.uint8, device=device)
-    ms = timed(lambda: ctx.indel_ext_cigar_dev(reads, d_ct, ng, d_cr, d_cc, 512))
+    ms = timed(lambda: ctx.indel_ext_cigar_dev(reads, d_ct, ng, d_cr, d_cc, 512), tag="G_indel_ext_cigar", units=ng)
     cres = d_cr.cpu().numpy().view(api.INDEL_CIGAR_RESULT)
     out["G_indel_ext_cigar"] = {"shape": "GetExtCigarNew of S8's found mappings", "records": ng, "kernel_ms": ms,
                                 "records_per_s": ng / ms * 1e3, "ok_fraction": float(cres["ok"].mean()),
@@ -528,7 +554,7 @@ def run_extras(ctx, device, genome_symbols, stream, n_small):
     d_t = dev_bytes(t)
     d_r = torch.zeros(ns * api.SOFTCLIP_RESULT.itemsize, dtype=torch.uint8, device=device)
     d_c = torch.zeros(ns * 384, dtype=torch.uint8, device=device)
-    ms = timed(lambda: ctx.softclip_match_dev(reads, d_t, ns, d_r, d_c, 384, 660))
+    ms = timed(lambda: ctx.softclip_match_dev(reads, d_t, ns, d_r, d_c, 384, 660), tag="S_softclip_match", units=ns)
     res = d_r.cpu().numpy().view(api.SOFTCLIP_RESULT)
     out["S_softclip_match"] = {"shape": "CSoftClipping::match + getExtCigar m=150 W=660", "tasks": ns, "kernel_ms": ms,
                                "candidates_per_s": ns / ms * 1e3, "found_fraction": float((res["found"] == 1).mean()),
@@ -566,11 +592,14 @@ def main():
     ap.add_argument("--true-frac", type=float, default=0.5,
                     help="fraction of candidates planted at their locus (S1 = 0.5; other values are experiments)")
     ap.add_argument("--no-boundary", action="store_true", help="skip the host-buffer (PCIe-inclusive) measurements")
+    ap.add_argument("--profile-markers", action="store_true",
+                    help="bracket every timed region with marker kernels (for scripts/summarize_extras.py; profiling only)")
     ap.add_argument("--gather", choices=("torch", "cabi"), default="torch",
                     help="N > 1: the record gather through torch.distributed (RCCL behind it; pipelined behind the next "
                          "bin) or through the library's own C-ABI (wamd_gather_records_dev over librccl, what the "
                          "C++ host calls)")
     args = ap.parse_args()
+    MARKS["on"] = args.profile_markers
 
     # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, as a CHILD process, before
     # anything here has touched the GPU, and relay the one JSON line rank 0 prints
@@ -722,12 +751,15 @@ def main():
 
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
            for _ in range(args.steps)]
+    main_tag = "S1_exact" if args.distance_mode == "exact" else "S1_accepted_only"
+    mark(main_tag, True, stream, device, args.steps, n)   # (no-ops unless --profile-markers; never in a judged run)
     t0 = time.perf_counter()
     for a, b in evs:
         # (in the multi-rank path the bracket also holds the wait for the buffer's last reader)
         a.record(stream)
         step()
         b.record(stream)
+    mark(main_tag, False, stream, device)
     last_buf = res_bufs[(args.steps - 1) & 1] if multi else d_results
     finish_gathers()
     ctx.synchronize()
@@ -756,10 +788,12 @@ def main():
         verify()
         ctx.synchronize()
         bev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+        mark("S1_accepted_only", True, stream, device, 5, n)
         for a, b in bev:
             a.record(stream)
             verify()
             b.record(stream)
+        mark("S1_accepted_only", False, stream, device)
         ctx.synchronize()
         ctx.set_distance_mode(api.DISTANCE_EXACT)
         bres = d_results.view(n, 2).cpu().numpy()
@@ -838,6 +872,8 @@ def main():
             torch.cuda.empty_cache()
             out["extras"] = run_extras(ctx, device, args.genome_symbols, stream, args.extras_tasks)
             out["extras"]["S1_accepted_only"] = banded
+        if MARKS["on"]:
+            out["profile_markers"] = {"tags": MARKS["tags"], "reps": MARKS["reps"], "units": MARKS["units"]}
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
         if out.get("parity_error"):

@@ -363,13 +363,19 @@ WAMD_API int wamd_cf_filter_dev(wamd_ctx* ctx, const wamd_reads* reads, const wa
 WAMD_API int wamd_align(wamd_ctx* ctx, const wamd_reads* reads, const wamd_dist_task* tasks,
                         uint32_t n, int last_symbol, int refine,
                         wamd_align_result* results, uint8_t* cigars, uint32_t cigar_stride);
-/* d_workspace: wamd_align_workspace_bytes(...) bytes of device scratch. */
+/* d_workspace: at least wamd_align_workspace_bytes(...) bytes of device scratch, 256-byte aligned; the
+ * call uses all of what it is given.  The minimum (about 270 B per task at 150 bp) serves batches whose
+ * accepted distances stay below 15 at full speed and the rare wider ones slowly; a caller whose tasks
+ * allow larger distances (the mate rescue with k' = 2 * floor(0.09 m), sam.cpp:190-203; 250 bp reads
+ * at high error rates) asks wamd_align_workspace_bytes_for with its largest max_ed and gets room for
+ * eight resident waves per CU of the wide traceback classes (0.8 GB at 150 bp, whatever n is). */
 WAMD_API int wamd_align_dev(wamd_ctx* ctx, const wamd_reads* reads,
                             const wamd_dist_task* d_tasks, uint32_t n, int last_symbol,
                             int refine, wamd_align_result* d_results, uint8_t* d_cigars,
                             uint32_t cigar_stride, void* d_workspace,
                             uint64_t workspace_bytes, void* stream);
 WAMD_API uint64_t wamd_align_workspace_bytes(const wamd_reads* reads, uint32_t n);
+WAMD_API uint64_t wamd_align_workspace_bytes_for(const wamd_reads* reads, uint32_t n, uint32_t max_ed);
 
 /* ---- long-indel / clipping matcher (sensitive mapping stages) ----------- *
  * Replaces indel_matching_{dir,rc}->Match(...) at mapping_core_sa.cpp:264/317 and

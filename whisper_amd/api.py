@@ -116,7 +116,7 @@ EXPORTS = [
     "wamd_ctx_set_max_text_len", "wamd_ctx_set_distance_mode", "wamd_ctx_set_reference_params", "wamd_ctx_stream",
     "wamd_ctx_synchronize", "wamd_ctx_take_flags", "wamd_reads_upload", "wamd_reads_free",
     "wamd_reads_count", "wamd_verify_distance", "wamd_verify_distance_dev", "wamd_levdiag",
-    "wamd_levdiag_dev", "wamd_cf_filter", "wamd_cf_filter_dev", "wamd_align", "wamd_align_dev", "wamd_align_workspace_bytes",
+    "wamd_levdiag_dev", "wamd_cf_filter", "wamd_cf_filter_dev", "wamd_align", "wamd_align_dev", "wamd_align_workspace_bytes", "wamd_align_workspace_bytes_for",
     "wamd_indel_match", "wamd_indel_match_dev", "wamd_indel_ext_cigar", "wamd_indel_ext_cigar_dev",
     "wamd_clip_boundary", "wamd_clip_boundary_dev", "wamd_clip_illegal", "wamd_clip_illegal_dev",
     "wamd_clip_overlapping_pairs", "wamd_clip_overlapping_pairs_dev", "wamd_softclip_match",
@@ -166,6 +166,7 @@ def lib():
         L.wamd_last_error.restype = C.c_char_p
         L.wamd_ctx_stream.restype = C.c_void_p
         L.wamd_align_workspace_bytes.restype = C.c_uint64
+        L.wamd_align_workspace_bytes_for.restype = C.c_uint64
         L.wamd_reads_count.restype = C.c_uint32
         L.wamd_records_scratch_bytes.restype = C.c_uint64
         L.wamd_finish_workspace_bytes.restype = C.c_uint64
@@ -492,8 +493,10 @@ class Context:
         _check(lib().wamd_indel_match_dev(self.h, reads.h, _ptr(d_tasks), C.c_uint32(n), C.byref(prm),
                                           _ptr(d_results), C.c_void_p(stream or 0)))
 
-    def align_workspace_bytes(self, reads, n):
-        return int(lib().wamd_align_workspace_bytes(reads.h, C.c_uint32(n)))
+    def align_workspace_bytes(self, reads, n, max_ed=None):
+        if max_ed is None:
+            return int(lib().wamd_align_workspace_bytes(reads.h, C.c_uint32(n)))
+        return int(lib().wamd_align_workspace_bytes_for(reads.h, C.c_uint32(n), C.c_uint32(max_ed)))
 
     def align_dev(self, reads, d_tasks, n, d_results, d_cigars, cigar_stride, d_ws, ws_bytes,
                   last_symbol=0, refine=1, stream=None):

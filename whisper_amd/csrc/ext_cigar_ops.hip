@@ -1118,8 +1118,15 @@ __global__ __launch_bounds__(64) void post_passes_kernel(uint32_t n, const wamd_
         __syncthreads();
     }
     if (live) {
-        lens[slot] = sam_cigar_one(ec, ext_stride, cigars + (uint64_t)slot * cigar_stride, cigar_stride,
-                                   mdz + (uint64_t)slot * mdz_stride, mdz_stride, nullptr, 0, flags);
+        wamd_sam_cigar_len l = sam_cigar_one(ec, ext_stride, cigars + (uint64_t)slot * cigar_stride, cigar_stride,
+                                             mdz + (uint64_t)slot * mdz_stride, mdz_stride, nullptr, 0, flags);
+        // the length of the ext-CIGAR as the passes left it, + 2 (0 / 1 = not measured), for the caller's bookkeeping:
+        // here it costs LDS reads, from the slots in memory a line fetch per lane and byte
+        uint32_t el = 0;
+        while (el < ext_stride && ec[el])
+            ++el;
+        l.reserved = el + 2;
+        lens[slot] = l;
         records[slot] = d;
     }
     __syncthreads();

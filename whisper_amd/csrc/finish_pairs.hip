@@ -244,10 +244,15 @@ __global__ __launch_bounds__(256) void finish_final_kernel(ReadsView rv, const w
     o.err_edit_distance = r.err_edit_distance;
     o.left_clipping = r.left_clipping;
     o.right_clipping = r.right_clipping;
-    const uint8_t* e = ext + (uint64_t)i * ext_stride;
-    uint32_t el = 0;
-    while (el < ext_stride && e[el])
-        ++el;
+    uint32_t el = lens[i].reserved;   // the fused post-passes measured it on their LDS copy
+    if (el >= 2) {
+        el -= 2;
+    } else {
+        el = 0;
+        const uint8_t* e = ext + (uint64_t)i * ext_stride;
+        while (el < ext_stride && e[el])
+            ++el;
+    }
     o.ext_cigar_len = el;
     if (o.method == WAMD_METHOD_PERFECT || o.method == WAMD_METHOD_PERFECT_DISTANT) {
         // perfect_cigar / perfect_mdz (sam.cpp:1504-1515): a perfect match keeps them even when a clipping

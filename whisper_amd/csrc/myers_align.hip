@@ -1086,7 +1086,7 @@ struct AlignLayout {
     uint64_t per_block[4];           // per class: bytes of one block's slot
 };
 
-static AlignLayout align_layout(const wamd_reads* r, uint32_t n)
+static AlignLayout align_layout(const wamd_reads* r, uint32_t n, bool wide_class)
 {
     AlignLayout L{};
     const uint32_t nw = r->words ? r->words : 1;
@@ -1115,11 +1115,11 @@ static AlignLayout align_layout(const wamd_reads* r, uint32_t n)
     if (L.blocks == 0)
         L.blocks = 1;
     // the region serves the classes one after the other: all blocks of the banded class, and blocks of the
-    // 64-row class (ed 15 .. 30) - 2048 of them (eight waves per CU) where such distances are the workload
-    // (reads above 160 symbols: the 250 bp high-error configuration), 256 (one wave per CU) for Illumina 150 bp
-    // reads, where they are stragglers: what a task then costs the caller is about 200 B instead of 840 B
+    // 64-row class (ed 15 .. 30) - 2048 of them (eight waves per CU) where the caller expects such distances
+    // (wamd_align_workspace_bytes_for with max_ed >= 15: the mate rescue, the 250 bp high-error configuration),
+    // else 256 (one wave per CU: stragglers).  The launcher uses whatever the caller gives beyond the minimum.
     uint64_t region = (uint64_t)L.blocks * per_block[0];
-    const uint32_t wide_blocks = m > 160 ? 2048u : 256u;
+    const uint32_t wide_blocks = wide_class ? 2048u : 256u;
     const uint64_t wide = (uint64_t)(need_blocks < wide_blocks ? (need_blocks ? need_blocks : 1u) : wide_blocks) * per_block[1];
     region = region < wide ? wide : region;
     if (region < L.slot_bytes_max)
@@ -1134,7 +1134,10 @@ static AlignLayout align_layout(const wamd_reads* r, uint32_t n)
     return L;
 }
 
-uint64_t align_workspace_bytes(const wamd_reads* r, uint32_t n) { return align_layout(r, n).total; }
+uint64_t align_workspace_bytes(const wamd_reads* r, uint32_t n, uint32_t max_ed)
+{
+    return align_layout(r, n, max_ed >= 15).total;
+}
 
 template <int NW, int WW, int BLOCK>
 static int launch_tb(const GenomeView& g, const ReadsView& rv, AlignParams ap, uint32_t blocks, uint32_t groups,
@@ -1174,7 +1177,7 @@ int launch_align(wamd_ctx* ctx, const wamd_reads* r, const wamd_dist_task* d_tas
         set_error("wamd_align: cigar_stride must be a multiple of 4, buffers aligned (cigars 4, workspace 256)");
         return WAMD_ERR_INVALID_ARG;
     }
-    const AlignLayout L = align_layout(r, n);
+    const AlignLayout L = align_layout(r, n, false);
     if (ws_bytes < L.total)
         return WAMD_ERR_INVALID_ARG;
     char* ws = (char*)d_ws;
@@ -1182,7 +1185,7 @@ int launch_align(wamd_ctx* ctx, const wamd_reads* r, const wamd_dist_task* d_tas
     auto* d_lists = (uint32_t*)(ws + L.lists_off);
     auto* d_counters = (uint32_t*)(ws + L.counters_off);
     auto* d_slots = (uint64_t*)(ws + L.slots_off);
-    const uint64_t region = L.total - L.slots_off;
+    const uint64_t region = (ws_bytes & ~255ull) - L.slots_off;   // everything the caller gave
 
     WAMD_HIP(hipMemsetAsync(d_counters, 0, 256, s));
     int rc = ensure_pm(r, s);   // the wide classes read the 64-bit vectors

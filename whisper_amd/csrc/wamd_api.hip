@@ -586,6 +586,11 @@ uint64_t wamd_align_workspace_bytes(const wamd_reads* reads, uint32_t n)
     return reads ? align_workspace_bytes(reads, n) : 0;
 }
 
+uint64_t wamd_align_workspace_bytes_for(const wamd_reads* reads, uint32_t n, uint32_t max_ed)
+{
+    return reads ? align_workspace_bytes(reads, n, max_ed) : 0;
+}
+
 int wamd_align_dev(wamd_ctx* ctx, const wamd_reads* reads, const wamd_dist_task* d_tasks, uint32_t n,
                    int last_symbol, int refine, wamd_align_result* d_results, uint8_t* d_cigars,
                    uint32_t cigar_stride, void* d_workspace, uint64_t workspace_bytes, void* stream)
@@ -621,7 +626,10 @@ int wamd_align(wamd_ctx* ctx, const wamd_reads* reads, const wamd_dist_task* tas
     const uint64_t tb = (uint64_t)n * sizeof(wamd_dist_task);
     const uint64_t rb = (uint64_t)n * sizeof(wamd_align_result);
     const uint64_t cb = (uint64_t)n * cigar_stride;
-    const uint64_t wb = align_workspace_bytes(reads, n);
+    uint32_t max_ed = 0;   // the host form sees the tasks: room for the wide classes when they can occur
+    for (uint32_t i = 0; i < n; ++i)
+        max_ed = tasks[i].max_ed > max_ed ? tasks[i].max_ed : max_ed;
+    const uint64_t wb = align_workspace_bytes(reads, n, max_ed);
     auto up = [](uint64_t x) { return (x + 255) / 256 * 256; };
     rc = ensure_stage(ctx, up(tb) + up(rb) + up(cb) + up(wb), 0);
     if (rc)
