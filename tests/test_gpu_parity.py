@@ -1,6 +1,8 @@
 """HIP path (through the C-ABI) vs the oracle on seeded tasks.  Bit-exact bar for edit
 distances, positions, CIGARs, events; affine scores are sums of the same doubles in the
 same order, so they are compared for equality as well (north_star allows 1e-5)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -502,6 +504,15 @@ def test_finish_pairs_chain(ctx, oracle, seed, m, flank):
         rc, *want = oracle.finish_pairs(packed, blob, off, lens, tasks[:600], ob.FinishParams(flank, *sw), ext_stride=768)
         got = ctx.finish_pairs(reads, tasks[:600], api.FinishParams(flank, *sw), ext_stride=768)
         common.same_finish_output(got, want)
+    # the fused passes without the per-slot length hints: every wave serves its slots in two halves at the full stride
+    # (what it also does when the packed strings of a wave do not fit its LDS)
+    rc, *want = oracle.finish_pairs(packed, blob, off, lens, tasks, ob.default_finish_params(flank), ext_stride=768)
+    os.environ["WAMD_POST_NO_HINTS"] = "1"
+    try:
+        got = ctx.finish_pairs(reads, tasks, api.default_finish_params(flank), ext_stride=768)
+    finally:
+        del os.environ["WAMD_POST_NO_HINTS"]
+    common.same_finish_output(got, want)
     reads.free()
 
 

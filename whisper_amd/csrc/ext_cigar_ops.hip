@@ -7,6 +7,8 @@
 // ext-CIGARs produced by the align kernels need not travel to the host and back.
 #include <mutex>
 
+#include <stdlib.h>
+
 #include "wamd_internal.h"
 
 namespace wamd {
@@ -1069,7 +1071,8 @@ __global__ __launch_bounds__(256) void sam_cigar_kernel(uint32_t n, const uint8_
 __global__ __launch_bounds__(64) void post_passes_kernel(uint32_t n, const wamd_clip_illegal_task* __restrict__ it,
                                                          const wamd_clip_pair_task* __restrict__ pt,
                                                          wamd_clip_record* __restrict__ records, uint8_t* __restrict__ ext,
-                                                         uint32_t ext_stride, uint32_t lds_dw, wamd_scoring sc,
+                                                         uint32_t ext_stride, const uint32_t* __restrict__ cap_hint,
+                                                         uint32_t budget_dw, wamd_scoring sc,
                                                          int do_boundary, int do_pairs, uint8_t* __restrict__ cigars,
                                                          uint32_t cigar_stride, uint8_t* __restrict__ mdz,
                                                          uint32_t mdz_stride, wamd_sam_cigar_len* __restrict__ lens,
@@ -1079,74 +1082,131 @@ __global__ __launch_bounds__(64) void post_passes_kernel(uint32_t n, const wamd_
     const uint32_t lane = threadIdx.x;
     const uint32_t base = blockIdx.x * 64;
     const uint32_t here = n - base < 64u ? n - base : 64u;   // slots of this wave (n is even: pairs stay together)
-    const uint32_t dw = ext_stride / 4;
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(ext + (uint64_t)base * ext_stride);
-    for (uint32_t i = lane; i < here * dw; i += 64)
-        post_lds[(i / dw) * lds_dw + i % dw] = src[i];
-    __syncthreads();
     const uint32_t slot = base + lane;
     const bool live = lane < here;
-    uint8_t* ec = reinterpret_cast<uint8_t*>(post_lds + lane * lds_dw);
-    wamd_clip_record d{};
+    const uint32_t full_dw = (ext_stride / 4) | 1u;   // odd: lanes at the same offset of their strings hit different banks
+    // What a lane's string needs.  A caller that knows how long the strings are (and can get: a clipping pass never
+    // lengthens one, a perfect match may receive read_length dots) says so per slot, and the wave packs its strings:
+    // the LDS of a wave, not its registers, is what limits the waves per CU here.  Both strings of a pair get the
+    // room of the longer one (the pair routine takes one capacity).  Without hints, or when the packed strings
+    // do not fit the budget, the wave serves its 32 even / odd pairs in two halves at the full stride.
+    uint32_t my_dw = 0;
     if (live) {
-        d = records[slot];
-        clip_illegal_one(d, it[slot], ec, ext_stride, sc, flags);
-        if (do_boundary)
-            clip_boundary_one(d, ec, ext_stride, sc);
+        my_dw = full_dw;
+        if (cap_hint) {
+            const uint32_t c = cap_hint[slot] < ext_stride ? cap_hint[slot] : ext_stride;
+            my_dw = ((c + 3) / 4) | 1u;
+            my_dw = my_dw > full_dw ? full_dw : my_dw;
+        }
     }
-    __syncthreads();   // every lane's string is as its own passes left it before a partner touches it
-    if (do_pairs) {
-        // the even lane of a pair takes its partner's record, clips both strings, hands the record back
-        uint32_t w[8], v[8];
-        memcpy(w, &d, 32);
+    {
+        const uint32_t other = (uint32_t)__shfl_xor((int)my_dw, 1);
+        my_dw = my_dw > other ? my_dw : (live ? other : 0u);
+    }
+    uint32_t incl = my_dw;
 #pragma unroll
-        for (int q = 0; q < 8; ++q)
-            v[q] = (uint32_t)__shfl_down((int)w[q], 1);
-        wamd_clip_record rec[2];
-        rec[0] = d;
-        memcpy(&rec[1], v, 32);
-        if (live && !(lane & 1u) && lane + 1 < here)
-            clip_pair_one(pt[slot >> 1], rec, ec, ec + 4 * lds_dw, ext_stride, flags);
-        memcpy(w, &rec[1], 32);
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
+        if (lane >= (uint32_t)d)
+            incl += o;
+    }
+    const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+    const int halves = total <= budget_dw ? 1 : 2;
+    for (int h = 0; h < halves; ++h) {
+        // lanes of this pass, where their strings start and how many dwords they hold
+        const bool mine = halves == 1 || (lane >> 5) == (uint32_t)h;
+        uint32_t ndw = mine ? my_dw : 0u, off = incl - my_dw;
+        if (halves == 2) {
+            ndw = (mine && live) ? full_dw : 0u;
+            off = (lane & 31u) * full_dw;
+        }
+        const uint32_t cap = ndw * 4 < ext_stride ? ndw * 4 : ext_stride;   // bytes of the string the routines may use
+        for (uint32_t sl = 0; sl < here; ++sl) {   // coalesced: the wave copies one string after the other
+            const uint32_t n_s = (uint32_t)__builtin_amdgcn_readlane((int)ndw, (int)sl);
+            if (!n_s)
+                continue;
+            const uint32_t o_s = (uint32_t)__builtin_amdgcn_readlane((int)off, (int)sl);
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(ext + (uint64_t)(base + sl) * ext_stride);
+            const uint32_t lim = n_s < ext_stride / 4 ? n_s : ext_stride / 4;
+            for (uint32_t i = lane; i < lim; i += 64)
+                post_lds[o_s + i] = src[i];
+        }
+        __syncthreads();
+        const bool act = live && mine;
+        uint8_t* ec = reinterpret_cast<uint8_t*>(post_lds + off);
+        wamd_clip_record d{};
+        if (act) {
+            d = records[slot];
+            clip_illegal_one(d, it[slot], ec, cap, sc, flags);
+            if (do_boundary)
+                clip_boundary_one(d, ec, cap, sc);
+        }
+        __syncthreads();   // every lane's string is as its own passes left it before a partner touches it
+        if (do_pairs) {
+            // the even lane of a pair takes its partner's record, clips both strings, hands the record back
+            uint32_t w[8], v[8];
+            memcpy(w, &d, 32);
 #pragma unroll
-        for (int q = 0; q < 8; ++q)
-            v[q] = (uint32_t)__shfl_up((int)w[q], 1);
-        if (lane & 1u)
-            memcpy(&d, v, 32);
-        else
-            d = rec[0];
+            for (int q = 0; q < 8; ++q)
+                v[q] = (uint32_t)__shfl_down((int)w[q], 1);
+            const uint32_t off1 = (uint32_t)__shfl_down((int)off, 1);
+            wamd_clip_record rec[2];
+            rec[0] = d;
+            memcpy(&rec[1], v, 32);
+            if (act && !(lane & 1u) && lane + 1 < here)
+                clip_pair_one(pt[slot >> 1], rec, ec, reinterpret_cast<uint8_t*>(post_lds + off1), cap, flags);
+            memcpy(w, &rec[1], 32);
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                v[q] = (uint32_t)__shfl_up((int)w[q], 1);
+            if (lane & 1u)
+                memcpy(&d, v, 32);
+            else
+                d = rec[0];
+            __syncthreads();
+        }
+        if (act) {
+            wamd_sam_cigar_len l = sam_cigar_one(ec, cap, cigars + (uint64_t)slot * cigar_stride, cigar_stride,
+                                                 mdz + (uint64_t)slot * mdz_stride, mdz_stride, nullptr, 0, flags);
+            // the length of the ext-CIGAR as the passes left it, + 2 (0 / 1 = not measured), for the caller's bookkeeping:
+            // here it costs LDS reads, from the slots in memory a line fetch per lane and byte
+            uint32_t el = 0;
+            while (el < cap && ec[el])
+                ++el;
+            l.reserved = el + 2;
+            lens[slot] = l;
+            records[slot] = d;
+        }
+        __syncthreads();
+        for (uint32_t sl = 0; sl < here; ++sl) {
+            const uint32_t n_s = (uint32_t)__builtin_amdgcn_readlane((int)ndw, (int)sl);
+            if (!n_s)
+                continue;
+            const uint32_t o_s = (uint32_t)__builtin_amdgcn_readlane((int)off, (int)sl);
+            uint32_t* dst = reinterpret_cast<uint32_t*>(ext + (uint64_t)(base + sl) * ext_stride);
+            const uint32_t lim = n_s < ext_stride / 4 ? n_s : ext_stride / 4;
+            for (uint32_t i = lane; i < lim; i += 64)
+                dst[i] = post_lds[o_s + i];
+        }
         __syncthreads();
     }
-    if (live) {
-        wamd_sam_cigar_len l = sam_cigar_one(ec, ext_stride, cigars + (uint64_t)slot * cigar_stride, cigar_stride,
-                                             mdz + (uint64_t)slot * mdz_stride, mdz_stride, nullptr, 0, flags);
-        // the length of the ext-CIGAR as the passes left it, + 2 (0 / 1 = not measured), for the caller's bookkeeping:
-        // here it costs LDS reads, from the slots in memory a line fetch per lane and byte
-        uint32_t el = 0;
-        while (el < ext_stride && ec[el])
-            ++el;
-        l.reserved = el + 2;
-        lens[slot] = l;
-        records[slot] = d;
-    }
-    __syncthreads();
-    uint32_t* dst = reinterpret_cast<uint32_t*>(ext + (uint64_t)base * ext_stride);
-    for (uint32_t i = lane; i < here * dw; i += 64)
-        dst[i] = post_lds[(i / dw) * lds_dw + i % dw];
 }
 
-// the fused form when the slots fit LDS (64 KB per wave: ext_stride up to 1000), else the four kernels in turn
+// the fused form when half a wave's slots fit LDS (64 KB: ext_stride up to 2000), else the four kernels in turn
 int launch_post_passes(wamd_ctx* ctx, uint32_t n, const wamd_clip_illegal_task* d_it, const wamd_clip_pair_task* d_pt,
-                       wamd_clip_record* d_rec, uint8_t* d_ext, uint32_t ext_stride, int do_boundary, int do_pairs,
-                       uint8_t* d_cigars, uint32_t cigar_stride, uint8_t* d_mdz, uint32_t mdz_stride,
-                       wamd_sam_cigar_len* d_lens, hipStream_t s)
+                       wamd_clip_record* d_rec, uint8_t* d_ext, uint32_t ext_stride, const uint32_t* d_cap_hint,
+                       int do_boundary, int do_pairs, uint8_t* d_cigars, uint32_t cigar_stride, uint8_t* d_mdz,
+                       uint32_t mdz_stride, wamd_sam_cigar_len* d_lens, hipStream_t s)
 {
     WAMD_HIP(hipSetDevice(ctx->device));
-    if ((ext_stride & 3u) == 0 && ext_stride <= 1000 && ((uintptr_t)d_ext & 3u) == 0 && (n & 1u) == 0) {
-        const uint32_t lds_dw = (ext_stride / 4) | 1u;   // odd: conflict-free per-lane strings
-        hipLaunchKernelGGL(post_passes_kernel, dim3((n + 63) / 64), dim3(64), (size_t)64 * lds_dw * 4, s, n, d_it, d_pt,
-                           d_rec, d_ext, ext_stride, lds_dw, ctx->scoring, do_boundary, do_pairs, d_cigars, cigar_stride,
-                           d_mdz, mdz_stride, d_lens, ctx->d_flags);
+    if (getenv("WAMD_POST_NO_HINTS"))   // test hook: the two-halves path of every wave
+        d_cap_hint = nullptr;
+    if ((ext_stride & 3u) == 0 && ext_stride <= 2000 && ((uintptr_t)d_ext & 3u) == 0 && (n & 1u) == 0) {
+        // LDS of a wave: 32 strings at the full (odd) stride - what a half needs when the strings are not packed
+        const uint32_t budget_dw = 32u * ((ext_stride / 4) | 1u);
+        hipLaunchKernelGGL(post_passes_kernel, dim3((n + 63) / 64), dim3(64), (size_t)budget_dw * 4, s, n, d_it, d_pt,
+                           d_rec, d_ext, ext_stride, d_cap_hint, budget_dw, ctx->scoring, do_boundary, do_pairs, d_cigars,
+                           cigar_stride, d_mdz, mdz_stride, d_lens, ctx->d_flags);
         WAMD_HIP(hipGetLastError());
         return WAMD_OK;
     }

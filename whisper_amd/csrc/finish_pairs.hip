@@ -29,6 +29,7 @@ struct FinishWs {
     wamd_clip_illegal_task* it;
     wamd_clip_pair_task* pt;
     wamd_sam_cigar_len* lens;
+    uint32_t* cap;   // per slot: bytes its ext-CIGAR can need in the post-passes (their LDS packing)
     void* align_ws;
     uint64_t align_ws_bytes;
     uint64_t total;
@@ -54,6 +55,7 @@ static FinishWs finish_layout(const wamd_reads* r, uint32_t n_pairs, char* base)
     w.it = (wamd_clip_illegal_task*)take(n * sizeof(wamd_clip_illegal_task));
     w.pt = (wamd_clip_pair_task*)take((uint64_t)n_pairs * sizeof(wamd_clip_pair_task));
     w.lens = (wamd_sam_cigar_len*)take(n * sizeof(wamd_sam_cigar_len));
+    w.cap = (uint32_t*)take(n * sizeof(uint32_t));
     w.align_ws = base + off;
     w.align_ws_bytes = align_workspace_bytes(r, (uint32_t)n);
     w.total = off + w.align_ws_bytes;
@@ -130,7 +132,8 @@ __global__ __launch_bounds__(256) void finish_merge_kernel(ReadsView rv, const w
                                                            wamd_clip_illegal_task* __restrict__ it,
                                                            wamd_clip_pair_task* __restrict__ pt,
                                                            wamd_finish_result* __restrict__ results,
-                                                           uint8_t* __restrict__ ext, uint32_t ext_stride)
+                                                           uint8_t* __restrict__ ext, uint32_t ext_stride,
+                                                           uint32_t* __restrict__ cap)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
@@ -192,6 +195,10 @@ __global__ __launch_bounds__(256) void finish_merge_kernel(ReadsView rv, const w
     rec[i] = r;
     it[i] = ti;
     results[i] = o;
+    {   // what the slot's string can grow to: itself (clipping never lengthens it) or read_length dots, NUL, slack
+        const uint32_t len = !ok ? 0u : (kind == FK_LEV ? a.cigar_len : (kind == FK_PERFECT ? 0u : c.cigar_len));
+        cap[i] = (len > m ? len : m) + 1 + 8;
+    }
     if ((i & 1u) == 0) {   // clipOverlappingPairs' view of the pair, soft_clipping.cpp:997-1044
         wamd_clip_pair_task p{};
         const uint32_t km = finish_kind(tm, rv);
@@ -302,9 +309,9 @@ int launch_finish_pairs(wamd_ctx* ctx, const wamd_reads* r, const wamd_finish_ta
     if (rc)
         return rc;
     hipLaunchKernelGGL(finish_merge_kernel, dim3(blocks), dim3(256), 0, s, rv, d_tasks, n, prm->flank,
-                       ctx->scoring.match, w.ar, w.cr, w.rec, w.it, w.pt, d_results, d_ext, ext_stride);
+                       ctx->scoring.match, w.ar, w.cr, w.rec, w.it, w.pt, d_results, d_ext, ext_stride, w.cap);
     WAMD_HIP(hipGetLastError());
-    rc = launch_post_passes(ctx, n, w.it, w.pt, w.rec, d_ext, ext_stride, prm->enable_boundary_clipping != 0,
+    rc = launch_post_passes(ctx, n, w.it, w.pt, w.rec, d_ext, ext_stride, w.cap, prm->enable_boundary_clipping != 0,
                             prm->enable_paired_clipping != 0, d_cigars, cigar_stride, d_mdz, mdz_stride, w.lens, s);
     if (rc)
         return rc;

@@ -159,9 +159,9 @@ int launch_serialize(wamd_ctx* ctx, uint32_t n, const wamd_mapping* d_mappings, 
                      uint8_t* d_out, uint8_t* d_sizes, hipStream_t s);
 
 int launch_post_passes(wamd_ctx* ctx, uint32_t n, const wamd_clip_illegal_task* d_it, const wamd_clip_pair_task* d_pt,
-                       wamd_clip_record* d_rec, uint8_t* d_ext, uint32_t ext_stride, int do_boundary, int do_pairs,
-                       uint8_t* d_cigars, uint32_t cigar_stride, uint8_t* d_mdz, uint32_t mdz_stride,
-                       wamd_sam_cigar_len* d_lens, hipStream_t s);
+                       wamd_clip_record* d_rec, uint8_t* d_ext, uint32_t ext_stride, const uint32_t* d_cap_hint,
+                       int do_boundary, int do_pairs, uint8_t* d_cigars, uint32_t cigar_stride, uint8_t* d_mdz,
+                       uint32_t mdz_stride, wamd_sam_cigar_len* d_lens, hipStream_t s);
 
 int launch_cf_filter(wamd_ctx* ctx, const wamd_reads* r, const wamd_cf_task* d_tasks, uint32_t n,
                      uint32_t* d_results, hipStream_t s);
