@@ -16,6 +16,7 @@ stream the kernel runs on; `cpu_baseline` times the reference's own AVX2 verifie
 (kind "port") on a bounded sample of the same tasks on this box's host cores.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -247,19 +248,26 @@ def run_extras(ctx, device, genome_symbols, stream, n_small):
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
         if tag:
             mark(tag, True, stream, device, reps, units)
-        for a, b in evs:
-            if prep:
-                prep()
-            a.record(stream)
-            fn()
-            b.record(stream)
+        # (a collection of Python's garbage between an event and the launch behind it once put 36 ms of host stall
+        #  into a 2.7 ms kernel's bracket: collect before, not during; and report the median bracket)
+        gc.collect()
+        gc.disable()
+        try:
+            for a, b in evs:
+                if prep:
+                    prep()
+                a.record(stream)
+                fn()
+                b.record(stream)
+        finally:
+            gc.enable()
         if tag:
             mark(tag, False, stream, device)
         ctx.synchronize()
         f = ctx.take_flags()
         if f:
             raise SystemExit("device error flags 0x%x in extras" % f)
-        return float(np.mean([a.elapsed_time(b) for a, b in evs]))
+        return float(np.median([a.elapsed_time(b) for a, b in evs]))
 
     def host(rd_codes, enc):
         blob, off, lens = synth.pack_reads(rd_codes, enc)
@@ -569,9 +577,12 @@ def run_extras(ctx, device, genome_symbols, stream, n_small):
             units = e.get("tasks") or e.get("records") or e.get("pairs")
             if "hbm_bytes_per_unit" in m_:
                 e["roofline"]["traffic"] = m_["hbm_bytes_per_unit"] * units
-            if "valu_insts_per_unit" in m_ and e["roofline"]["bound"] == "valu":
+            if "valu_insts_per_unit" in m_:   # issued VALU lane-ops (wave instructions x 64) against the VALU peak
                 e["roofline"]["measured_valu_frac"] = (m_["valu_insts_per_unit"] * units /
                                                        (e.get("kernel_ms", e.get("total_ms")) * 1e-3) / PEAK_VALU_LANEOPS)
+            for k_ in ("sq_wait_any_frac", "sq_wait_inst_any_frac", "sq_active_inst_any_frac"):
+                if k_ in m_:
+                    e["roofline"][k_] = m_[k_]
     return out
 
 
@@ -753,6 +764,8 @@ def main():
            for _ in range(args.steps)]
     main_tag = "S1_exact" if args.distance_mode == "exact" else "S1_accepted_only"
     mark(main_tag, True, stream, device, args.steps, n)   # (no-ops unless --profile-markers; never in a judged run)
+    gc.collect()
+    gc.disable()   # no collection pause inside the timed steps
     t0 = time.perf_counter()
     for a, b in evs:
         # (in the multi-rank path the bracket also holds the wait for the buffer's last reader)
@@ -768,6 +781,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    gc.enable()
     if dist:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
