@@ -89,10 +89,30 @@ __global__ __launch_bounds__(256) void indel_ext_cigar_kernel(const uint8_t* __r
     }
     const uint8_t* codes = rv.codes + rv.code_off[t.read_idx];
     const bool rev = t.flags & WAMD_TASK_FLAG_REV_COMP;
-    auto Q = [&](uint32_t i) -> uint32_t {
-        return rev ? rc_code_indel2(packed_symbol(codes, m - 1 - i)) : packed_symbol(codes, i);
+    // Both sequences are walked symbol by symbol; a byte load per symbol is a line fetch per lane and symbol
+    // (24 KB of line traffic per record), so each keeps the dword it is in (eight symbols, either direction).
+    // Genome and code buffers are 4-byte aligned and padded to whole dwords.
+    const uint32_t* codes_dw = reinterpret_cast<const uint32_t*>(codes);
+    const uint32_t* genome_dw = reinterpret_cast<const uint32_t*>(genome);
+    uint32_t q_at = 0xffffffffu, q_dw = 0;
+    uint64_t g_at = ~0ull;
+    uint32_t g_dw = 0;
+    auto Qraw = [&](uint32_t i) -> uint32_t {
+        if ((i >> 3) != q_at) {
+            q_at = i >> 3;
+            q_dw = nibble_swap(codes_dw[q_at]);
+        }
+        return (q_dw >> (4 * (i & 7u))) & 15u;
     };
-    auto G = [&](uint32_t i) -> uint32_t { return packed_symbol(genome, (uint64_t)t.examined_start_pos + i); };
+    auto Q = [&](uint32_t i) -> uint32_t { return rev ? rc_code_indel2(Qraw(m - 1 - i)) : Qraw(i); };
+    auto G = [&](uint32_t i) -> uint32_t {
+        const uint64_t p = (uint64_t)t.examined_start_pos + i;
+        if ((p >> 3) != g_at) {
+            g_at = p >> 3;
+            g_dw = nibble_swap(genome_dw[g_at]);
+        }
+        return (g_dw >> (4 * ((uint32_t)p & 7u))) & 15u;
+    };
 
     CigarWriter w{slot, 0, 0};
     uint32_t i_genome = 0, i_query = 0;
@@ -912,36 +932,6 @@ int launch_indel_ext_cigar(wamd_ctx* ctx, const wamd_reads* r, const wamd_indel_
     return WAMD_OK;
 }
 
-int launch_clip_boundary(wamd_ctx* ctx, uint32_t n, wamd_clip_record* d_records, uint8_t* d_cigars,
-                         uint32_t cigar_stride, hipStream_t s)
-{
-    WAMD_HIP(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(clip_boundary_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_records, d_cigars,
-                       cigar_stride, ctx->scoring);
-    WAMD_HIP(hipGetLastError());
-    return WAMD_OK;
-}
-
-int launch_clip_illegal(wamd_ctx* ctx, uint32_t n, const wamd_clip_illegal_task* d_tasks, wamd_clip_record* d_records,
-                        uint8_t* d_cigars, uint32_t cigar_stride, hipStream_t s)
-{
-    WAMD_HIP(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(clip_illegal_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_tasks, d_records, d_cigars,
-                       cigar_stride, ctx->scoring, ctx->d_flags);
-    WAMD_HIP(hipGetLastError());
-    return WAMD_OK;
-}
-
-int launch_clip_pairs(wamd_ctx* ctx, uint32_t n_pairs, const wamd_clip_pair_task* d_tasks, wamd_clip_record* d_records,
-                      uint8_t* d_cigars, uint32_t cigar_stride, hipStream_t s)
-{
-    WAMD_HIP(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(clip_pairs_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, s, n_pairs, d_tasks, d_records,
-                       d_cigars, cigar_stride, ctx->d_flags);
-    WAMD_HIP(hipGetLastError());
-    return WAMD_OK;
-}
-
 // ---- ext-CIGAR -> SAM CIGAR text, BAM operations, MD:Z (row X) ------------------------------
 // CSamGenerator::extract_cigar_and_mdz / extract_cigarbin_and_mdz (sam.cpp:805-928, 932-1051):
 // one state machine over the ext-CIGAR bytes; an operation is flushed when the state changes,
@@ -1192,6 +1182,123 @@ __global__ __launch_bounds__(64) void post_passes_kernel(uint32_t n, const wamd_
     }
 }
 
+// ---- rows L, B, X one at a time, on an LDS copy as well ------------------------------------------------
+// The stand-alone entry points of these rows used to run their byte loops on the slots in HBM: every byte a lane
+// touches is its own cache line there, and lines do not survive in L1 between a lane's accesses - 8 to 37 KB of
+// line traffic per 150-byte string.  Same device functions, same bytes; the wave serves its 64 slots in two halves
+// of 32 at the full stride (no length hints at these entry points).
+template <int MODE>   // 0 clipIllegalPositions, 1 clipBoundaryPositions, 2 clipOverlappingPairs, 3 extract_cigar_and_mdz
+__global__ __launch_bounds__(64) void staged_row_kernel(uint32_t n, const wamd_clip_illegal_task* __restrict__ it,
+                                                        const wamd_clip_pair_task* __restrict__ pt,
+                                                        wamd_clip_record* __restrict__ records, uint8_t* __restrict__ ext,
+                                                        uint32_t ext_stride, wamd_scoring sc, uint8_t* __restrict__ cigars,
+                                                        uint32_t cigar_stride, uint8_t* __restrict__ mdz, uint32_t mdz_stride,
+                                                        uint32_t* __restrict__ cigar_bin, uint32_t bin_stride,
+                                                        wamd_sam_cigar_len* __restrict__ lens, uint32_t* __restrict__ flags)
+{
+    extern __shared__ uint32_t row_lds[];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t base = blockIdx.x * 64;
+    const uint32_t here = n - base < 64u ? n - base : 64u;
+    const uint32_t dw = ext_stride / 4, full_dw = dw | 1u;
+    for (uint32_t h = 0; h < 2 && 32 * h < here; ++h) {
+        const uint32_t first = 32 * h;
+        const uint32_t cnt = here - first < 32u ? here - first : 32u;
+        uint32_t* g = reinterpret_cast<uint32_t*>(ext + (uint64_t)(base + first) * ext_stride);
+        for (uint32_t i = lane; i < cnt * dw; i += 64)
+            row_lds[(i / dw) * full_dw + i % dw] = g[i];
+        __syncthreads();
+        const bool act = (lane >> 5) == h && lane < here;
+        const uint32_t slot = base + lane;
+        uint8_t* ec = reinterpret_cast<uint8_t*>(row_lds + (lane & 31u) * full_dw);
+        if (MODE == 0 && act) {
+            wamd_clip_record d = records[slot];
+            clip_illegal_one(d, it[slot], ec, ext_stride, sc, flags);
+            records[slot] = d;
+        }
+        if (MODE == 1 && act) {
+            wamd_clip_record d = records[slot];
+            clip_boundary_one(d, ec, ext_stride, sc);
+            records[slot] = d;
+        }
+        if (MODE == 2 && act && !(lane & 1u) && lane + 1 < here) {
+            wamd_clip_record rec[2] = {records[slot], records[slot + 1]};
+            clip_pair_one(pt[slot >> 1], rec, ec, ec + 4 * full_dw, ext_stride, flags);
+            records[slot] = rec[0];
+            records[slot + 1] = rec[1];
+        }
+        if (MODE == 3 && act)
+            lens[slot] = sam_cigar_one(ec, ext_stride, cigars + (uint64_t)slot * cigar_stride, cigar_stride,
+                                       mdz + (uint64_t)slot * mdz_stride, mdz_stride,
+                                       cigar_bin ? cigar_bin + (uint64_t)slot * bin_stride : nullptr, bin_stride, flags);
+        __syncthreads();
+        if (MODE != 3) {
+            for (uint32_t i = lane; i < cnt * dw; i += 64)
+                g[i] = row_lds[(i / dw) * full_dw + i % dw];
+            __syncthreads();
+        }
+    }
+}
+
+static bool rows_can_stage(const void* slots, uint32_t stride)
+{
+    return (stride & 3u) == 0 && stride >= 4 && stride <= 2000 && ((uintptr_t)slots & 3u) == 0;
+}
+
+template <int MODE>
+static int launch_staged_row(wamd_ctx* ctx, uint32_t n, const wamd_clip_illegal_task* it, const wamd_clip_pair_task* pt,
+                             wamd_clip_record* rec, uint8_t* ext, uint32_t ext_stride, uint8_t* cigars, uint32_t cigar_stride,
+                             uint8_t* mdz, uint32_t mdz_stride, uint32_t* bin, uint32_t bin_stride, wamd_sam_cigar_len* lens,
+                             hipStream_t s)
+{
+    if (n == 0)
+        return WAMD_OK;
+    const size_t lds = (size_t)32 * ((ext_stride / 4) | 1u) * 4;
+    hipLaunchKernelGGL(staged_row_kernel<MODE>, dim3((n + 63) / 64), dim3(64), lds, s, n, it, pt, rec, ext, ext_stride,
+                       ctx->scoring, cigars, cigar_stride, mdz, mdz_stride, bin, bin_stride, lens, ctx->d_flags);
+    WAMD_HIP(hipGetLastError());
+    return WAMD_OK;
+}
+
+int launch_clip_boundary(wamd_ctx* ctx, uint32_t n, wamd_clip_record* d_records, uint8_t* d_cigars,
+                         uint32_t cigar_stride, hipStream_t s)
+{
+    WAMD_HIP(hipSetDevice(ctx->device));
+    if (rows_can_stage(d_cigars, cigar_stride))
+        return launch_staged_row<1>(ctx, n, nullptr, nullptr, d_records, d_cigars, cigar_stride, nullptr, 0, nullptr, 0,
+                                    nullptr, 0, nullptr, s);
+    hipLaunchKernelGGL(clip_boundary_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_records, d_cigars,
+                       cigar_stride, ctx->scoring);
+    WAMD_HIP(hipGetLastError());
+    return WAMD_OK;
+}
+
+int launch_clip_illegal(wamd_ctx* ctx, uint32_t n, const wamd_clip_illegal_task* d_tasks, wamd_clip_record* d_records,
+                        uint8_t* d_cigars, uint32_t cigar_stride, hipStream_t s)
+{
+    WAMD_HIP(hipSetDevice(ctx->device));
+    if (rows_can_stage(d_cigars, cigar_stride))
+        return launch_staged_row<0>(ctx, n, d_tasks, nullptr, d_records, d_cigars, cigar_stride, nullptr, 0, nullptr, 0,
+                                    nullptr, 0, nullptr, s);
+    hipLaunchKernelGGL(clip_illegal_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_tasks, d_records, d_cigars,
+                       cigar_stride, ctx->scoring, ctx->d_flags);
+    WAMD_HIP(hipGetLastError());
+    return WAMD_OK;
+}
+
+int launch_clip_pairs(wamd_ctx* ctx, uint32_t n_pairs, const wamd_clip_pair_task* d_tasks, wamd_clip_record* d_records,
+                      uint8_t* d_cigars, uint32_t cigar_stride, hipStream_t s)
+{
+    WAMD_HIP(hipSetDevice(ctx->device));
+    if (rows_can_stage(d_cigars, cigar_stride) && n_pairs <= 0x7fffffffu)
+        return launch_staged_row<2>(ctx, 2 * n_pairs, nullptr, d_tasks, d_records, d_cigars, cigar_stride, nullptr, 0,
+                                    nullptr, 0, nullptr, 0, nullptr, s);
+    hipLaunchKernelGGL(clip_pairs_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, s, n_pairs, d_tasks, d_records,
+                       d_cigars, cigar_stride, ctx->d_flags);
+    WAMD_HIP(hipGetLastError());
+    return WAMD_OK;
+}
+
 // the fused form when half a wave's slots fit LDS (64 KB: ext_stride up to 2000), else the four kernels in turn
 int launch_post_passes(wamd_ctx* ctx, uint32_t n, const wamd_clip_illegal_task* d_it, const wamd_clip_pair_task* d_pt,
                        wamd_clip_record* d_rec, uint8_t* d_ext, uint32_t ext_stride, const uint32_t* d_cap_hint,
@@ -1225,6 +1332,9 @@ int launch_sam_cigar(wamd_ctx* ctx, uint32_t n, const uint8_t* d_ext, uint32_t e
                      wamd_sam_cigar_len* d_lens, hipStream_t s)
 {
     WAMD_HIP(hipSetDevice(ctx->device));
+    if (rows_can_stage(d_ext, ext_stride))
+        return launch_staged_row<3>(ctx, n, nullptr, nullptr, nullptr, const_cast<uint8_t*>(d_ext), ext_stride, d_cigars,
+                                    cigar_stride, d_mdz, mdz_stride, d_bin, bin_stride, d_lens, s);
     hipLaunchKernelGGL(sam_cigar_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_ext, ext_stride, d_cigars,
                        cigar_stride, d_mdz, mdz_stride, d_bin, bin_stride, d_lens, ctx->d_flags);
     WAMD_HIP(hipGetLastError());
