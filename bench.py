@@ -462,8 +462,76 @@ def run_extras(ctx, device, genome_symbols, stream, n_small):
                               "roofline": roof_hbm(na, 64 + 48 + q(150) + q(180) + float(fres["ext_cigar_len"].mean()) +
                                                    float(fres["cigar_len"].mean() + fres["mdz_len"].mean()), ms,
                                                    "finish_prepare + align + indel_ext_cigar + finish_merge + clip_* + sam_cigar + finish_final")}
+    # R1: mapped reads/s of the device leg (BASELINE.json's second metric), one chained pass over the same reads in
+    # the reference's order: 8 suffix-array candidates per read (its locus and 7 others; SURVEY 3.4 implies 4 - 8)
+    # through dynamicProgramming, the loop's bookkeeping of mapping_core_sa.cpp:241-344 -> the bytes of the bin's
+    # result group (results.cpp:546-598), then every pair through store_mapped_pair_reads' finish to CIGAR + MD:Z.
+    # What the host keeps (SA search, pairing, MAPQ, SAM text) is not in it.
+    c_per = 8
+    nt = na * c_per
+    rng = np.random.default_rng(91)
+    rt = np.zeros(nt, api.DIST_TASK)
+    rt["read_idx"] = np.repeat(np.arange(na, dtype=np.uint32), c_per)
+    loci = rng.integers(1 << 16, G - (1 << 16), nt)
+    loci[0::c_per] = p0 - 12
+    rt["ref_pos"] = loci.astype(np.uint32)
+    rt["max_distance_in_ref"] = 150 + 2 * 12
+    rt["max_ed"] = 12
+    rt["flags"] = np.repeat(is_rc.astype(np.uint8), c_per)
+    d_rt = dev_bytes(rt)
+    d_rr = torch.zeros(nt * 2, dtype=torch.int32, device=device)
+    ctx.dynamic_programming_dev(reads_fin, d_rt, nt, d_rr, last_symbol=-1)
+    ctx.synchronize()
+    ed = d_rr.view(nt, 2).cpu().numpy()
+    cm = np.zeros(nt, api.COMMIT_TASK)   # what the host loop writes down per candidate once its verifier has answered
+    cm["lev_pos"] = (loci + 12).astype(np.uint32)
+    cm["lev_errors"] = ed[:, 0].astype(np.uint32)
+    cm["max_mismatches"] = 12
+    cm["pattern_len"] = 150
+    cm["direct"] = np.repeat(~is_rc, c_per)
+    d_cm = dev_bytes(cm)
+    d_committed = torch.zeros(nt * api.MAPPING.itemsize, dtype=torch.uint8, device=device)
+    d_rf = torch.arange(0, nt + 1, c_per, dtype=torch.int32, device=device)
+    d_ids = torch.arange(na, dtype=torch.int64, device=device) + (7 << 32)
+    gcap = na * 16 + nt * 11 + 64
+    d_gout = torch.zeros(gcap, dtype=torch.uint8, device=device)
+    d_gnb = torch.zeros(1, dtype=torch.int32, device=device)
+    d_goff = torch.zeros(na + 1, dtype=torch.int32, device=device)
+    d_gws = torch.zeros(ctx.result_groups_workspace_bytes(nt, na), dtype=torch.uint8, device=device)
+    gp = api.GroupParams(5, 4, 8, 0)
+
+    def verify_all():
+        ctx.dynamic_programming_dev(reads_fin, d_rt, nt, d_rr, last_symbol=-1)
+
+    def groups():
+        ctx.commit_candidates_dev(nt, d_cm, None, d_committed)
+        ctx.emit_result_groups_dev(nt, d_cm, d_committed, na, d_rf, d_ids, gp, d_gout, gcap, d_gnb, d_goff, d_gws)
+
+    def finish():
+        ctx.finish_pairs_dev(reads_fin, d_ft, np_pairs, d_fr, d_fe, 352, d_fc, 352, d_fm, 352, d_fw[padw:], fwb, params=prm)
+
+    def chain():
+        verify_all()
+        groups()
+        finish()
+
+    ms_v = timed(verify_all, tag="R1_verify", units=nt)
+    ms_g = timed(groups, tag="K_result_groups", units=nt)
+    ms = timed(chain, tag="R1_mapped_reads", units=na)
+    out["K_result_groups"] = {"shape": "commit_candidates + result group of the bin (heap of 8 per read, 5-byte ids)",
+                              "tasks": nt, "reads": na, "kernel_ms": ms_g, "candidates_per_s": nt / ms_g * 1e3,
+                              "group_bytes": int(d_gnb.item()),
+                              "roofline": roof_hbm(nt, 16 + 2 * 40 + 4 + int(d_gnb.item()) / nt, ms_g,
+                                                   "commit_kernel + group_order_kernel + group_write_kernel")}
+    out["R1_mapped_reads"] = {"shape": "150 bp pairs, %d candidates per read: dynamicProgramming (exact mode, k = 12) -> "
+                                       "commit + result groups -> finish_pairs (fill_cigar, clipping, CIGAR + MD:Z); "
+                                       "device leg only, inputs resident" % c_per,
+                              "reads": na, "candidates_per_read": c_per, "total_ms": ms,
+                              "mapped_reads_per_s": na / ms * 1e3,
+                              "stages_ms": {"verify": ms_v, "result_groups": ms_g, "finish_pairs": out["N1_finish_pairs"]["total_ms"]},
+                              "accepted_fraction": float((ed[:, 0] <= 12).mean())}
     reads_fin.free()
-    del d_ft, d_fr, d_fe, d_fc, d_fm, d_fw
+    del d_ft, d_fr, d_fe, d_fc, d_fm, d_fw, d_rt, d_rr, d_cm, d_committed, d_rf, d_ids, d_gout, d_gnb, d_goff, d_gws
 
     # S3 / S6: mate rescue with traceback - long windows, k' = 2 * floor(0.09 m) (W = mu + 7 sigma + 2k')
     def rescue(tag, m, k, W, seed, count):
@@ -886,6 +954,12 @@ def main():
             torch.cuda.empty_cache()
             out["extras"] = run_extras(ctx, device, args.genome_symbols, stream, args.extras_tasks)
             out["extras"]["S1_accepted_only"] = banded
+            r1 = out["extras"].get("R1_mapped_reads")
+            if r1 and "cpu_baseline" in out:
+                # the reference's verifier alone on the host cores, the same candidates per read: an upper bound
+                # on what the CPU leg can map (its traceback and post-passes come on top)
+                r1["cpu_verify_only_reads_per_s"] = out["cpu_baseline"]["value"] / r1["candidates_per_read"]
+                r1["cpu_cores"] = out["cpu_baseline"]["cores"]
         if MARKS["on"]:
             out["profile_markers"] = {"tags": MARKS["tags"], "reps": MARKS["reps"], "units": MARKS["units"]}
         json_out.write(json.dumps(out) + "\n")
