@@ -255,17 +255,42 @@ __global__ __launch_bounds__(256) void indel_ext_cigar_kernel(const uint8_t* __r
 
 __device__ __forceinline__ bool is_alpha(uint32_t c) { return ((c | 32u) - 'a') < 26u; }
 
+// Strings by the dword.  Most of an ext-CIGAR is runs of '.', and a lane walking its string byte by byte pays a whole
+// state-machine step per symbol; where the next four bytes are dots the routines below take them in one step (what
+// four steps of the reference's loop would do to their state is written out at each site).  `str4` reads four
+// bytes at any offset of a string whose base is dword-aligned; callers keep e + 8 <= the string's capacity.
+constexpr uint32_t FOUR_DOTS = 0x2E2E2E2Eu;
+__device__ __forceinline__ bool str_aligned(const uint8_t* s) { return ((uintptr_t)s & 3u) == 0; }
+__device__ __forceinline__ uint32_t str4(const uint8_t* s, uint32_t e)
+{
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(s) + (e >> 2);
+    return __builtin_amdgcn_alignbyte(w[1], w[0], e & 3u);
+}
+
+// strlen bounded by the slot: whole dwords while none of their bytes is zero
+__device__ __forceinline__ uint32_t bounded_len(const uint8_t* ec, uint32_t stride)
+{
+    uint32_t l = 0;
+    if (str_aligned(ec)) {
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(ec);
+        while (l + 4 <= stride) {
+            const uint32_t v = w[l >> 2];
+            if ((v - 0x01010101u) & ~v & 0x80808080u)
+                break;
+            l += 4;
+        }
+    }
+    while (l < stride && ec[l])
+        ++l;
+    return l;
+}
+
 // One record: the body of clipBoundaryPositions.  `ec` may point to global memory or to an LDS copy of the slot.
 __device__ void clip_boundary_one(wamd_clip_record& d, uint8_t* ec, uint32_t cigar_stride, const wamd_scoring& sc)
 {
     d.no_clippings = 0;
 
-    auto length = [&]() {
-        uint32_t l = 0;
-        while (l < cigar_stride && ec[l])
-            ++l;
-        return l;
-    };
+    auto length = [&]() { return bounded_len(ec, cigar_stride); };
     if (d.err_edit_distance == 0) {
         d.cigar_len = length();
         return;
@@ -277,7 +302,28 @@ __device__ void clip_boundary_one(wamd_clip_record& d, uint8_t* ec, uint32_t cig
     uint32_t in = d.left_clipping;
     bool in_indel = false;
     int pos;
+    // four dots at once: with a positive match score the running score rises through them, so only the first can
+    // be a new minimum and only the last a new maximum (the comparisons are strict); the sums are taken one by one
+    const bool by4 = str_aligned(ec) && sc.match > 0;
     for (pos = 0; in < cigar_stride && ec[in] && ec[in] != '$'; ++pos) {   // 849-890
+        if (by4 && in + 8 <= cigar_stride && str4(ec, in) == FOUR_DOTS) {
+            cur += sc.match;
+            if (cur < mini) {
+                mini_pos = pos;
+                mini = cur;
+            }
+            cur += sc.match;
+            cur += sc.match;
+            cur += sc.match;
+            pos += 3;
+            in += 4;
+            in_indel = false;
+            if (cur > maxi) {
+                maxi_pos = pos;
+                maxi = cur;
+            }
+            continue;
+        }
         const uint32_t c = ec[in];
         if (c == '.') {
             cur += sc.match;
@@ -408,14 +454,6 @@ __global__ __launch_bounds__(256) void clip_boundary_kernel(uint32_t n, wamd_cli
 // One record per lane.  The three loops of the reference, byte for byte - including the tail
 // loop that does not advance its input on an ordinary symbol and so pads with '$' up to
 // read_length, and the '$' of an earlier clipping being scored as a mismatch.
-__device__ __forceinline__ uint32_t bounded_len(const uint8_t* ec, uint32_t stride)
-{
-    uint32_t l = 0;
-    while (l < stride && ec[l])
-        ++l;
-    return l;
-}
-
 __device__ void clip_illegal_one(wamd_clip_record& d, const wamd_clip_illegal_task& t, uint8_t* ec, uint32_t stride,
                                  const wamd_scoring& sc, uint32_t* flags)
 {
@@ -957,12 +995,21 @@ __device__ wamd_sam_cigar_len sam_cigar_one(const uint8_t* ext, uint32_t ext_str
     uint32_t run_m = 0, run_md = 0;            // cnt_match_mismatch, cnt_match_ignoring_insert
     int cur = Begin, prev = Begin;
     bool overflow = false;
+    const bool by4 = str_aligned(ext);
     while (cur != End) {
         const uint32_t ch = e < ext_stride ? ext[e] : 0u;   // a slot without a NUL ends at its stride
         // 12 bytes of head room cover the longest single step (a count and two symbols)
         if (c + 12 > cigar_stride || d + 14 > mdz_stride || (cb && b + 1 > bin_stride)) {
             overflow = true;
             break;
+        }
+        // inside a run of matches four more dots change three counts and nothing else (no flush: cur == prev)
+        if (by4 && prev == Match && e + 8 <= ext_stride && str4(ext, e) == FOUR_DOTS) {
+            counters[Match] += 4;
+            run_m += 4;
+            run_md += 4;
+            e += 4;
+            continue;
         }
         if (ch == '$') {
             cur = Clipping;
@@ -1160,9 +1207,7 @@ __global__ __launch_bounds__(64) void post_passes_kernel(uint32_t n, const wamd_
                                                  mdz + (uint64_t)slot * mdz_stride, mdz_stride, nullptr, 0, flags);
             // the length of the ext-CIGAR as the passes left it, + 2 (0 / 1 = not measured), for the caller's bookkeeping:
             // here it costs LDS reads, from the slots in memory a line fetch per lane and byte
-            uint32_t el = 0;
-            while (el < cap && ec[el])
-                ++el;
+            const uint32_t el = bounded_len(ec, cap);
             l.reserved = el + 2;
             lens[slot] = l;
             records[slot] = d;
