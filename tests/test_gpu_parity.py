@@ -485,6 +485,45 @@ def test_sam_cigar(ctx, oracle):
         ctx.sam_cigar(ext[:64], out_stride=16)
 
 
+def _restride(cig, stride):
+    out = np.zeros((cig.shape[0], stride), np.uint8)
+    w = min(stride, cig.shape[1])
+    out[:, :w] = cig[:, :w]
+    return out
+
+
+@pytest.mark.parametrize("m,stride,n", [(150, 512, 2999), (150, 400, 1537), (250, 640, 1001), (100, 192, 777),
+                                        (150, 388, 1000)])
+def test_post_rows_slot_layouts(ctx, oracle, m, stride, n):
+    """Rows L / B / X through their stand-alone entry points on every way their kernel stages the slots: strings a
+    lane keeps in registers (strides that are multiples of 16: measured in registers at 150 bp, by the wave above 192
+    bytes at 250 bp, whole slots at stride 192), the copy loops (stride 388), a ragged last wave and an odd count."""
+    t, rec, cig = common.clip_illegal_workload(oracle, n, seed=60 + m + stride % 7, m=m)
+    cig = _restride(cig, stride)
+    rc, wrec, wcig = oracle.clip_illegal(t, rec, cig)
+    assert rc == 0
+    grec, gcig = ctx.clip_illegal(t, rec, cig)
+    _same_clip_output(grec, gcig, wrec, wcig)
+    _, wrec2, wcig2 = oracle.clip_boundary(wrec, wcig)
+    grec2, gcig2 = ctx.clip_boundary(grec, gcig)
+    np.testing.assert_array_equal(grec2, wrec2)
+    for i in range(len(wrec2)):
+        k = wrec2["cigar_len"][i] + 1
+        assert bytes(gcig2[i, :k]) == bytes(wcig2[i, :k]), i
+    rc, wc, wm, wb, wl = oracle.sam_cigar(wcig2)
+    gc, gm, gb, gl = ctx.sam_cigar(gcig2)
+    np.testing.assert_array_equal(gl, wl)
+    for i in range(len(wl)):
+        assert bytes(gc[i, :wl["cigar_len"][i] + 1]) == bytes(wc[i, :wl["cigar_len"][i] + 1])
+        assert bytes(gm[i, :wl["mdz_len"][i] + 1]) == bytes(wm[i, :wl["mdz_len"][i] + 1])
+    tp, recp, cigp = common.clip_pairs_workload(oracle, n // 2, seed=61 + m, m=m)
+    cigp = _restride(cigp, stride)
+    rc, wrecp, wcigp = oracle.clip_overlapping_pairs(tp, recp, cigp)
+    assert rc == 0
+    grecp, gcigp = ctx.clip_overlapping_pairs(tp, recp, cigp)
+    _same_clip_output(grecp, gcigp, wrecp, wcigp)
+
+
 @pytest.mark.parametrize("seed,m,flank", [(31, 150, 6), (32, 250, 8), (33, 100, 5), (34, 150, 13)])
 def test_finish_pairs_chain(ctx, oracle, seed, m, flank):
     """Row N1's stand-in: the reference's post-processing order on one set of pairs - fill_cigar (perfect / lev /

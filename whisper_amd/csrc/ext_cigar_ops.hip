@@ -1099,42 +1099,130 @@ __global__ __launch_bounds__(256) void sam_cigar_kernel(uint32_t n, const uint8_
 
 // ---- rows L, B, L, X behind one another on an LDS copy of the ext-CIGARs --------------------------
 // clipIllegalPositions, clipBoundaryPositions, clipOverlappingPairs and extract_cigar_and_mdz
-// (sam.cpp:1889-1900, 2002-2007) for 64 consecutive slots (32 pairs) per wave.  The wave copies its
-// slots from global memory into LDS with coalesced loads (the slots are contiguous), every lane then runs
-// the four routines on its own copy - the per-record state machines above, unchanged, so the bytes they
-// produce are the same - and the wave writes the slots back once.  A lane's copy starts at an odd dword
-// stride, so lanes reading the same offset of their strings hit different banks.  Records travel
-// between the two lanes of a pair by shuffles.
+// (sam.cpp:1889-1900, 2002-2007) for 64 consecutive slots (32 pairs) per wave - all four behind one another
+// (finish_pairs) or any one of them (the stand-alone entry points of these rows: on the slots in HBM every byte
+// a lane touches is its own cache line, and lines do not survive in L1 between a lane's accesses - 8 to 37 KB of
+// line traffic per 150-byte string).  The wave copies its slots from global memory into LDS with coalesced loads
+// (the slots are contiguous), every lane then runs the routines on its own copy - the per-record state machines
+// above, unchanged, so the bytes they produce are the same - and the wave writes the slots back once.  A lane's
+// copy starts at an odd dword stride, so lanes reading the same offset of their strings hit different banks.
+// Records travel between the two lanes of a pair by shuffles.
+enum { POST_ILLEGAL = 1, POST_BOUNDARY = 2, POST_PAIRS = 4, POST_SAM = 8,
+       POST_LEN_IN_RESERVED = 16,   // lens[].reserved = length of the ext-CIGAR + 2 (finish_pairs' bookkeeping)
+       POST_TWO_HALVES = 32 };      // test hook: never pack
+
 __global__ __launch_bounds__(64) void post_passes_kernel(uint32_t n, const wamd_clip_illegal_task* __restrict__ it,
                                                          const wamd_clip_pair_task* __restrict__ pt,
                                                          wamd_clip_record* __restrict__ records, uint8_t* __restrict__ ext,
                                                          uint32_t ext_stride, const uint32_t* __restrict__ cap_hint,
-                                                         uint32_t budget_dw, wamd_scoring sc,
-                                                         int do_boundary, int do_pairs, uint8_t* __restrict__ cigars,
-                                                         uint32_t cigar_stride, uint8_t* __restrict__ mdz,
-                                                         uint32_t mdz_stride, wamd_sam_cigar_len* __restrict__ lens,
-                                                         uint32_t* __restrict__ flags)
+                                                         uint32_t budget_dw, wamd_scoring sc, uint32_t passes,
+                                                         uint8_t* __restrict__ cigars, uint32_t cigar_stride,
+                                                         uint8_t* __restrict__ mdz, uint32_t mdz_stride,
+                                                         uint32_t* __restrict__ cigar_bin, uint32_t bin_stride,
+                                                         wamd_sam_cigar_len* __restrict__ lens, uint32_t* __restrict__ flags)
 {
     extern __shared__ uint32_t post_lds[];
     const uint32_t lane = threadIdx.x;
     const uint32_t base = blockIdx.x * 64;
-    const uint32_t here = n - base < 64u ? n - base : 64u;   // slots of this wave (n is even: pairs stay together)
+    const uint32_t here = n - base < 64u ? n - base : 64u;   // slots of this wave (pairs stay together: base is even)
     const uint32_t slot = base + lane;
     const bool live = lane < here;
     const uint32_t full_dw = (ext_stride / 4) | 1u;   // odd: lanes at the same offset of their strings hit different banks
-    // What a lane's string needs.  A caller that knows how long the strings are (and can get: a clipping pass never
-    // lengthens one, a perfect match may receive read_length dots) says so per slot, and the wave packs its strings:
-    // the LDS of a wave, not its registers, is what limits the waves per CU here.  Both strings of a pair get the
-    // room of the longer one (the pair routine takes one capacity).  Without hints, or when the packed strings
-    // do not fit the budget, the wave serves its 32 even / odd pairs in two halves at the full stride.
+    // What a lane's string needs.  The wave packs its strings by their lengths: the LDS of a wave, not its
+    // registers, is what limits the waves per CU here.  A caller that knows how long the strings are (and can get: a
+    // clipping pass never lengthens one, a perfect match may receive read_length dots) says so per slot; otherwise
+    // the wave measures them, one slot after the other with the lanes side by side on its dwords.  Both strings of
+    // a pair get the room of the longer one (the pair routine takes one capacity).  When the packed strings do not
+    // fit the budget, the wave serves its 32 even / odd pairs in two halves at the full stride.
+    //
+    // Staging: a lane fetches ITS OWN slot, sixteen bytes at a time into registers (strings up to 16 * POST_CH
+    // bytes), all requests in flight at once - a loop in which the wave copies one slot after the other, coalesced
+    // as it is, waits for memory sixty-four times in a row, and that wait was most of these kernels' time.  The
+    // loop form remains for longer strings, unaligned strides and the two-halves case.
+    constexpr int POST_CH = 12;
+    const bool regs_ok = (ext_stride & 15u) == 0 && ((uintptr_t)ext & 15u) == 0;
+    wamd_u32x4 rg[POST_CH];
     uint32_t my_dw = 0;
-    if (live) {
-        my_dw = full_dw;
-        if (cap_hint) {
-            const uint32_t c = cap_hint[slot] < ext_stride ? cap_hint[slot] : ext_stride;
+    bool in_regs = regs_ok;   // (wave-uniform from here on)
+    if (cap_hint) {
+        uint32_t c = 0;
+        if (live) {
+            c = cap_hint[slot] < ext_stride ? cap_hint[slot] : ext_stride;
             my_dw = ((c + 3) / 4) | 1u;
             my_dw = my_dw > full_dw ? full_dw : my_dw;
         }
+        {   // (a pair shares the longer capacity, see below: what is fetched must cover it)
+            const uint32_t other = (uint32_t)__shfl_xor((int)my_dw, 1);
+            my_dw = my_dw > other ? my_dw : (live ? other : 0u);
+        }
+        in_regs = regs_ok && !__any(live && my_dw * 4 > 16u * POST_CH);
+        if (in_regs) {
+            const wamd_u32x4* src = reinterpret_cast<const wamd_u32x4*>(ext + (uint64_t)(live ? slot : base) * ext_stride);
+#pragma unroll
+            for (int q = 0; q < POST_CH; ++q)
+                if (live && 16u * q < my_dw * 4 && 16u * q < ext_stride)
+                    rg[q] = src[q];
+        }
+    } else {
+        uint32_t my_len = ext_stride;   // bytes up to and including the dword that holds the NUL
+        bool found = false;
+        if (regs_ok) {
+            const wamd_u32x4* src = reinterpret_cast<const wamd_u32x4*>(ext + (uint64_t)(live ? slot : base) * ext_stride);
+#pragma unroll
+            for (int q = 0; q < POST_CH; ++q)
+                if (live && 16u * q < ext_stride)
+                    rg[q] = src[q];
+#pragma unroll
+            for (int q = 0; q < POST_CH; ++q)
+                if (live && !found && 16u * q < ext_stride) {
+                    const uint32_t w[4] = {rg[q].x, rg[q].y, rg[q].z, rg[q].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (!found && ((w[j] - 0x01010101u) & ~w[j] & 0x80808080u)) {
+                            found = true;
+                            my_len = 16u * q + 4u * j + 4u;
+                        }
+                }
+            if (ext_stride <= 16u * POST_CH)
+                found = true;   // the whole slot is in the registers
+        }
+        const bool measured = regs_ok && !__any(live && !found);
+        if (!measured) {   // the wave measures its slots one after the other, the lanes side by side on a slot's dwords
+            for (uint32_t sl = 0; sl < here; ++sl) {
+                const uint32_t* src = reinterpret_cast<const uint32_t*>(ext + (uint64_t)(base + sl) * ext_stride);
+                uint32_t len = ext_stride;
+                for (uint32_t i0 = 0; i0 < ext_stride / 4; i0 += 64) {
+                    const uint32_t i = i0 + lane;
+                    bool z = false;
+                    if (i < ext_stride / 4) {
+                        const uint32_t v = src[i];
+                        z = ((v - 0x01010101u) & ~v & 0x80808080u) != 0;
+                    }
+                    const uint64_t m = __ballot(z);
+                    if (m) {
+                        len = 4 * (i0 + (uint32_t)__builtin_ctzll(m)) + 4;
+                        break;
+                    }
+                }
+                if (lane == sl)
+                    my_len = len;
+            }
+        }
+        if (live) {
+            // a perfect match may be filled with read_length dots (clipIllegalPositions, 614-618), and the tail loop
+            // of that routine pads up to read_length
+            // (so may clipOverlappingPairs, 1029-1036)
+            uint32_t grow = (passes & POST_ILLEGAL) ? (uint32_t)it[slot].read_length + 1u : 0u;
+            if (passes & POST_PAIRS) {
+                const uint32_t g2 = (uint32_t)pt[slot >> 1].read_length[lane & 1u] + 1u;
+                grow = grow > g2 ? grow : g2;
+            }
+            uint32_t c = (my_len > grow ? my_len : grow) + 8u;
+            c = c < ext_stride ? c : ext_stride;
+            my_dw = ((c + 3) / 4) | 1u;
+            my_dw = my_dw > full_dw ? full_dw : my_dw;
+        }
+        in_regs = measured && !__any(live && my_dw * 4 > 16u * POST_CH && ext_stride > 16u * POST_CH);
     }
     {
         const uint32_t other = (uint32_t)__shfl_xor((int)my_dw, 1);
@@ -1148,7 +1236,7 @@ __global__ __launch_bounds__(64) void post_passes_kernel(uint32_t n, const wamd_
             incl += o;
     }
     const uint32_t total = (uint32_t)__shfl((int)incl, 63);
-    const int halves = total <= budget_dw ? 1 : 2;
+    const int halves = (total <= budget_dw && !(passes & POST_TWO_HALVES)) ? 1 : 2;
     for (int h = 0; h < halves; ++h) {
         // lanes of this pass, where their strings start and how many dwords they hold
         const bool mine = halves == 1 || (lane >> 5) == (uint32_t)h;
@@ -1158,28 +1246,41 @@ __global__ __launch_bounds__(64) void post_passes_kernel(uint32_t n, const wamd_
             off = (lane & 31u) * full_dw;
         }
         const uint32_t cap = ndw * 4 < ext_stride ? ndw * 4 : ext_stride;   // bytes of the string the routines may use
-        for (uint32_t sl = 0; sl < here; ++sl) {   // coalesced: the wave copies one string after the other
-            const uint32_t n_s = (uint32_t)__builtin_amdgcn_readlane((int)ndw, (int)sl);
-            if (!n_s)
-                continue;
-            const uint32_t o_s = (uint32_t)__builtin_amdgcn_readlane((int)off, (int)sl);
-            const uint32_t* src = reinterpret_cast<const uint32_t*>(ext + (uint64_t)(base + sl) * ext_stride);
-            const uint32_t lim = n_s < ext_stride / 4 ? n_s : ext_stride / 4;
-            for (uint32_t i = lane; i < lim; i += 64)
-                post_lds[o_s + i] = src[i];
+        const uint32_t lim_dw = ndw < ext_stride / 4 ? ndw : ext_stride / 4;   // dwords that travel
+        const bool by_regs = in_regs && halves == 1;
+        if (by_regs) {
+#pragma unroll
+            for (int q = 0; q < POST_CH; ++q) {
+                const uint32_t w[4] = {rg[q].x, rg[q].y, rg[q].z, rg[q].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (4u * q + j < lim_dw)
+                        post_lds[off + 4 * q + j] = w[j];
+            }
+        } else {
+            for (uint32_t sl = 0; sl < here; ++sl) {   // coalesced: the wave copies one string after the other
+                const uint32_t n_s = (uint32_t)__builtin_amdgcn_readlane((int)lim_dw, (int)sl);
+                if (!n_s)
+                    continue;
+                const uint32_t o_s = (uint32_t)__builtin_amdgcn_readlane((int)off, (int)sl);
+                const uint32_t* src = reinterpret_cast<const uint32_t*>(ext + (uint64_t)(base + sl) * ext_stride);
+                for (uint32_t i = lane; i < n_s; i += 64)
+                    post_lds[o_s + i] = src[i];
+            }
         }
         __syncthreads();
         const bool act = live && mine;
         uint8_t* ec = reinterpret_cast<uint8_t*>(post_lds + off);
         wamd_clip_record d{};
-        if (act) {
+        if (act && (passes & (POST_ILLEGAL | POST_BOUNDARY | POST_PAIRS))) {
             d = records[slot];
-            clip_illegal_one(d, it[slot], ec, cap, sc, flags);
-            if (do_boundary)
+            if (passes & POST_ILLEGAL)
+                clip_illegal_one(d, it[slot], ec, cap, sc, flags);
+            if (passes & POST_BOUNDARY)
                 clip_boundary_one(d, ec, cap, sc);
         }
         __syncthreads();   // every lane's string is as its own passes left it before a partner touches it
-        if (do_pairs) {
+        if (passes & POST_PAIRS) {
             // the even lane of a pair takes its partner's record, clips both strings, hands the record back
             uint32_t w[8], v[8];
             memcpy(w, &d, 32);
@@ -1203,83 +1304,48 @@ __global__ __launch_bounds__(64) void post_passes_kernel(uint32_t n, const wamd_
             __syncthreads();
         }
         if (act) {
-            wamd_sam_cigar_len l = sam_cigar_one(ec, cap, cigars + (uint64_t)slot * cigar_stride, cigar_stride,
-                                                 mdz + (uint64_t)slot * mdz_stride, mdz_stride, nullptr, 0, flags);
-            // the length of the ext-CIGAR as the passes left it, + 2 (0 / 1 = not measured), for the caller's bookkeeping:
-            // here it costs LDS reads, from the slots in memory a line fetch per lane and byte
-            const uint32_t el = bounded_len(ec, cap);
-            l.reserved = el + 2;
-            lens[slot] = l;
-            records[slot] = d;
+            if (passes & POST_SAM) {
+                wamd_sam_cigar_len l = sam_cigar_one(ec, cap, cigars + (uint64_t)slot * cigar_stride, cigar_stride,
+                                                     mdz + (uint64_t)slot * mdz_stride, mdz_stride,
+                                                     cigar_bin ? cigar_bin + (uint64_t)slot * bin_stride : nullptr, bin_stride,
+                                                     flags);
+                // the length of the ext-CIGAR as the passes left it, + 2 (0 / 1 = not measured), for the caller's
+                // bookkeeping: here it costs LDS reads, from the slots in memory a line fetch per lane and byte
+                if (passes & POST_LEN_IN_RESERVED)
+                    l.reserved = bounded_len(ec, cap) + 2;
+                lens[slot] = l;
+            }
+            if (passes & (POST_ILLEGAL | POST_BOUNDARY | POST_PAIRS))
+                records[slot] = d;
         }
         __syncthreads();
-        for (uint32_t sl = 0; sl < here; ++sl) {
-            const uint32_t n_s = (uint32_t)__builtin_amdgcn_readlane((int)ndw, (int)sl);
-            if (!n_s)
-                continue;
-            const uint32_t o_s = (uint32_t)__builtin_amdgcn_readlane((int)off, (int)sl);
-            uint32_t* dst = reinterpret_cast<uint32_t*>(ext + (uint64_t)(base + sl) * ext_stride);
-            const uint32_t lim = n_s < ext_stride / 4 ? n_s : ext_stride / 4;
-            for (uint32_t i = lane; i < lim; i += 64)
-                dst[i] = post_lds[o_s + i];
-        }
-        __syncthreads();
-    }
-}
-
-// ---- rows L, B, X one at a time, on an LDS copy as well ------------------------------------------------
-// The stand-alone entry points of these rows used to run their byte loops on the slots in HBM: every byte a lane
-// touches is its own cache line there, and lines do not survive in L1 between a lane's accesses - 8 to 37 KB of
-// line traffic per 150-byte string.  Same device functions, same bytes; the wave serves its 64 slots in two halves
-// of 32 at the full stride (no length hints at these entry points).
-template <int MODE>   // 0 clipIllegalPositions, 1 clipBoundaryPositions, 2 clipOverlappingPairs, 3 extract_cigar_and_mdz
-__global__ __launch_bounds__(64) void staged_row_kernel(uint32_t n, const wamd_clip_illegal_task* __restrict__ it,
-                                                        const wamd_clip_pair_task* __restrict__ pt,
-                                                        wamd_clip_record* __restrict__ records, uint8_t* __restrict__ ext,
-                                                        uint32_t ext_stride, wamd_scoring sc, uint8_t* __restrict__ cigars,
-                                                        uint32_t cigar_stride, uint8_t* __restrict__ mdz, uint32_t mdz_stride,
-                                                        uint32_t* __restrict__ cigar_bin, uint32_t bin_stride,
-                                                        wamd_sam_cigar_len* __restrict__ lens, uint32_t* __restrict__ flags)
-{
-    extern __shared__ uint32_t row_lds[];
-    const uint32_t lane = threadIdx.x;
-    const uint32_t base = blockIdx.x * 64;
-    const uint32_t here = n - base < 64u ? n - base : 64u;
-    const uint32_t dw = ext_stride / 4, full_dw = dw | 1u;
-    for (uint32_t h = 0; h < 2 && 32 * h < here; ++h) {
-        const uint32_t first = 32 * h;
-        const uint32_t cnt = here - first < 32u ? here - first : 32u;
-        uint32_t* g = reinterpret_cast<uint32_t*>(ext + (uint64_t)(base + first) * ext_stride);
-        for (uint32_t i = lane; i < cnt * dw; i += 64)
-            row_lds[(i / dw) * full_dw + i % dw] = g[i];
-        __syncthreads();
-        const bool act = (lane >> 5) == h && lane < here;
-        const uint32_t slot = base + lane;
-        uint8_t* ec = reinterpret_cast<uint8_t*>(row_lds + (lane & 31u) * full_dw);
-        if (MODE == 0 && act) {
-            wamd_clip_record d = records[slot];
-            clip_illegal_one(d, it[slot], ec, ext_stride, sc, flags);
-            records[slot] = d;
-        }
-        if (MODE == 1 && act) {
-            wamd_clip_record d = records[slot];
-            clip_boundary_one(d, ec, ext_stride, sc);
-            records[slot] = d;
-        }
-        if (MODE == 2 && act && !(lane & 1u) && lane + 1 < here) {
-            wamd_clip_record rec[2] = {records[slot], records[slot + 1]};
-            clip_pair_one(pt[slot >> 1], rec, ec, ec + 4 * full_dw, ext_stride, flags);
-            records[slot] = rec[0];
-            records[slot + 1] = rec[1];
-        }
-        if (MODE == 3 && act)
-            lens[slot] = sam_cigar_one(ec, ext_stride, cigars + (uint64_t)slot * cigar_stride, cigar_stride,
-                                       mdz + (uint64_t)slot * mdz_stride, mdz_stride,
-                                       cigar_bin ? cigar_bin + (uint64_t)slot * bin_stride : nullptr, bin_stride, flags);
-        __syncthreads();
-        if (MODE != 3) {
-            for (uint32_t i = lane; i < cnt * dw; i += 64)
-                g[i] = row_lds[(i / dw) * full_dw + i % dw];
+        if (passes & (POST_ILLEGAL | POST_BOUNDARY | POST_PAIRS)) {   // (extract_cigar_and_mdz only reads)
+            if (by_regs) {
+                uint32_t* dst = reinterpret_cast<uint32_t*>(ext + (uint64_t)(live ? slot : base) * ext_stride);
+#pragma unroll
+                for (int q = 0; q < POST_CH; ++q) {
+                    if (4u * q + 4u <= lim_dw) {
+                        wamd_u32x4 v = {post_lds[off + 4 * q], post_lds[off + 4 * q + 1], post_lds[off + 4 * q + 2],
+                                        post_lds[off + 4 * q + 3]};
+                        *reinterpret_cast<wamd_u32x4*>(dst + 4 * q) = v;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (4u * q + j < lim_dw)
+                                dst[4 * q + j] = post_lds[off + 4 * q + j];
+                    }
+                }
+            } else {
+                for (uint32_t sl = 0; sl < here; ++sl) {
+                    const uint32_t n_s = (uint32_t)__builtin_amdgcn_readlane((int)lim_dw, (int)sl);
+                    if (!n_s)
+                        continue;
+                    const uint32_t o_s = (uint32_t)__builtin_amdgcn_readlane((int)off, (int)sl);
+                    uint32_t* dst = reinterpret_cast<uint32_t*>(ext + (uint64_t)(base + sl) * ext_stride);
+                    for (uint32_t i = lane; i < n_s; i += 64)
+                        dst[i] = post_lds[o_s + i];
+                }
+            }
             __syncthreads();
         }
     }
@@ -1290,17 +1356,22 @@ static bool rows_can_stage(const void* slots, uint32_t stride)
     return (stride & 3u) == 0 && stride >= 4 && stride <= 2000 && ((uintptr_t)slots & 3u) == 0;
 }
 
-template <int MODE>
-static int launch_staged_row(wamd_ctx* ctx, uint32_t n, const wamd_clip_illegal_task* it, const wamd_clip_pair_task* pt,
-                             wamd_clip_record* rec, uint8_t* ext, uint32_t ext_stride, uint8_t* cigars, uint32_t cigar_stride,
-                             uint8_t* mdz, uint32_t mdz_stride, uint32_t* bin, uint32_t bin_stride, wamd_sam_cigar_len* lens,
-                             hipStream_t s)
+static int launch_post_kernel(wamd_ctx* ctx, uint32_t n, const wamd_clip_illegal_task* it, const wamd_clip_pair_task* pt,
+                              wamd_clip_record* rec, uint8_t* ext, uint32_t ext_stride, const uint32_t* cap_hint,
+                              uint32_t passes, uint8_t* cigars, uint32_t cigar_stride, uint8_t* mdz, uint32_t mdz_stride,
+                              uint32_t* bin, uint32_t bin_stride, wamd_sam_cigar_len* lens, hipStream_t s)
 {
     if (n == 0)
         return WAMD_OK;
-    const size_t lds = (size_t)32 * ((ext_stride / 4) | 1u) * 4;
-    hipLaunchKernelGGL(staged_row_kernel<MODE>, dim3((n + 63) / 64), dim3(64), lds, s, n, it, pt, rec, ext, ext_stride,
-                       ctx->scoring, cigars, cigar_stride, mdz, mdz_stride, bin, bin_stride, lens, ctx->d_flags);
+    if (getenv("WAMD_POST_NO_HINTS")) {   // test hook: the two-halves path of every wave
+        cap_hint = nullptr;
+        passes |= POST_TWO_HALVES;
+    }
+    // LDS of a wave: 32 strings at the full (odd) stride - what a half needs when the strings are not packed
+    const uint32_t budget_dw = 32u * ((ext_stride / 4) | 1u);
+    hipLaunchKernelGGL(post_passes_kernel, dim3((n + 63) / 64), dim3(64), (size_t)budget_dw * 4, s, n, it, pt, rec, ext,
+                       ext_stride, cap_hint, budget_dw, ctx->scoring, passes, cigars, cigar_stride, mdz, mdz_stride, bin,
+                       bin_stride, lens, ctx->d_flags);
     WAMD_HIP(hipGetLastError());
     return WAMD_OK;
 }
@@ -1310,8 +1381,8 @@ int launch_clip_boundary(wamd_ctx* ctx, uint32_t n, wamd_clip_record* d_records,
 {
     WAMD_HIP(hipSetDevice(ctx->device));
     if (rows_can_stage(d_cigars, cigar_stride))
-        return launch_staged_row<1>(ctx, n, nullptr, nullptr, d_records, d_cigars, cigar_stride, nullptr, 0, nullptr, 0,
-                                    nullptr, 0, nullptr, s);
+        return launch_post_kernel(ctx, n, nullptr, nullptr, d_records, d_cigars, cigar_stride, nullptr, POST_BOUNDARY,
+                                  nullptr, 0, nullptr, 0, nullptr, 0, nullptr, s);
     hipLaunchKernelGGL(clip_boundary_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_records, d_cigars,
                        cigar_stride, ctx->scoring);
     WAMD_HIP(hipGetLastError());
@@ -1323,8 +1394,8 @@ int launch_clip_illegal(wamd_ctx* ctx, uint32_t n, const wamd_clip_illegal_task*
 {
     WAMD_HIP(hipSetDevice(ctx->device));
     if (rows_can_stage(d_cigars, cigar_stride))
-        return launch_staged_row<0>(ctx, n, d_tasks, nullptr, d_records, d_cigars, cigar_stride, nullptr, 0, nullptr, 0,
-                                    nullptr, 0, nullptr, s);
+        return launch_post_kernel(ctx, n, d_tasks, nullptr, d_records, d_cigars, cigar_stride, nullptr, POST_ILLEGAL,
+                                  nullptr, 0, nullptr, 0, nullptr, 0, nullptr, s);
     hipLaunchKernelGGL(clip_illegal_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_tasks, d_records, d_cigars,
                        cigar_stride, ctx->scoring, ctx->d_flags);
     WAMD_HIP(hipGetLastError());
@@ -1336,8 +1407,8 @@ int launch_clip_pairs(wamd_ctx* ctx, uint32_t n_pairs, const wamd_clip_pair_task
 {
     WAMD_HIP(hipSetDevice(ctx->device));
     if (rows_can_stage(d_cigars, cigar_stride) && n_pairs <= 0x7fffffffu)
-        return launch_staged_row<2>(ctx, 2 * n_pairs, nullptr, d_tasks, d_records, d_cigars, cigar_stride, nullptr, 0,
-                                    nullptr, 0, nullptr, 0, nullptr, s);
+        return launch_post_kernel(ctx, 2 * n_pairs, nullptr, d_tasks, d_records, d_cigars, cigar_stride, nullptr, POST_PAIRS,
+                                  nullptr, 0, nullptr, 0, nullptr, 0, nullptr, s);
     hipLaunchKernelGGL(clip_pairs_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, s, n_pairs, d_tasks, d_records,
                        d_cigars, cigar_stride, ctx->d_flags);
     WAMD_HIP(hipGetLastError());
@@ -1351,17 +1422,11 @@ int launch_post_passes(wamd_ctx* ctx, uint32_t n, const wamd_clip_illegal_task* 
                        uint32_t mdz_stride, wamd_sam_cigar_len* d_lens, hipStream_t s)
 {
     WAMD_HIP(hipSetDevice(ctx->device));
-    if (getenv("WAMD_POST_NO_HINTS"))   // test hook: the two-halves path of every wave
-        d_cap_hint = nullptr;
-    if ((ext_stride & 3u) == 0 && ext_stride <= 2000 && ((uintptr_t)d_ext & 3u) == 0 && (n & 1u) == 0) {
-        // LDS of a wave: 32 strings at the full (odd) stride - what a half needs when the strings are not packed
-        const uint32_t budget_dw = 32u * ((ext_stride / 4) | 1u);
-        hipLaunchKernelGGL(post_passes_kernel, dim3((n + 63) / 64), dim3(64), (size_t)budget_dw * 4, s, n, d_it, d_pt,
-                           d_rec, d_ext, ext_stride, d_cap_hint, budget_dw, ctx->scoring, do_boundary, do_pairs, d_cigars,
-                           cigar_stride, d_mdz, mdz_stride, d_lens, ctx->d_flags);
-        WAMD_HIP(hipGetLastError());
-        return WAMD_OK;
-    }
+    if (rows_can_stage(d_ext, ext_stride) && (n & 1u) == 0)
+        return launch_post_kernel(ctx, n, d_it, d_pt, d_rec, d_ext, ext_stride, d_cap_hint,
+                                  POST_ILLEGAL | (do_boundary ? POST_BOUNDARY : 0) | (do_pairs ? POST_PAIRS : 0) | POST_SAM |
+                                      POST_LEN_IN_RESERVED,
+                                  d_cigars, cigar_stride, d_mdz, mdz_stride, nullptr, 0, d_lens, s);
     int rc = launch_clip_illegal(ctx, n, d_it, d_rec, d_ext, ext_stride, s);
     if (!rc && do_boundary)
         rc = launch_clip_boundary(ctx, n, d_rec, d_ext, ext_stride, s);
@@ -1378,8 +1443,8 @@ int launch_sam_cigar(wamd_ctx* ctx, uint32_t n, const uint8_t* d_ext, uint32_t e
 {
     WAMD_HIP(hipSetDevice(ctx->device));
     if (rows_can_stage(d_ext, ext_stride))
-        return launch_staged_row<3>(ctx, n, nullptr, nullptr, nullptr, const_cast<uint8_t*>(d_ext), ext_stride, d_cigars,
-                                    cigar_stride, d_mdz, mdz_stride, d_bin, bin_stride, d_lens, s);
+        return launch_post_kernel(ctx, n, nullptr, nullptr, nullptr, const_cast<uint8_t*>(d_ext), ext_stride, nullptr, POST_SAM,
+                                  d_cigars, cigar_stride, d_mdz, mdz_stride, d_bin, bin_stride, d_lens, s);
     hipLaunchKernelGGL(sam_cigar_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_ext, ext_stride, d_cigars,
                        cigar_stride, d_mdz, mdz_stride, d_bin, bin_stride, d_lens, ctx->d_flags);
     WAMD_HIP(hipGetLastError());
