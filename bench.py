@@ -518,6 +518,15 @@ def run_extras(ctx, device, genome_symbols, stream, n_small):
     ms_v = timed(verify_all, tag="R1_verify", units=nt)
     ms_g = timed(groups, tag="K_result_groups", units=nt)
     ms = timed(chain, tag="R1_mapped_reads", units=na)
+    # the same chain with the verifier in accepted-only mode (banded kernels): the commit step only asks
+    # cur_match <= max_mismatches (mapping_core_sa.cpp:241), so the group bytes are the same
+    ctx.set_distance_mode(api.DISTANCE_ACCEPTED_ONLY)
+    ms_va = timed(verify_all, tag="R1_verify_accepted_only", units=nt)
+    ms_a = timed(chain, tag="R1_mapped_reads_accepted_only", units=na)
+    ctx.synchronize()
+    ed_a = d_rr.view(nt, 2).cpu().numpy()
+    same_accepts = bool(((ed_a[:, 0] <= 12) == (ed[:, 0] <= 12)).all() and (ed_a[ed[:, 0] <= 12] == ed[ed[:, 0] <= 12]).all())
+    ctx.set_distance_mode(api.DISTANCE_EXACT)
     out["K_result_groups"] = {"shape": "commit_candidates + result group of the bin (heap of 8 per read, 5-byte ids)",
                               "tasks": nt, "reads": na, "kernel_ms": ms_g, "candidates_per_s": nt / ms_g * 1e3,
                               "group_bytes": int(d_gnb.item()),
@@ -529,7 +538,9 @@ def run_extras(ctx, device, genome_symbols, stream, n_small):
                               "reads": na, "candidates_per_read": c_per, "total_ms": ms,
                               "mapped_reads_per_s": na / ms * 1e3,
                               "stages_ms": {"verify": ms_v, "result_groups": ms_g, "finish_pairs": out["N1_finish_pairs"]["total_ms"]},
-                              "accepted_fraction": float((ed[:, 0] <= 12).mean())}
+                              "accepted_fraction": float((ed[:, 0] <= 12).mean()),
+                              "accepted_only": {"total_ms": ms_a, "mapped_reads_per_s": na / ms_a * 1e3, "verify_ms": ms_va,
+                                                "same_accepted_candidates": same_accepts}}
     reads_fin.free()
     del d_ft, d_fr, d_fe, d_fc, d_fm, d_fw, d_rt, d_rr, d_cm, d_committed, d_rf, d_ids, d_gout, d_gnb, d_goff, d_gws
 
