@@ -22,15 +22,35 @@ __device__ __forceinline__ uint32_t code2symbol(uint32_t c)
     return c < 4 ? ((0x54474341u >> (8 * c)) & 0xffu) : (uint32_t)'N';
 }
 
+// Bytes of an ext-CIGAR gather in a dword, dwords in a 16-byte buffer that leaves with one store where the slot is
+// 16-byte aligned (every lane writes its own slot: a wave's store costs the 64 lines it touches whatever its width,
+// and a line that is written in four pieces at four times is four partial writes once it has left L2 in between).
 struct CigarWriter {
     uint8_t* slot;
+    bool wide;
     uint32_t cur, acc;
+    uint32_t q0, q1, q2;
+    __device__ __forceinline__ void word(uint32_t at_dw, uint32_t v)
+    {
+        if (!wide) {
+            *reinterpret_cast<uint32_t*>(slot + 4 * at_dw) = v;
+            return;
+        }
+        const uint32_t qi = at_dw & 3u;
+        if (qi == 3) {
+            const wamd_u32x4 o = {q0, q1, q2, v};
+            *reinterpret_cast<wamd_u32x4*>(slot + 4 * (at_dw - 3)) = o;
+        }
+        q0 = qi == 0 ? v : q0;
+        q1 = qi == 1 ? v : q1;
+        q2 = qi == 2 ? v : q2;
+    }
     __device__ __forceinline__ void put(uint32_t b)
     {
         acc |= b << (8 * (cur & 3u));
         ++cur;
         if ((cur & 3u) == 0) {
-            *reinterpret_cast<uint32_t*>(slot + cur - 4) = acc;
+            word(cur / 4 - 1, acc);
             acc = 0;
         }
     }
@@ -38,23 +58,50 @@ struct CigarWriter {
     {
         const uint32_t len = cur;
         put(0);
-        if (cur & 3u)
-            *reinterpret_cast<uint32_t*>(slot + (cur & ~3u)) = acc;
+        uint32_t n_dw = cur / 4;   // whole dwords written so far
+        if (cur & 3u) {
+            word(n_dw, acc);
+            ++n_dw;
+        }
+        if (wide) {   // what the buffer still holds
+            const uint32_t blk = n_dw & ~3u, left = n_dw & 3u;
+            uint32_t* dst = reinterpret_cast<uint32_t*>(slot) + blk;
+            if (left > 0)
+                dst[0] = q0;
+            if (left > 1)
+                dst[1] = q1;
+            if (left > 2)
+                dst[2] = q2;
+        }
         return len;
     }
 };
 
-__global__ __launch_bounds__(256) void indel_ext_cigar_kernel(const uint8_t* __restrict__ genome,
-                                                              uint64_t genome_symbols, ReadsView rv,
-                                                              const wamd_indel_cigar_task* __restrict__ tasks,
-                                                              uint32_t n, wamd_scoring sc,
-                                                              wamd_indel_cigar_result* __restrict__ results,
-                                                              uint8_t* __restrict__ cigars, uint32_t cigar_stride,
-                                                              uint32_t* __restrict__ flags)
+// One record per lane, one wave per block.  The symbol loops read nothing from memory: the lane first fetches its
+// read and its genome window with 16-byte loads, all in flight together, into its columns of an LDS buffer
+// ([dword][lane]: no two lanes share a bank, no barrier is needed - a lane only ever touches its own columns); the
+// ext-CIGAR leaves through CigarWriter's 16-byte buffer.  (Round 2 before this: a dword load on demand per eight
+// symbols, each waited for together with the dword stores of the string before it, and every one of those stores a
+// partial write of a line that had left L2 since the last one: 6.8 KB of traffic per record, SQ_WAIT_ANY 0.86,
+// 0.65 ms per 425 K records; now 0.44.  Keeping the string in a third column until the end cost more in waves per
+// CU than it saved; one loop over all of a lane's segments instead of the reference's call sequence per mapping
+// type was slower as well - the bench's records are nearly all of one type.)  Symbols beyond the staged dwords
+// (a window longer than qd / gd say) still come from memory.
+__global__ __launch_bounds__(64) void indel_ext_cigar_kernel(GenomeView gv, ReadsView rv,
+                                                             const wamd_indel_cigar_task* __restrict__ tasks,
+                                                             uint32_t n, wamd_scoring sc,
+                                                             wamd_indel_cigar_result* __restrict__ results,
+                                                             uint8_t* __restrict__ cigars, uint32_t cigar_stride,
+                                                             uint32_t qd, uint32_t gd, uint32_t* __restrict__ flags)
 {
+    extern __shared__ uint32_t gx_lds[];
+    const uint8_t* genome = reinterpret_cast<const uint8_t*>(gv.dwords);
+    const uint64_t genome_symbols = gv.n_symbols;
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= n)
         return;
+    uint32_t* const q_col = gx_lds + threadIdx.x;
+    uint32_t* const g_col = q_col + qd * 64;
     const wamd_indel_cigar_task t = tasks[gid];
     wamd_indel_cigar_result r;
     r.score = 0;
@@ -94,27 +141,48 @@ __global__ __launch_bounds__(256) void indel_ext_cigar_kernel(const uint8_t* __r
     // Genome and code buffers are 4-byte aligned and padded to whole dwords.
     const uint32_t* codes_dw = reinterpret_cast<const uint32_t*>(codes);
     const uint32_t* genome_dw = reinterpret_cast<const uint32_t*>(genome);
+    // staged: the read's dwords 0 .. q_n - 1 and the genome's g_first .. g_first + g_n - 1, nibble-swapped
+    const uint32_t q_n = (m + 7) / 8 < qd ? (m + 7) / 8 : qd;
+    const uint32_t g_first = (uint32_t)(t.examined_start_pos >> 3);
+    const uint32_t g_need = (uint32_t)(((uint64_t)t.examined_start_pos + m + a1 + a2 + 1 + 7) >> 3) - g_first;
+    const uint32_t g_n = g_need < gd ? g_need : gd;
+    for (uint32_t d4 = 0; d4 < q_n; d4 += 4) {   // (the codes buffer has 64 bytes of slack behind the last read)
+        const wamd_u32x4_a4 v = *reinterpret_cast<const wamd_u32x4_a4*>(codes_dw + d4);
+        const uint32_t b[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (uint32_t c = 0; c < 4; ++c)
+            if (d4 + c < q_n)
+                q_col[(d4 + c) * 64] = nibble_swap(b[c]);
+    }
+    for (uint32_t d4 = 0; d4 < g_n; d4 += 4) {
+        uint32_t b[4];
+        load_genome_raw4(gv, g_first + d4, b);
+#pragma unroll
+        for (uint32_t c = 0; c < 4; ++c)
+            if (d4 + c < g_n)
+                g_col[(d4 + c) * 64] = nibble_swap(b[c]);
+    }
     uint32_t q_at = 0xffffffffu, q_dw = 0;
-    uint64_t g_at = ~0ull;
-    uint32_t g_dw = 0;
+    uint32_t g_at = 0xffffffffu, g_dw = 0;
     auto Qraw = [&](uint32_t i) -> uint32_t {
         if ((i >> 3) != q_at) {
             q_at = i >> 3;
-            q_dw = nibble_swap(codes_dw[q_at]);
+            q_dw = q_at < q_n ? q_col[q_at * 64] : nibble_swap(codes_dw[q_at]);
         }
         return (q_dw >> (4 * (i & 7u))) & 15u;
     };
     auto Q = [&](uint32_t i) -> uint32_t { return rev ? rc_code_indel2(Qraw(m - 1 - i)) : Qraw(i); };
     auto G = [&](uint32_t i) -> uint32_t {
         const uint64_t p = (uint64_t)t.examined_start_pos + i;
-        if ((p >> 3) != g_at) {
-            g_at = p >> 3;
-            g_dw = nibble_swap(genome_dw[g_at]);
+        const uint32_t at = (uint32_t)(p >> 3);
+        if (at != g_at) {
+            g_at = at;
+            g_dw = at - g_first < g_n ? g_col[(at - g_first) * 64] : nibble_swap(genome_dw[at]);
         }
         return (g_dw >> (4 * ((uint32_t)p & 7u))) & 15u;
     };
 
-    CigarWriter w{slot, 0, 0};
+    CigarWriter w{slot, (((uintptr_t)cigars | cigar_stride) & 15u) == 0, 0, 0, 0, 0, 0};
     uint32_t i_genome = 0, i_query = 0;
     uint16_t edist = 0, events = 0;
     double score = 0;
@@ -223,7 +291,10 @@ __global__ __launch_bounds__(256) void indel_ext_cigar_kernel(const uint8_t* __r
             r.method = t.indel_len1 > 0 ? 24 : 22;
             matching(t.matching_len1);
             indel(t.indel_len1);
-            matching(m - i_query - t.clipping_len);
+            if (t.clipping_len > m - i_query)   // (the reference would run off the read here)
+                overflow = true;
+            else
+                matching(m - i_query - t.clipping_len);
             clipping((int)t.clipping_len);
             r.right_clipping = (uint16_t)t.clipping_len;
         }
@@ -963,9 +1034,17 @@ int launch_indel_ext_cigar(wamd_ctx* ctx, const wamd_reads* r, const wamd_indel_
                            uint32_t cigar_stride, hipStream_t s)
 {
     WAMD_HIP(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(indel_ext_cigar_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ctx->d_genome,
-                       2 * ctx->genome_bytes, r->view(), d_tasks, n, ctx->scoring, d_results, d_cigars,
-                       cigar_stride, ctx->d_flags);
+    if (n == 0)
+        return WAMD_OK;
+    // LDS columns per lane: the longest read, a genome window of that plus 64 symbols of deletions, and a string of
+    // up to 1.25 bytes per read symbol (what is longer than that finishes in memory) - 31 KB per wave at 150 bp
+    // (64 KB at most: reads above 560 symbols keep their tails in memory)
+    uint32_t qd = (r->max_len + 7) / 8 + 1, gd = (r->max_len + 64 + 7) / 8 + 2;
+    qd = qd < 72u ? qd : 72u;
+    gd = gd < 88u ? gd : 88u;
+    hipLaunchKernelGGL(indel_ext_cigar_kernel, dim3((n + 63) / 64), dim3(64), (size_t)(qd + gd) * 256, s,
+                       genome_view(ctx), r->view(), d_tasks, n, ctx->scoring, d_results, d_cigars, cigar_stride, qd, gd,
+                       ctx->d_flags);
     WAMD_HIP(hipGetLastError());
     return WAMD_OK;
 }
