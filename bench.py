@@ -729,6 +729,8 @@ def main():
     if multi:
         import torch.distributed as dist_mod
         dist = dist_mod
+        for k_, v_ in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533")):
+            os.environ.setdefault(k_, v_)   # (the one-rank rehearsal without a launcher)
         dist.init_process_group("nccl", device_id=device)
 
     n = args.tasks
