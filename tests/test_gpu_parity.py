@@ -312,6 +312,43 @@ def test_align(ctx, oracle, m, k, W, last, refine, variant):
         assert bytes(gcig[i, :n + 1]) == bytes(wcig[i, :n + 1]), i
 
 
+def test_align_dev_workspace_sizes(ctx, oracle):
+    """wamd_align_dev on a mate-rescue batch (ed up to 26: the 64-row and wider classes) with the workspace of
+    wamd_align_workspace_bytes (sized for the banded class), of wamd_align_workspace_bytes_for(max_ed) and with
+    twice that: the same answers - the size only decides how many blocks of a wide class are resident -
+    and a workspace below the smallest is an error, not a wild write."""
+    import torch
+    dev = torch.device("cuda", 0)
+    m, k, W, n = 150, 26, 660, 6000
+    codes, packed, (blob, off, lens), tasks = common.distance_workload(m, k, n, seed=977, encoding=1, W=W)
+    stride = 4 * ((2 * (m + k) + 8 + 3) // 4)
+    rc, want, wcig = oracle.align(packed, blob, off, lens, 1, tasks, 0, 1, cigar_stride=stride)
+    assert rc == 0 and (want["edit_distance"][want["ok"] == 1] > 14).sum() > 100
+    reads = ctx.upload_reads(blob, off, lens, 1)
+    d_t = torch.from_numpy(np.ascontiguousarray(tasks).view(np.uint8).reshape(-1).copy()).to(dev)
+    small = ctx.align_workspace_bytes(reads, n)
+    wide = ctx.align_workspace_bytes(reads, n, max_ed=k)
+    assert wide >= small
+    for wsb in (small, wide, 2 * wide):
+        d_r = torch.zeros(n * api.ALIGN_RESULT.itemsize, dtype=torch.uint8, device=dev)
+        d_c = torch.zeros(n * stride, dtype=torch.uint8, device=dev)
+        d_w = torch.zeros(wsb + 256, dtype=torch.uint8, device=dev)
+        pad = (-d_w.data_ptr()) % 256
+        ctx.align_dev(reads, d_t, n, d_r, d_c, stride, d_w[pad:], wsb, last_symbol=0, refine=1)
+        ctx.synchronize()
+        assert ctx.take_flags() == 0
+        got = d_r.cpu().numpy().view(api.ALIGN_RESULT)
+        gcig = d_c.cpu().numpy().reshape(n, stride)
+        for f in want.dtype.names:
+            np.testing.assert_array_equal(got[f], want[f], err_msg="%s at workspace %d" % (f, wsb))
+        for i in np.nonzero(want["ok"])[0][::7]:
+            ln = want["cigar_len"][i]
+            assert bytes(gcig[i, :ln + 1]) == bytes(wcig[i, :ln + 1]), i
+    with pytest.raises(api.WamdError):
+        ctx.align_dev(reads, d_t, n, d_r, d_c, stride, d_w[pad:], 4096, last_symbol=0, refine=1)
+    reads.free()
+
+
 @pytest.mark.parametrize("m,enc,mcf,stage,max_indel", [(150, 0, 1.0, 5, 50), (150, 1, 0.6, 5, 50), (100, 0, 0.5, 4, 50),
                                                         (250, 0, 1.0, 4, 50),
                                                         (300, 0, 0.6, 8, 50),      # reads above 256: indel_match_kernel<false>
