@@ -33,7 +33,8 @@
 namespace wamd {
 
 enum { OP_NONE = 0, OP_M = 1, OP_X = 2, OP_D = 3, OP_I = 4 };
-enum { DIR_D = 0, DIR_H = 1, DIR_V = 2 };
+enum { DIR_D = 0, DIR_H = 1, DIR_V = 2, DIR_X = 3 };   // DIR_X: a diagonal step over a mismatch, recorded by the split
+                                                        // class only (its replay then needs no symbols for matches)
 
 // reader of 4-bit symbols, either direction, over dwords staged in LDS as [dword][lane]
 // (already nibble-swapped: symbol s of a dword at bits 4s); dword 0 holds symbols
@@ -773,7 +774,7 @@ __global__ __launch_bounds__(BLOCK, (PHASE == 1 && NW <= 4 ? WAMD_WALK_WAVES : 1
                         read_pos -= take_h ? 0u : 1u;
                         pos -= (take_d || take_h) ? 1u : 0u;
                         prev_dir = dir;
-                        push_step(dir);
+                        push_step(PHASE == 1 && take_d && fdx ? DIR_X : dir);
                         pending = dir == DIR_V && read_pos != 0;
                     }
                 }
@@ -1073,6 +1074,177 @@ __global__ __launch_bounds__(BLOCK, (PHASE == 1 && NW <= 4 ? WAMD_WALK_WAVES : 1
     }
 }
 
+// ---- replay of the banded class: the recorded path becomes the ext-CIGAR ----------------------
+// The walk (PHASE 1) leaves two bits per step, last step first: match, mismatch, deletion ('^' + genome
+// letter), insertion ('#' + read letter).  A 150 bp alignment is some 160 steps of which a handful are
+// not matches, so the string is written as what it mostly is - dots, sixteen per store - and then only
+// the edits are visited: a lane skips the matches between two edits with one count-leading-zeros, and a
+// wave's trip count per path dword is the largest number of edits any of its lanes has in it, not 16.
+// Symbols are fetched for edits only (a deletion's or mismatch's genome letter, an insertion's read
+// letter), straight from memory: no staging, no LDS.
+// refine_ext_cigar (sam_matching.cpp:858-924) rewrites the string's first ". ^x . . #y ." or
+// ". #y . . ^x ." into three mismatches.  In operations that is: an indel whose predecessor is a match,
+// the opposite indel exactly three operations later with no edit in between, and a match behind it -
+// all of which is known at the NEXT edit (or at the end), where the six bytes are rewritten and
+// everything behind them moves down by three (nothing behind them has been written yet but dots).
+__global__ __launch_bounds__(256) void align_replay_kernel(GenomeView g, ReadsView rv, AlignParams ap)
+{
+    const uint32_t li = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t count = *ap.count;
+    if (li >= count)
+        return;
+    const uint32_t gid = ap.list[li];
+    const uint32_t* const path = ap.paths + (uint64_t)(li >> 6) * ap.path_dwords * 64u + (li & 63u);   // [16 steps][lane]
+    const wamd_align_result h = ap.results[gid];   // totals of the walk
+    uint8_t* const slot = ap.cigars + (uint64_t)gid * ap.cigar_stride;
+    const uint32_t nsteps = h.cigar_len;
+    bool valid = h.edit_distance != RESULT_ERROR;
+    if (valid && 2 * nsteps + 4 > ap.cigar_stride) {
+        raise_flag(ap.flags, FLAG_CIGAR);
+        valid = false;
+    }
+    if (!valid) {
+        wamd_align_result r{};
+        r.edit_distance = RESULT_ERROR;
+        ap.results[gid] = r;
+        slot[0] = 0;
+        return;
+    }
+    const wamd_dist_task task = ap.tasks[gid];
+    const wamd_dist_result d = ap.dist[gid];
+    const uint32_t m = rv.lens[task.read_idx];
+    const bool rev = task.flags & WAMD_TASK_FLAG_REV_COMP;
+    const uint8_t* const codes = rv.codes + rv.code_off[task.read_idx];
+    // decode = "ACGTNNXX" (LevMyers64.cpp:398)
+    auto decode = [](uint32_t c) -> uint32_t { return (uint32_t)(0x58584e4e54474341ull >> (8 * (c & 7u))) & 0xffu; };
+    auto genome_letter = [&](uint64_t gi) -> uint32_t {   // ref_copy_direct clamps to N_ref (sam.cpp:2372-2374)
+        const uint32_t x = (load_genome_dword(g, (uint32_t)(gi >> 3)) >> (4u * ((uint32_t)gi & 7u))) & 15u;
+        return decode(x > 5u ? 5u : x);
+    };
+    auto read_letter = [&](uint32_t q) -> uint32_t {   // oriented read symbol q; copy_direct / convert_to_rev_comp:
+        const uint32_t raw = packed_symbol(codes, rev ? m - 1 - q : q);   // anything but ACGT is N_read (sam.cpp:2296-2347)
+        const uint32_t c = rev ? rc_code(raw) : raw;
+        return decode((ap.ascii && c > 3u) ? 4u : c);
+    };
+
+    // ---- dots: the string has nsteps + (indels) <= nsteps + ed bytes -----------------------------
+    {
+        const uint32_t need = (nsteps + d.edit_distance + 1u + 3u) & ~3u;   // <= 2 nsteps + 4 <= cigar_stride
+        const wamd_u32x4 dots = {0x2e2e2e2eu, 0x2e2e2e2eu, 0x2e2e2e2eu, 0x2e2e2e2eu};
+#ifndef WAMD_EXP_NO_FILL
+        uint32_t b = 0;
+        for (; b + 16u <= need; b += 16u)
+            *reinterpret_cast<wamd_u32x4_a4*>(slot + b) = dots;
+        for (; b < need; b += 4u)
+            *reinterpret_cast<uint32_t*>(slot + b) = 0x2e2e2e2eu;
+#endif
+    }
+
+    uint32_t cur = 0, ri = 0, opi = 0;                          // next byte, next read symbol, next operation
+    uint64_t gi = (uint64_t)task.ref_pos + h.begin_pos;         // next genome symbol
+    // refinement: the last edit, the indel that may open the pattern, the pattern waiting for the match behind it
+    int32_t prev_t = -1;
+    bool open = false, pend = false;
+    uint32_t t1 = 0, k1 = 0, c1 = 0, t2 = 0, pc = 0, refined = 0;
+    uint64_t g1 = 0, pg = 0;
+    double score = h.affine_score;
+    uint32_t events = h.num_events;
+    auto refine_now = [&]() {
+        slot[pc + 0] = (uint8_t)genome_letter(pg);   // the three genome symbols under the four operations
+        slot[pc + 1] = (uint8_t)genome_letter(pg + 1);
+        slot[pc + 2] = (uint8_t)genome_letter(pg + 2);
+        slot[pc + 3] = '.';
+        slot[pc + 4] = '.';
+        slot[pc + 5] = '.';
+        cur -= 3;
+        refined = 1;
+        ++events;
+        score += 3 * ap.sc.mismatch;
+        score -= ap.sc.gap_ins_open + ap.sc.gap_del_open;
+    };
+
+    const uint32_t q_last = nsteps ? (nsteps - 1u) >> 4 : 0u;
+    uint32_t w_next = nsteps ? path[(uint64_t)q_last * 64u] : 0u;
+    for (uint32_t qq = 0; nsteps && qq <= q_last; ++qq) {
+        const uint32_t q = q_last - qq;
+        const uint32_t w = w_next;
+        if (q)
+            w_next = path[(uint64_t)(q - 1u) * 64u];   // in flight while this one is served
+        uint32_t left = q == q_last ? nsteps - 16u * q : 16u;   // steps of this dword, the highest field first
+        uint32_t wl = w << (2u * (16u - left));
+        while (wl) {
+            const uint32_t z = (uint32_t)__builtin_clz(wl) >> 1;   // matches before the edit
+            cur += z;
+            ri += z;
+            gi += z;
+            opi += z;
+            wl <<= 2u * z;
+            const uint32_t k = wl >> 30;
+            wl <<= 2;
+            left -= z + 1u;
+            if (ap.refine && !refined) {
+                if (pend) {
+                    pend = false;
+                    if (opi > t2 + 1u)   // a match behind the second indel
+                        refine_now();
+                }
+                const bool indel = k == DIR_H || k == DIR_V;
+                if (!refined && open && indel && opi == t1 + 3u && k != k1) {   // (no edit since t1: two matches between)
+                    pend = true;
+                    t2 = opi;
+                    pc = c1;
+                    pg = g1;
+                }
+                open = indel && (int32_t)opi - 1 > prev_t;   // its predecessor exists and is a match
+                t1 = opi;
+                k1 = k;
+                c1 = cur;
+                g1 = gi;
+                prev_t = (int32_t)opi;
+            }
+#ifndef WAMD_EXP_NO_EDITS
+            if (k == DIR_X) {
+                slot[cur] = (uint8_t)genome_letter(gi);
+                cur += 1;
+                ++ri;
+                ++gi;
+            } else if (k == DIR_H) {
+                slot[cur] = '^';
+                slot[cur + 1] = (uint8_t)genome_letter(gi);
+                cur += 2;
+                ++gi;
+            } else {
+                slot[cur] = '#';
+                slot[cur + 1] = (uint8_t)read_letter(ri);
+                cur += 2;
+                ++ri;
+            }
+#else
+            cur += k == DIR_X ? 1 : 2; ri += k != DIR_H; gi += k != DIR_V;
+#endif
+            ++opi;
+        }
+        cur += left;
+        ri += left;
+        gi += left;
+        opi += left;
+    }
+    if (pend && t2 + 1u < nsteps)
+        refine_now();
+    slot[cur] = 0;
+    wamd_align_result r;
+    r.affine_score = score;
+    r.ok = 1;
+    r.edit_distance = d.edit_distance;
+    r.end_pos = d.pos;
+    r.begin_pos = h.begin_pos;
+    r.num_events = events;
+    r.cigar_len = cur;
+    r.refined = refined;
+    r.reserved = 0;
+    ap.results[gid] = r;
+}
+
 // ---- host side -----------------------------------------------------------------------
 
 static inline uint64_t up256(uint64_t x) { return (x + 255) / 256 * 256; }
@@ -1145,9 +1317,7 @@ static int launch_tb(const GenomeView& g, const ReadsView& rv, AlignParams ap, u
 {
     if constexpr (WW == 0) {
         hipLaunchKernelGGL((align_traceback_kernel<NW, WW, BLOCK, 1>), dim3(blocks), dim3(BLOCK), 0, s, g, rv, ap);
-        const uint32_t b2 = groups < 256u * 32u ? (groups ? groups : 1u) : 256u * 32u;
-        hipLaunchKernelGGL((align_traceback_kernel<NW, WW, BLOCK, 2>), dim3(b2), dim3(BLOCK),
-                           (size_t)(ap.rd_cap + ap.gd_cap) * BLOCK * sizeof(uint32_t), s, g, rv, ap);
+        hipLaunchKernelGGL(align_replay_kernel, dim3((groups + 3u) / 4u ? (groups + 3u) / 4u : 1u), dim3(256), 0, s, g, rv, ap);
     } else {
         hipLaunchKernelGGL((align_traceback_kernel<NW, WW, BLOCK, 0>), dim3(blocks), dim3(BLOCK), 0, s, g, rv, ap);
     }
