@@ -240,3 +240,54 @@ def test_accepted_only_equals_exact_at_scale():
             reads.free()
     finally:
         c.destroy()
+
+
+@pytest.mark.parametrize("m,k,W,refine", [(150, 12, None, 1), (150, 13, 177, 0), (250, 17, None, 1), (100, 10, None, 1),
+                                          (150, 26, 660, 1), (300, 20, None, 1)])
+def test_align_takes_its_first_pass_in_the_contexts_mode(ctx, oracle, m, k, W, refine):
+    """getExtCigar only runs behind a dynamicProgramming that returned true (sam_matching.cpp:704-705): in
+    accepted-only mode every accepted task's alignment is the oracle's, byte for byte; a rejected task
+    comes back not ok with {k + 1, 0} and an empty string."""
+    codes, packed, (blob, off, lens), tasks = common.distance_workload(m, k, 5000, seed=1700 + m + k, encoding=1, W=W,
+                                                                      true_frac=0.6)
+    stride = 4 * ((2 * (m + k) + 8 + 3) // 4)
+    rc, want, wcig = oracle.align(packed, blob, off, lens, 1, tasks, 0, refine, cigar_stride=stride)
+    assert rc == 0
+    acc = want["ok"] == 1
+    assert acc.sum() > 1000 and (~acc).sum() > 500
+    reads = ctx.upload_reads(blob, off, lens, 1)
+    got, gcig = ctx.align(reads, tasks, 0, refine, cigar_stride=stride)
+    reads.free()
+    for f in want.dtype.names:
+        if f != "reserved":
+            np.testing.assert_array_equal(got[f][acc], want[f][acc], err_msg=f)
+    for i in np.flatnonzero(acc):
+        n = want["cigar_len"][i]
+        assert bytes(gcig[i, :n + 1]) == bytes(wcig[i, :n + 1]), i
+    rej = ~acc
+    assert (got["ok"][rej] == 0).all() and (got["edit_distance"][rej] == k + 1).all()
+    assert (got["end_pos"][rej] == 0).all() and (got["cigar_len"][rej] == 0).all() and (gcig[rej, 0] == 0).all()
+
+
+def test_finish_pairs_in_accepted_only_mode(ctx, oracle):
+    """wamd_finish_pairs re-verifies lev records with k = err_edit_distance (fill_cigar_with_lev,
+    sam_matching.cpp:689-752): the banded first pass gives the same SAM-visible output, and a record
+    that claims fewer errors than its read has fails the same way."""
+    from oracle import bindings as ob
+    (codes, packed), (blob, off, lens), desc, ridx, maps, direct, distant, stale = common.finish_workload(
+        oracle, 1500, 57, m=150, flank=6)
+    tasks = common.finish_tasks(desc, ridx, lens, maps, direct, distant, stale)
+    lev = np.nonzero((tasks["type"] == 0) & (tasks["err_edit_distance"] > 2))[0]
+    tasks["err_edit_distance"][lev[:20]] = 0
+    tasks["penalty"][lev[:20]] = 1
+    rc, *want = oracle.finish_pairs(packed, blob, off, lens, tasks, ob.default_finish_params(6), ext_stride=768)
+    assert rc == 0 and 0 < (want[0]["ok"] == 0).sum() <= 40
+    c = api.Context(packed, ref_size=codes.numel(), cur_offset=0)
+    try:
+        c.set_distance_mode(ACCEPTED_ONLY)
+        reads = c.upload_reads(blob, off, lens, 1, orientations=3)
+        got = c.finish_pairs(reads, tasks, api.default_finish_params(6), ext_stride=768)
+        common.same_finish_output(got, want)
+        reads.free()
+    finally:
+        c.destroy()

@@ -1091,25 +1091,60 @@ __global__ __launch_bounds__(256) void align_replay_kernel(GenomeView g, ReadsVi
 {
     const uint32_t li = blockIdx.x * 256u + threadIdx.x;
     const uint32_t count = *ap.count;
-    if (li >= count)
-        return;
-    const uint32_t gid = ap.list[li];
+    const bool inside = li < count;   // lanes behind the list's end still help with the dots
+    const uint32_t gid = inside ? ap.list[li] : 0u;
     const uint32_t* const path = ap.paths + (uint64_t)(li >> 6) * ap.path_dwords * 64u + (li & 63u);   // [16 steps][lane]
-    const wamd_align_result h = ap.results[gid];   // totals of the walk
+    wamd_align_result h{};   // totals of the walk
+    if (inside)
+        h = ap.results[gid];
     uint8_t* const slot = ap.cigars + (uint64_t)gid * ap.cigar_stride;
     const uint32_t nsteps = h.cigar_len;
-    bool valid = h.edit_distance != RESULT_ERROR;
+    bool valid = inside && h.edit_distance != RESULT_ERROR;
     if (valid && 2 * nsteps + 4 > ap.cigar_stride) {
         raise_flag(ap.flags, FLAG_CIGAR);
         valid = false;
     }
-    if (!valid) {
+    if (inside && !valid) {
         wamd_align_result r{};
         r.edit_distance = RESULT_ERROR;
         ap.results[gid] = r;
         slot[0] = 0;
-        return;
     }
+    // ---- dots: the string has nsteps + (indels) <= nsteps + ed bytes ------------------------------
+    // A lane filling its own slot would touch a line of its own with every store (64 lines per
+    // instruction).  The wave fills its 64 slots together instead: 16-byte block j of the wave belongs to
+    // slot j / nb, so neighbouring lanes write neighbouring blocks of one slot.
+    {
+        const uint32_t lane = threadIdx.x & 63u;
+        const uint32_t need = valid ? (nsteps + h.edit_distance + 1u + 3u) & ~3u : 0u;   // <= 2 nsteps + 4 <= cigar_stride
+        uint32_t need_max = need;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t other = (uint32_t)__shfl_xor((int)need_max, o);
+            need_max = other > need_max ? other : need_max;
+        }
+        const uint32_t nb = (need_max + 15u) >> 4;            // blocks per slot (wave-uniform)
+        const uint32_t inv = nb ? (1u << 20) / nb + 1u : 0u;   // j / nb = (j * inv) >> 20 for j < 64 nb <= 2^13
+        const wamd_u32x4 dots = {0x2e2e2e2eu, 0x2e2e2e2eu, 0x2e2e2e2eu, 0x2e2e2e2eu};
+        for (uint32_t i = 0; i < nb; ++i) {
+            const uint32_t j = i * 64u + lane;
+            const uint32_t t = (j * inv) >> 20;
+            const uint32_t off = (j - t * nb) * 16u;
+            const uint32_t t_need = (uint32_t)__shfl((int)need, (int)t);
+            const uint32_t t_gid = (uint32_t)__shfl((int)gid, (int)t);
+            uint8_t* const dst = ap.cigars + (uint64_t)t_gid * ap.cigar_stride + off;
+            if (off + 16u <= t_need) {
+                *reinterpret_cast<wamd_u32x4_a4*>(dst) = dots;
+            } else {
+                for (uint32_t b = off; b < t_need; b += 4u)
+                    *reinterpret_cast<uint32_t*>(dst + (b - off)) = 0x2e2e2e2eu;
+            }
+        }
+        // the edits below overwrite bytes that other lanes have just written: those stores first
+        __threadfence_block();
+    }
+    if (!valid)
+        return;
     const wamd_dist_task task = ap.tasks[gid];
     const wamd_dist_result d = ap.dist[gid];
     const uint32_t m = rv.lens[task.read_idx];
@@ -1121,24 +1156,7 @@ __global__ __launch_bounds__(256) void align_replay_kernel(GenomeView g, ReadsVi
         const uint32_t x = (load_genome_dword(g, (uint32_t)(gi >> 3)) >> (4u * ((uint32_t)gi & 7u))) & 15u;
         return decode(x > 5u ? 5u : x);
     };
-    auto read_letter = [&](uint32_t q) -> uint32_t {   // oriented read symbol q; copy_direct / convert_to_rev_comp:
-        const uint32_t raw = packed_symbol(codes, rev ? m - 1 - q : q);   // anything but ACGT is N_read (sam.cpp:2296-2347)
-        const uint32_t c = rev ? rc_code(raw) : raw;
-        return decode((ap.ascii && c > 3u) ? 4u : c);
-    };
-
-    // ---- dots: the string has nsteps + (indels) <= nsteps + ed bytes -----------------------------
-    {
-        const uint32_t need = (nsteps + d.edit_distance + 1u + 3u) & ~3u;   // <= 2 nsteps + 4 <= cigar_stride
-        const wamd_u32x4 dots = {0x2e2e2e2eu, 0x2e2e2e2eu, 0x2e2e2e2eu, 0x2e2e2e2eu};
-#ifndef WAMD_EXP_NO_FILL
-        uint32_t b = 0;
-        for (; b + 16u <= need; b += 16u)
-            *reinterpret_cast<wamd_u32x4_a4*>(slot + b) = dots;
-        for (; b < need; b += 4u)
-            *reinterpret_cast<uint32_t*>(slot + b) = 0x2e2e2e2eu;
-#endif
-    }
+    const uint32_t* const code_dwords = reinterpret_cast<const uint32_t*>(codes);   // reads start on dwords (reads_prepare.hip)
 
     uint32_t cur = 0, ri = 0, opi = 0;                          // next byte, next read symbol, next operation
     uint64_t gi = (uint64_t)task.ref_pos + h.begin_pos;         // next genome symbol
@@ -1202,26 +1220,22 @@ __global__ __launch_bounds__(256) void align_replay_kernel(GenomeView g, ReadsVi
                 g1 = gi;
                 prev_t = (int32_t)opi;
             }
-#ifndef WAMD_EXP_NO_EDITS
-            if (k == DIR_X) {
-                slot[cur] = (uint8_t)genome_letter(gi);
-                cur += 1;
-                ++ri;
-                ++gi;
-            } else if (k == DIR_H) {
-                slot[cur] = '^';
-                slot[cur + 1] = (uint8_t)genome_letter(gi);
-                cur += 2;
-                ++gi;
-            } else {
-                slot[cur] = '#';
-                slot[cur + 1] = (uint8_t)read_letter(ri);
-                cur += 2;
-                ++ri;
-            }
-#else
-            cur += k == DIR_X ? 1 : 2; ri += k != DIR_H; gi += k != DIR_V;
-#endif
+            // one fetch whatever the edit: the genome dword of a mismatch or deletion, the code dword of an insertion
+            const bool ins = k == DIR_V;
+            const uint64_t at = ins ? (uint64_t)(rev ? m - 1u - ri : ri) : gi;
+            const uint32_t dw = (uint32_t)(at >> 3);
+            const uint32_t* const src = ins ? code_dwords + dw : g.dwords + (dw < g.last_dword ? dw : g.last_dword);
+            const uint32_t sym = (nibble_swap(*src) >> (4u * ((uint32_t)at & 7u))) & 15u;
+            const uint32_t oriented = rev ? rc_code(sym) : sym;
+            // copy_direct / convert_to_rev_comp: anything but ACGT is N_read (sam.cpp:2296-2347);
+            // ref_copy_direct clamps to N_ref (sam.cpp:2372-2374)
+            const uint32_t letter = decode(ins ? ((ap.ascii && oriented > 3u) ? 4u : oriented) : (sym > 5u ? 5u : sym));
+            slot[cur] = (uint8_t)(k == DIR_X ? letter : (ins ? (uint32_t)'#' : (uint32_t)'^'));
+            if (k != DIR_X)
+                slot[cur + 1] = (uint8_t)letter;
+            cur += k == DIR_X ? 1u : 2u;
+            ri += k != DIR_H ? 1u : 0u;
+            gi += ins ? 0u : 1u;
             ++opi;
         }
         cur += left;
@@ -1361,7 +1375,10 @@ int launch_align(wamd_ctx* ctx, const wamd_reads* r, const wamd_dist_task* d_tas
     int rc = ensure_pm(r, s);   // the wide classes read the 64-bit vectors
     if (rc != WAMD_OK)
         return rc;
-    rc = launch_distance(ctx, r, d_tasks, n, last_symbol, d_dist, WAMD_DISTANCE_EXACT, s);
+    // pass 1 follows the context's distance mode: fill_cigar_with_lev and find_pairs only go on when
+    // dynamicProgramming returned true (sam_matching.cpp:704-705), so in accepted-only mode the rejected
+    // tasks come back as {k + 1, 0}, not ok, from the banded kernels
+    rc = launch_distance(ctx, r, d_tasks, n, last_symbol, d_dist, ctx->distance_mode, s);
     if (rc)
         return rc;
     const ReadsView rv = r->view();
