@@ -312,8 +312,26 @@ def run_extras(ctx, device, genome_symbols, stream, n_small):
                           "kernel_ms": ms, "candidates_per_s": n / ms * 1e3,
                           "pass_fraction": float((d_rc.cpu().numpy().view(np.uint32) <= 20).mean()),
                           "roofline": roof_hbm(n, 2 * q(150) + 16 + 4, ms, "cf_filter_kernel")}
+    # the loop body as one call: filter, survivors packed into full waves, LevDiag on those (mapping_core_sa.cpp:223-255)
+    d_t = dev_bytes(t)
+    d_r = torch.zeros(n, dtype=torch.int32, device=device)
+    d_r2 = torch.zeros(n, dtype=torch.int32, device=device)
+    fwb = ctx.filter_verify_workspace_bytes(n)
+    d_fw = torch.zeros(fwb + 256, dtype=torch.uint8, device=device)
+    padf = (-d_fw.data_ptr()) % 256
+    ms_f = timed(lambda: ctx.filter_levdiag_dev(reads, d_tc, d_t, n, d_r2, d_fw[padf:], fwb), tag="F_filter_levdiag", units=n)
+    ctx.lev_diag_dev(reads, d_t, n, d_r)
+    ctx.synchronize()
+    passed = d_rc.cpu().numpy().view(np.uint32) <= 20
+    alone, fused = d_r.cpu().numpy().view(np.uint32), d_r2.cpu().numpy().view(np.uint32)
+    out["F_filter_levdiag"] = {"shape": "CF pre-filter -> pack -> LevDiag on the survivors -> unpack, S2's candidates, one call",
+                               "tasks": n, "total_ms": ms_f, "candidates_per_s": n / ms_f * 1e3,
+                               "separate_calls_ms": out["C_cf_filter"]["kernel_ms"] + out["S2_levdiag"]["kernel_ms"],
+                               "same_as_separate_calls": bool((fused == np.where(passed, alone, 6)).all()),
+                               "roofline": roof_hbm(n, 2 * q(150) + 16 + 16 + 4 + float(passed.mean()) * (80 + q(161) + 2 * 20), ms_f,
+                                                    "filter_pack_kernel + levdiag_band_kernel + filter_unpack_kernel")}
     reads.free()
-    del d_tc, d_rc
+    del d_tc, d_rc, d_t, d_r, d_r2, d_fw
 
     # S5: LevMyers256 distance, m = 250, k = 17, W = 284 (8 dwords per vector)
     rd = synth.make_reads(codes, n, 250, 17, 78, chunk=1 << 16)

@@ -354,6 +354,28 @@ WAMD_API int wamd_cf_filter(wamd_ctx* ctx, const wamd_reads* reads, const wamd_c
 WAMD_API int wamd_cf_filter_dev(wamd_ctx* ctx, const wamd_reads* reads, const wamd_cf_task* d_tasks,
                                 uint32_t n, uint32_t* d_results, void* stream);
 
+/* ---- the filter in front of its verifier: one iteration of the suffix-array loops' body ---- *
+ * mapping_core_sa.cpp:223-255 / 279-307 (and :388-460 of the variable-length version):
+ *     if (is_short_read || test_CF_128b_SSE_difference(..., 4 * max_mismatches))
+ *         cur_match = dynamicProgramming(...) or LevDiag(...);
+ *     else
+ *         cur_match = max_mismatches + 1;
+ * cf_tasks[i] and tasks[i] describe candidate i exactly as wamd_cf_filter and wamd_verify_distance /
+ * wamd_levdiag take them; a CF task with pattern_len == 0 is a short read (no filter, always verified).
+ * results[i] is the verifier's answer for a candidate the filter passed and {max_ed + 1, 0}
+ * (max_mismatches + 1 for LevDiag) for one it turned away.  The verifier only runs on the survivors,
+ * packed into full waves on the device; wamd_filter_verify_distance_dev follows the context's distance
+ * mode like wamd_verify_distance.  d_workspace: wamd_filter_verify_workspace_bytes(n) bytes (28 n + 1 KB),
+ * 256-byte aligned, the caller's; nothing is allocated and nothing synchronises. */
+WAMD_API uint64_t wamd_filter_verify_workspace_bytes(uint32_t n);
+WAMD_API int wamd_filter_verify_distance_dev(wamd_ctx* ctx, const wamd_reads* reads, const wamd_cf_task* d_cf_tasks,
+                                             const wamd_dist_task* d_tasks, uint32_t n, int last_symbol,
+                                             wamd_dist_result* d_results, void* d_workspace, uint64_t workspace_bytes,
+                                             void* stream);
+WAMD_API int wamd_filter_levdiag_dev(wamd_ctx* ctx, const wamd_reads* reads, const wamd_cf_task* d_cf_tasks,
+                                     const wamd_levdiag_task* d_tasks, uint32_t n, uint32_t* d_results,
+                                     void* d_workspace, uint64_t workspace_bytes, void* stream);
+
 /* ---- verification with alignment (post-processing) --------------------- *
  * dynamicProgramming + getExtCigar (+ refine_ext_cigar when refine != 0) as in
  * fill_cigar_with_lev (sam_matching.cpp:689-752) and find_pairs<LevMyers>

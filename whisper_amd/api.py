@@ -126,6 +126,7 @@ EXPORTS = [
     "wamd_comm_get_unique_id", "wamd_comm_create", "wamd_comm_create_all", "wamd_comm_destroy",
     "wamd_gather_records_dev", "wamd_gather_records_all", "wamd_commit_candidates_dev",
     "wamd_result_groups_workspace_bytes", "wamd_emit_result_groups_dev",
+    "wamd_filter_verify_workspace_bytes", "wamd_filter_verify_distance_dev", "wamd_filter_levdiag_dev",
 ]
 
 
@@ -171,6 +172,7 @@ def lib():
         L.wamd_records_scratch_bytes.restype = C.c_uint64
         L.wamd_finish_workspace_bytes.restype = C.c_uint64
         L.wamd_result_groups_workspace_bytes.restype = C.c_uint64
+        L.wamd_filter_verify_workspace_bytes.restype = C.c_uint64
         _lib = L
     return _lib
 
@@ -295,6 +297,22 @@ class Context:
     def cf_filter_dev(self, reads, d_tasks, n, d_results, stream=None):
         _check(lib().wamd_cf_filter_dev(self.h, reads.h, _ptr(d_tasks), C.c_uint32(n), _ptr(d_results),
                                         C.c_void_p(stream or 0)))
+
+    def filter_verify_workspace_bytes(self, n):
+        return int(lib().wamd_filter_verify_workspace_bytes(C.c_uint32(n)))
+
+    def filter_verify_distance_dev(self, reads, d_cf_tasks, d_tasks, n, d_results, d_ws, ws_bytes, last_symbol=-1,
+                                   stream=None):
+        """CF pre-filter, then dynamicProgramming on the candidates it passes (mapping_core_sa.cpp:223-255)."""
+        _check(lib().wamd_filter_verify_distance_dev(self.h, reads.h, _ptr(d_cf_tasks), _ptr(d_tasks), C.c_uint32(n),
+                                                     C.c_int(last_symbol), _ptr(d_results), _ptr(d_ws),
+                                                     C.c_uint64(ws_bytes), C.c_void_p(stream or 0)))
+
+    def filter_levdiag_dev(self, reads, d_cf_tasks, d_tasks, n, d_results, d_ws, ws_bytes, stream=None):
+        """CF pre-filter, then LevDiag on the candidates it passes (mapping_core_sa.cpp:230-239)."""
+        _check(lib().wamd_filter_levdiag_dev(self.h, reads.h, _ptr(d_cf_tasks), _ptr(d_tasks), C.c_uint32(n),
+                                             _ptr(d_results), _ptr(d_ws), C.c_uint64(ws_bytes),
+                                             C.c_void_p(stream or 0)))
 
     def align(self, reads, tasks, last_symbol=0, refine=1, cigar_stride=1024):
         tasks = np.ascontiguousarray(tasks, DIST_TASK)

@@ -85,16 +85,13 @@ __device__ __forceinline__ void count_pairs(Load load, Load4 load4, int32_t lo1,
     }
 }
 
-__global__ __launch_bounds__(256) void cf_filter_kernel(GenomeView g, ReadsView rv,
-                                                        const wamd_cf_task* __restrict__ tasks, uint32_t n,
-                                                        uint32_t ref_size, uint32_t cur_offset,
-                                                        uint32_t* __restrict__ results, uint32_t* __restrict__ flags)
+// The filter's answer for one candidate: the L1 distance of the two histograms as the reference's
+// horizontal_add leaves it; `err` (FLAG_*) when the task is malformed.
+__device__ __forceinline__ uint32_t cf_value(const GenomeView& g, const ReadsView& rv, const wamd_cf_task& t,
+                                             uint32_t ref_size, uint32_t cur_offset, uint32_t& err)
 {
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= n)
-        return;
-    const wamd_cf_task t = tasks[gid];
-    uint32_t err = 0, m = 0, left_end = 0;
+    err = 0;
+    uint32_t m = 0, left_end = 0;
     const uint32_t plen = t.pattern_len, fl = t.fixed_left, fr = t.fixed_right;
     if (t.read_idx >= rv.n) {
         err = FLAG_READ_IDX;
@@ -107,11 +104,8 @@ __global__ __launch_bounds__(256) void cf_filter_kernel(GenomeView g, ReadsView 
         else if ((uint64_t)left_end + plen + 1 > g.n_symbols)
             err = FLAG_RANGE;
     }
-    if (err) {
-        raise_flag(flags, err);
-        results[gid] = RESULT_ERROR;
-        return;
-    }
+    if (err)
+        return RESULT_ERROR;
 
     // pair starts of the two regions, relative to the window's first symbol
     const int32_t p_lo1 = 0, p_hi1 = fl ? (int32_t)fl - 1 : 0;
@@ -173,7 +167,187 @@ __global__ __launch_bounds__(256) void cf_filter_kernel(GenomeView g, ReadsView 
         const int32_t a = (int32_t)min(cr[i], 127u), b = (int32_t)min(cg[i], 127u);
         sum += (uint32_t)(a > b ? a - b : b - a);
     }
-    results[gid] = (uint32_t)(int32_t)(int8_t)(sum & 0xffu);
+    return (uint32_t)(int32_t)(int8_t)(sum & 0xffu);
+}
+
+__global__ __launch_bounds__(256) void cf_filter_kernel(GenomeView g, ReadsView rv,
+                                                        const wamd_cf_task* __restrict__ tasks, uint32_t n,
+                                                        uint32_t ref_size, uint32_t cur_offset,
+                                                        uint32_t* __restrict__ results, uint32_t* __restrict__ flags)
+{
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n)
+        return;
+    uint32_t err;
+    const uint32_t v = cf_value(g, rv, tasks[gid], ref_size, cur_offset, err);
+    if (err)
+        raise_flag(flags, err);
+    results[gid] = v;
+}
+
+// =============================================================================================
+// The filter in front of its verifier, as the suffix-array loops have it (mapping_core_sa.cpp:223-255,
+// 279-307, 388-460): a candidate reaches dynamicProgramming / LevDiag only when the filter passes it,
+// cur_match = max_mismatches + 1 otherwise.  One candidate per lane cannot skip work for the lanes the
+// filter turns away - the wave runs as long as its slowest lane - so the survivors are packed first:
+//   filter_pack_kernel    CF decision per candidate; rejected ones get their final answer, passed ones
+//                         are copied (verifier task + index) to the front of a list, in task order inside
+//                         a block, blocks in the order they arrive (results go back by index, so the
+//                         answers do not depend on that order);
+//   the verifier's own kernels over the list, its length read from the device (n_dev);
+//   filter_unpack_kernel  answers back to their candidates' slots.
+// A CF task with pattern_len == 0 is the loops' is_short_read: no filter, always verified.
+// =============================================================================================
+template <class VTask>
+__device__ __forceinline__ uint32_t verifier_budget(const VTask& t);
+template <>
+__device__ __forceinline__ uint32_t verifier_budget<wamd_dist_task>(const wamd_dist_task& t) { return t.max_ed; }
+template <>
+__device__ __forceinline__ uint32_t verifier_budget<wamd_levdiag_task>(const wamd_levdiag_task& t) { return t.max_mismatches; }
+
+__device__ __forceinline__ void store_rejected(wamd_dist_result* results, uint32_t i, uint32_t value, uint32_t pos)
+{
+    results[i].edit_distance = value;
+    results[i].pos = pos;
+}
+__device__ __forceinline__ void store_rejected(uint32_t* results, uint32_t i, uint32_t value, uint32_t) { results[i] = value; }
+
+template <class VTask, class VResult>
+__global__ __launch_bounds__(256) void filter_pack_kernel(GenomeView g, ReadsView rv, const wamd_cf_task* __restrict__ cf_tasks,
+                                                          const VTask* __restrict__ v_tasks, uint32_t n, uint32_t ref_size,
+                                                          uint32_t cur_offset, VResult* __restrict__ results,
+                                                          VTask* __restrict__ packed_tasks, uint32_t* __restrict__ packed_idx,
+                                                          uint32_t* __restrict__ count, uint32_t* __restrict__ flags)
+{
+    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+    bool pass = false;
+    VTask vt{};
+    if (gid < n) {
+        const wamd_cf_task ct = cf_tasks[gid];
+        vt = v_tasks[gid];
+        const uint32_t k = verifier_budget<VTask>(vt);
+        if (ct.pattern_len == 0) {
+            pass = true;
+        } else {
+            uint32_t err;
+            const uint32_t v = cf_value(g, rv, ct, ref_size, cur_offset, err);
+            if (err) {
+                raise_flag(flags, err);
+                store_rejected(results, gid, RESULT_ERROR, err);
+            } else if (v <= 4u * k) {   // test_CF_128b_SSE_difference(..., 4 * max_mismatches), mapping_core.h:260-263
+                pass = true;
+            } else {
+                store_rejected(results, gid, k + 1u, 0u);
+            }
+        }
+    }
+    __shared__ uint32_t wave_cnt[4];
+    __shared__ uint32_t block_base;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint64_t mask = __ballot(pass);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+    if (lane == 0)
+        wave_cnt[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < 4; ++w) {
+            const uint32_t c = wave_cnt[w];
+            wave_cnt[w] = total;
+            total += c;
+        }
+        block_base = total ? atomicAdd(count, total) : 0u;
+    }
+    __syncthreads();
+    if (pass) {
+        const uint32_t slot = block_base + wave_cnt[wave] + rank;
+        packed_tasks[slot] = vt;
+        packed_idx[slot] = gid;
+    }
+}
+
+template <class VResult>
+__global__ __launch_bounds__(256) void filter_unpack_kernel(const VResult* __restrict__ packed_results,
+                                                            const uint32_t* __restrict__ packed_idx,
+                                                            const uint32_t* __restrict__ count, VResult* __restrict__ results)
+{
+    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    if (slot < *count)
+        results[packed_idx[slot]] = packed_results[slot];
+}
+
+// workspace: [count, 256 B][packed tasks][packed results][packed indices], every part 256-byte aligned
+struct FilterLayout {
+    uint64_t tasks, results, idx, total;
+};
+static FilterLayout filter_layout(uint32_t n, uint64_t task_bytes, uint64_t result_bytes)
+{
+    auto up = [](uint64_t x) { return (x + 255u) & ~255ull; };
+    FilterLayout l;
+    l.tasks = 256;
+    l.results = l.tasks + up((uint64_t)n * task_bytes);
+    l.idx = l.results + up((uint64_t)n * result_bytes);
+    l.total = l.idx + up((uint64_t)n * 4u);
+    return l;
+}
+
+uint64_t filter_verify_workspace_bytes(uint32_t n)
+{
+    static_assert(sizeof(wamd_dist_task) >= sizeof(wamd_levdiag_task) && sizeof(wamd_dist_result) >= sizeof(uint32_t),
+                  "one size serves both verifiers");
+    return filter_layout(n, sizeof(wamd_dist_task), sizeof(wamd_dist_result)).total;
+}
+
+int launch_filter_distance(wamd_ctx* ctx, const wamd_reads* r, const wamd_cf_task* d_cf, const wamd_dist_task* d_tasks,
+                           uint32_t n, int last_symbol, wamd_dist_result* d_results, void* d_ws, hipStream_t s)
+{
+    WAMD_HIP(hipSetDevice(ctx->device));
+    if (n == 0)
+        return WAMD_OK;
+    const FilterLayout l = filter_layout(n, sizeof(wamd_dist_task), sizeof(wamd_dist_result));
+    char* ws = (char*)d_ws;
+    uint32_t* count = (uint32_t*)ws;
+    auto* p_tasks = (wamd_dist_task*)(ws + l.tasks);
+    auto* p_res = (wamd_dist_result*)(ws + l.results);
+    auto* p_idx = (uint32_t*)(ws + l.idx);
+    WAMD_HIP(hipMemsetAsync(count, 0, sizeof(uint32_t), s));
+    const uint32_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL((filter_pack_kernel<wamd_dist_task, wamd_dist_result>), dim3(blocks), dim3(256), 0, s, genome_view(ctx),
+                       r->view(), d_cf, d_tasks, n, ctx->ref_size, ctx->cur_offset, d_results, p_tasks, p_idx, count,
+                       ctx->d_flags);
+    WAMD_HIP(hipGetLastError());
+    const int rc = launch_distance(ctx, r, p_tasks, n, last_symbol, p_res, ctx->distance_mode, s, count);
+    if (rc)
+        return rc;
+    hipLaunchKernelGGL((filter_unpack_kernel<wamd_dist_result>), dim3(blocks), dim3(256), 0, s, p_res, p_idx, count, d_results);
+    WAMD_HIP(hipGetLastError());
+    return WAMD_OK;
+}
+
+int launch_filter_levdiag(wamd_ctx* ctx, const wamd_reads* r, const wamd_cf_task* d_cf, const wamd_levdiag_task* d_tasks,
+                          uint32_t n, uint32_t* d_results, void* d_ws, hipStream_t s)
+{
+    WAMD_HIP(hipSetDevice(ctx->device));
+    if (n == 0)
+        return WAMD_OK;
+    const FilterLayout l = filter_layout(n, sizeof(wamd_dist_task), sizeof(wamd_dist_result));
+    char* ws = (char*)d_ws;
+    uint32_t* count = (uint32_t*)ws;
+    auto* p_tasks = (wamd_levdiag_task*)(ws + l.tasks);
+    auto* p_res = (uint32_t*)(ws + l.results);
+    auto* p_idx = (uint32_t*)(ws + l.idx);
+    WAMD_HIP(hipMemsetAsync(count, 0, sizeof(uint32_t), s));
+    const uint32_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL((filter_pack_kernel<wamd_levdiag_task, uint32_t>), dim3(blocks), dim3(256), 0, s, genome_view(ctx),
+                       r->view(), d_cf, d_tasks, n, ctx->ref_size, ctx->cur_offset, d_results, p_tasks, p_idx, count,
+                       ctx->d_flags);
+    WAMD_HIP(hipGetLastError());
+    const int rc = launch_levdiag(ctx, r, p_tasks, n, p_res, s, count);
+    if (rc)
+        return rc;
+    hipLaunchKernelGGL((filter_unpack_kernel<uint32_t>), dim3(blocks), dim3(256), 0, s, p_res, p_idx, count, d_results);
+    WAMD_HIP(hipGetLastError());
+    return WAMD_OK;
 }
 
 int launch_cf_filter(wamd_ctx* ctx, const wamd_reads* r, const wamd_cf_task* d_tasks, uint32_t n,

@@ -119,13 +119,15 @@ __global__ __launch_bounds__(BLOCK) void levdiag_kernel(GenomeView g, ReadsView 
                                                         const wamd_levdiag_task* __restrict__ tasks, uint32_t n,
                                                         uint32_t ref_size, uint32_t cur_offset,
                                                         uint32_t* __restrict__ results, uint32_t* __restrict__ flags,
-                                                        int chained)
+                                                        int chained, const uint32_t* __restrict__ n_dev)
 {
     constexpr int GW = PW + 2;
     __shared__ uint32_t pat_lds[PW * BLOCK];   // [dword][lane]: pad, read symbols, pad
     __shared__ uint32_t gen_lds[GW * BLOCK];   // [dword][lane]: pad, window of m + 2k + 1 symbols, pad
 
     const uint32_t tid = threadIdx.x;
+    if (n_dev)   // the batch is a compacted list whose length only the device knows (cf_filter.hip)
+        n = min(n, *n_dev);
     // (a chained launch walks the batch with a small grid: almost every wave only looks at its results and moves on.
     //  No barriers below, and a lane only ever touches its own LDS column, so waves loop independently.)
     for (uint32_t base = blockIdx.x * BLOCK; base < n; base += gridDim.x * BLOCK) {
@@ -660,37 +662,43 @@ template <int NW, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void levdiag_band_kernel(GenomeView g, ReadsView rv,
                                                              const wamd_levdiag_task* __restrict__ tasks, uint32_t n,
                                                              uint32_t ref_size, uint32_t cur_offset,
-                                                             uint32_t* __restrict__ results, uint32_t* __restrict__ flags)
+                                                             uint32_t* __restrict__ results, uint32_t* __restrict__ flags,
+                                                             const uint32_t* __restrict__ n_dev)
 {
     __shared__ uint32_t pm_lds[(NW + 2 * LDB_PAD) * 3 * BLOCK];
+    if (n_dev) {
+        n = min(n, *n_dev);
+        if (blockIdx.x * BLOCK >= n)
+            return;
+    }
     levdiag_band_body<NW, BLOCK, true>(g, rv, tasks, n, ref_size, cur_offset, results, flags, pm_lds);
 }
 template <int NW, int BLOCK>
 static int launch_ld_band(wamd_ctx* ctx, const wamd_reads* r, const wamd_levdiag_task* d_tasks, uint32_t n,
-                          uint32_t* d_results, hipStream_t s)
+                          uint32_t* d_results, hipStream_t s, const uint32_t* n_dev)
 {
     const uint32_t blocks = (n + BLOCK - 1) / BLOCK;
     hipLaunchKernelGGL((levdiag_band_kernel<NW, BLOCK>), dim3(blocks), dim3(BLOCK), 0, s, genome_view(ctx), r->view(),
-                       d_tasks, n, ctx->ref_size, ctx->cur_offset, d_results, ctx->d_flags);
+                       d_tasks, n, ctx->ref_size, ctx->cur_offset, d_results, ctx->d_flags, n_dev);
     WAMD_HIP(hipGetLastError());
     return WAMD_OK;
 }
 
 template <int PW, int BLOCK>
 static int launch_ld(wamd_ctx* ctx, const wamd_reads* r, const wamd_levdiag_task* d_tasks, uint32_t n,
-                     uint32_t* d_results, hipStream_t s, int chained = 0)
+                     uint32_t* d_results, hipStream_t s, const uint32_t* n_dev, int chained = 0)
 {
     uint32_t blocks = (n + BLOCK - 1) / BLOCK;
     if (chained && blocks > 1024)
         blocks = 1024;
     hipLaunchKernelGGL((levdiag_kernel<PW, BLOCK>), dim3(blocks), dim3(BLOCK), 0, s, genome_view(ctx), r->view(),
-                       d_tasks, n, ctx->ref_size, ctx->cur_offset, d_results, ctx->d_flags, chained);
+                       d_tasks, n, ctx->ref_size, ctx->cur_offset, d_results, ctx->d_flags, chained, n_dev);
     WAMD_HIP(hipGetLastError());
     return WAMD_OK;
 }
 
 int launch_levdiag(wamd_ctx* ctx, const wamd_reads* r, const wamd_levdiag_task* d_tasks, uint32_t n,
-                   uint32_t* d_results, hipStream_t s)
+                   uint32_t* d_results, hipStream_t s, const uint32_t* n_dev)
 {
     WAMD_HIP(hipSetDevice(ctx->device));
     if (n == 0)
@@ -701,18 +709,18 @@ int launch_levdiag(wamd_ctx* ctx, const wamd_reads* r, const wamd_levdiag_task* 
     // run-extension kernel for the lanes it deferred (none in practice: 16 us)
     const bool band = (r->orientations & 1) && r->max_len <= 256 && !getenv("WAMD_LEVDIAG_RUNS");
     if (band) {
-        int rc = r->words32 <= 5 ? launch_ld_band<5, 128>(ctx, r, d_tasks, n, d_results, s)
-                                 : launch_ld_band<8, 128>(ctx, r, d_tasks, n, d_results, s);
+        int rc = r->words32 <= 5 ? launch_ld_band<5, 128>(ctx, r, d_tasks, n, d_results, s, n_dev)
+                                 : launch_ld_band<8, 128>(ctx, r, d_tasks, n, d_results, s, n_dev);
         if (rc)
             return rc;
     }
     if (need <= 22)
-        return launch_ld<22, 256>(ctx, r, d_tasks, n, d_results, s, band);   // reads up to 160 symbols
+        return launch_ld<22, 256>(ctx, r, d_tasks, n, d_results, s, n_dev, band);   // reads up to 160 symbols
     if (need <= 34)
-        return launch_ld<34, 128>(ctx, r, d_tasks, n, d_results, s, band);   // up to 256
+        return launch_ld<34, 128>(ctx, r, d_tasks, n, d_results, s, n_dev, band);   // up to 256
     if (need <= 66)
-        return launch_ld<66, 64>(ctx, r, d_tasks, n, d_results, s);    // up to 512
-    return launch_ld<130, 64>(ctx, r, d_tasks, n, d_results, s);       // up to 1024
+        return launch_ld<66, 64>(ctx, r, d_tasks, n, d_results, s, n_dev);    // up to 512
+    return launch_ld<130, 64>(ctx, r, d_tasks, n, d_results, s, n_dev);       // up to 1024
 }
 
 } // namespace wamd

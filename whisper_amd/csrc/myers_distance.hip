@@ -549,13 +549,19 @@ template <int NW, int BLOCK>
 __global__ __launch_bounds__(BLOCK) WAMD_KATTR void myers_distance_kernel(
     GenomeView g, ReadsView rv, const wamd_dist_task* __restrict__ tasks, uint32_t n,
     int last_symbol, uint32_t max_text_len, wamd_dist_result* __restrict__ results,
-    uint32_t* __restrict__ flags, int chained, const uint32_t* __restrict__ only_deferred, int clamp)
+    uint32_t* __restrict__ flags, int chained, const uint32_t* __restrict__ only_deferred, int clamp,
+    const uint32_t* __restrict__ n_dev)
 {
     // [dword][symbol A,C,G,T][lane]
     __shared__ uint32_t pm_lds[NW * 4 * BLOCK];
 
     if (only_deferred && *only_deferred == 0)
         return;
+    if (n_dev) {   // the batch is a compacted list whose length only the device knows (cf_filter.hip)
+        n = min(n, *n_dev);
+        if (blockIdx.x * BLOCK >= n)
+            return;
+    }
     const uint32_t tid = threadIdx.x;
     const uint32_t gid = blockIdx.x * BLOCK + tid;
     bool valid = gid < n;
@@ -775,7 +781,8 @@ template <int NB, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void myers_band_kernel(
     GenomeView g, ReadsView rv, const wamd_dist_task* __restrict__ tasks, uint32_t n, int last_symbol,
     uint32_t max_text_len, wamd_dist_result* __restrict__ results, uint32_t* __restrict__ flags,
-    int chained, const uint32_t* __restrict__ only_deferred, uint32_t* __restrict__ deferred)
+    int chained, const uint32_t* __restrict__ only_deferred, uint32_t* __restrict__ deferred,
+    const uint32_t* __restrict__ n_dev)
 {
     // [the read's words32 dwords][A,C,G,T][lane], as in the exact kernel
     extern __shared__ uint32_t pm_band[];
@@ -783,6 +790,11 @@ __global__ __launch_bounds__(BLOCK) void myers_band_kernel(
 
     if (only_deferred && *only_deferred == 0)
         return;
+    if (n_dev) {
+        n = min(n, *n_dev);
+        if (blockIdx.x * BLOCK >= n)
+            return;
+    }
     const uint32_t tid = threadIdx.x;
     const uint32_t gid = blockIdx.x * BLOCK + tid;
     bool valid = gid < n;
@@ -976,11 +988,12 @@ __global__ __launch_bounds__(BLOCK) void myers_band_kernel(
 template <int NW, int BLOCK>
 static int launch_one(const GenomeView& g, const ReadsView& rv, const wamd_dist_task* d_tasks,
                       uint32_t n, int last_symbol, uint32_t max_text_len, wamd_dist_result* d_results,
-                      uint32_t* d_flags, int chained, const uint32_t* only_deferred, int clamp, hipStream_t s)
+                      uint32_t* d_flags, int chained, const uint32_t* only_deferred, int clamp, const uint32_t* n_dev,
+                      hipStream_t s)
 {
     const uint32_t blocks = (n + BLOCK - 1) / BLOCK;
     hipLaunchKernelGGL((myers_distance_kernel<NW, BLOCK>), dim3(blocks), dim3(BLOCK), 0, s, g, rv,
-                       d_tasks, n, last_symbol, max_text_len, d_results, d_flags, chained, only_deferred, clamp);
+                       d_tasks, n, last_symbol, max_text_len, d_results, d_flags, chained, only_deferred, clamp, n_dev);
     WAMD_HIP(hipGetLastError());
     return WAMD_OK;
 }
@@ -988,7 +1001,7 @@ static int launch_one(const GenomeView& g, const ReadsView& rv, const wamd_dist_
 template <int NB>
 static int launch_band(const GenomeView& g, const ReadsView& rv, const wamd_dist_task* d_tasks, uint32_t n,
                        int last_symbol, uint32_t max_text_len, wamd_dist_result* d_results, uint32_t* d_flags,
-                       int chained, const uint32_t* only_deferred, uint32_t* deferred, hipStream_t s)
+                       int chained, const uint32_t* only_deferred, uint32_t* deferred, const uint32_t* n_dev, hipStream_t s)
 {
 #ifndef WAMD_BAND_BLOCK
 #define WAMD_BAND_BLOCK 128
@@ -997,18 +1010,18 @@ static int launch_band(const GenomeView& g, const ReadsView& rv, const wamd_dist
     const uint32_t blocks = (n + BLOCK - 1) / BLOCK;
     const size_t lds = (size_t)rv.words32 * 4 * BLOCK * sizeof(uint32_t);
     hipLaunchKernelGGL((myers_band_kernel<NB, BLOCK>), dim3(blocks), dim3(BLOCK), lds, s, g, rv, d_tasks, n,
-                       last_symbol, max_text_len, d_results, d_flags, chained, only_deferred, deferred);
+                       last_symbol, max_text_len, d_results, d_flags, chained, only_deferred, deferred, n_dev);
     WAMD_HIP(hipGetLastError());
     return WAMD_OK;
 }
 
 static int launch_exact(const GenomeView& g, const ReadsView& rv, const wamd_dist_task* d_tasks, uint32_t n,
                         int last_symbol, uint32_t mt, wamd_dist_result* d_results, uint32_t* f, int chained,
-                        const uint32_t* only_deferred, int clamp, hipStream_t s)
+                        const uint32_t* only_deferred, int clamp, const uint32_t* n_dev, hipStream_t s)
 {
 #define WAMD_DIST_CASE(NW, BLOCK) \
     if (rv.words32 <= NW)         \
-        return launch_one<NW, BLOCK>(g, rv, d_tasks, n, last_symbol, mt, d_results, f, chained, only_deferred, clamp, s);
+        return launch_one<NW, BLOCK>(g, rv, d_tasks, n, last_symbol, mt, d_results, f, chained, only_deferred, clamp, n_dev, s);
     WAMD_DIST_CASE(1, 256)
     WAMD_DIST_CASE(2, 256)
     WAMD_DIST_CASE(3, 256)
@@ -1047,7 +1060,7 @@ static uint32_t* band_flags(wamd_ctx* ctx, hipStream_t s)
 }
 
 int launch_distance(wamd_ctx* ctx, const wamd_reads* r, const wamd_dist_task* d_tasks, uint32_t n,
-                    int last_symbol, wamd_dist_result* d_results, int mode, hipStream_t s)
+                    int last_symbol, wamd_dist_result* d_results, int mode, hipStream_t s, const uint32_t* n_dev)
 {
     WAMD_HIP(hipSetDevice(ctx->device));
     if (n == 0)
@@ -1059,23 +1072,23 @@ int launch_distance(wamd_ctx* ctx, const wamd_reads* r, const wamd_dist_task* d_
     // the LDS rows of the banded kernels must fit a block: words32 x 2 KB <= 64 KB
     if (mode != WAMD_DISTANCE_ACCEPTED_ONLY || rv.words32 <= 2 || rv.words32 > 32)
         return launch_exact(g, rv, d_tasks, n, last_symbol, mt, d_results, f, 0, nullptr,
-                            mode == WAMD_DISTANCE_ACCEPTED_ONLY, s);
+                            mode == WAMD_DISTANCE_ACCEPTED_ONLY, n_dev, s);
     // 64-row band, then 96 rows for what did not fit, then whole columns
     uint32_t* cnt2 = band_flags(ctx, s);
     uint32_t* cnt3 = cnt2 ? cnt2 + 1 : nullptr;
     if (cnt2)
         WAMD_HIP(hipMemsetAsync(cnt2, 0, 2 * sizeof(uint32_t), s));
-    int rc = launch_band<2>(g, rv, d_tasks, n, last_symbol, mt, d_results, f, 0, nullptr, cnt2, s);
+    int rc = launch_band<2>(g, rv, d_tasks, n, last_symbol, mt, d_results, f, 0, nullptr, cnt2, n_dev, s);
     if (rc != WAMD_OK)
         return rc;
     const uint32_t* last = cnt2;
     if (rv.words32 > 3) {
-        rc = launch_band<3>(g, rv, d_tasks, n, last_symbol, mt, d_results, f, 1, cnt2, cnt3, s);
+        rc = launch_band<3>(g, rv, d_tasks, n, last_symbol, mt, d_results, f, 1, cnt2, cnt3, n_dev, s);
         if (rc != WAMD_OK)
             return rc;
         last = cnt3;
     }
-    return launch_exact(g, rv, d_tasks, n, last_symbol, mt, d_results, f, 1, last, 1, s);
+    return launch_exact(g, rv, d_tasks, n, last_symbol, mt, d_results, f, 1, last, 1, n_dev, s);
 }
 
 } // namespace wamd

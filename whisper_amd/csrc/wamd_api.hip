@@ -581,6 +581,56 @@ int wamd_cf_filter(wamd_ctx* ctx, const wamd_reads* reads, const wamd_cf_task* t
     return rc ? rc : flags_to_status(flags);
 }
 
+uint64_t wamd_filter_verify_workspace_bytes(uint32_t n) { return filter_verify_workspace_bytes(n); }
+
+static int check_filter_args(wamd_ctx* ctx, const wamd_reads* reads, const void* d_cf, const void* d_tasks, const void* d_results,
+                             const void* d_ws, uint64_t ws_bytes, uint32_t n, const char* who)
+{
+    int rc = check_batch(ctx, reads, d_tasks, d_results, who);
+    if (rc)
+        return rc;
+    if (!d_cf || !d_ws || ((uintptr_t)d_ws & 255u)) {
+        set_error("%s: null CF tasks or workspace, or a workspace that is not 256-byte aligned", who);
+        return WAMD_ERR_INVALID_ARG;
+    }
+    if (ws_bytes < filter_verify_workspace_bytes(n)) {
+        set_error("%s: workspace of %llu bytes, wamd_filter_verify_workspace_bytes(%u) = %llu", who,
+                  (unsigned long long)ws_bytes, n, (unsigned long long)filter_verify_workspace_bytes(n));
+        return WAMD_ERR_INVALID_ARG;
+    }
+    return WAMD_OK;
+}
+
+int wamd_filter_verify_distance_dev(wamd_ctx* ctx, const wamd_reads* reads, const wamd_cf_task* d_cf_tasks,
+                                    const wamd_dist_task* d_tasks, uint32_t n, int last_symbol, wamd_dist_result* d_results,
+                                    void* d_workspace, uint64_t workspace_bytes, void* stream)
+{
+    if (n == 0)
+        return WAMD_OK;
+    int rc = check_filter_args(ctx, reads, d_cf_tasks, d_tasks, d_results, d_workspace, workspace_bytes, n,
+                               "wamd_filter_verify_distance_dev");
+    if (rc)
+        return rc;
+    if (last_symbol < -1 || last_symbol > 15)
+        return WAMD_ERR_INVALID_ARG;
+    return launch_filter_distance(ctx, reads, d_cf_tasks, d_tasks, n, last_symbol, d_results, d_workspace,
+                                  stream ? (hipStream_t)stream : ctx->stream);
+}
+
+int wamd_filter_levdiag_dev(wamd_ctx* ctx, const wamd_reads* reads, const wamd_cf_task* d_cf_tasks,
+                            const wamd_levdiag_task* d_tasks, uint32_t n, uint32_t* d_results, void* d_workspace,
+                            uint64_t workspace_bytes, void* stream)
+{
+    if (n == 0)
+        return WAMD_OK;
+    int rc = check_filter_args(ctx, reads, d_cf_tasks, d_tasks, d_results, d_workspace, workspace_bytes, n,
+                               "wamd_filter_levdiag_dev");
+    if (rc)
+        return rc;
+    return launch_filter_levdiag(ctx, reads, d_cf_tasks, d_tasks, n, d_results, d_workspace,
+                                 stream ? (hipStream_t)stream : ctx->stream);
+}
+
 uint64_t wamd_align_workspace_bytes(const wamd_reads* reads, uint32_t n)
 {
     return reads ? align_workspace_bytes(reads, n) : 0;

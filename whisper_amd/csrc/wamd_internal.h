@@ -137,9 +137,10 @@ int launch_reads_prepare(wamd_ctx* ctx, wamd_reads* r, const uint8_t* d_raw,
                          const uint64_t* d_raw_off, hipStream_t s);
 int ensure_pm(const wamd_reads* r, hipStream_t s);
 int launch_distance(wamd_ctx* ctx, const wamd_reads* r, const wamd_dist_task* d_tasks, uint32_t n,
-                    int last_symbol, wamd_dist_result* d_results, int mode, hipStream_t s);
+                    int last_symbol, wamd_dist_result* d_results, int mode, hipStream_t s,
+                    const uint32_t* n_dev = nullptr);   // n_dev: device word holding the batch's real length (<= n)
 int launch_levdiag(wamd_ctx* ctx, const wamd_reads* r, const wamd_levdiag_task* d_tasks,
-                   uint32_t n, uint32_t* d_results, hipStream_t s);
+                   uint32_t n, uint32_t* d_results, hipStream_t s, const uint32_t* n_dev = nullptr);
 int launch_align(wamd_ctx* ctx, const wamd_reads* r, const wamd_dist_task* d_tasks, uint32_t n,
                  int last_symbol, int refine, wamd_align_result* d_results, uint8_t* d_cigars,
                  uint32_t cigar_stride, void* d_ws, uint64_t ws_bytes, hipStream_t s);
@@ -165,6 +166,12 @@ int launch_post_passes(wamd_ctx* ctx, uint32_t n, const wamd_clip_illegal_task* 
 
 int launch_cf_filter(wamd_ctx* ctx, const wamd_reads* r, const wamd_cf_task* d_tasks, uint32_t n,
                      uint32_t* d_results, hipStream_t s);
+
+uint64_t filter_verify_workspace_bytes(uint32_t n);
+int launch_filter_distance(wamd_ctx* ctx, const wamd_reads* r, const wamd_cf_task* d_cf, const wamd_dist_task* d_tasks,
+                           uint32_t n, int last_symbol, wamd_dist_result* d_results, void* d_ws, hipStream_t s);
+int launch_filter_levdiag(wamd_ctx* ctx, const wamd_reads* r, const wamd_cf_task* d_cf, const wamd_levdiag_task* d_tasks,
+                          uint32_t n, uint32_t* d_results, void* d_ws, hipStream_t s);
 
 int launch_sam_cigar(wamd_ctx* ctx, uint32_t n, const uint8_t* d_ext, uint32_t ext_stride, uint8_t* d_cigars,
                      uint32_t cigar_stride, uint8_t* d_mdz, uint32_t mdz_stride, uint32_t* d_bin, uint32_t bin_stride,
