@@ -192,6 +192,23 @@ __device__ __forceinline__ uint32_t extract32(const uint64_t (&V)[NW], uint32_t 
     return (uint32_t)(sh ? ((s0 >> sh) | (s1 << (64u - sh))) : s0);
 }
 
+// Which way getExtCigar leaves a cell (LevMyers64.cpp:431-442): diagonal before horizontal before vertical, but a
+// move that continues the previous direction wins.  Entry (prev_dir, from_d, from_h, from_v) -> DIR_*, two bits each.
+constexpr uint64_t walk_table()
+{
+    uint64_t t = 0;
+    for (uint32_t prev = 0; prev < 3; ++prev)
+        for (uint32_t i = 0; i < 8; ++i) {
+            const bool fd = i & 4u, fh = i & 2u, fv = i & 1u;
+            const bool take_d = fd && (prev == DIR_D || (prev == DIR_H && !fh) || (prev == DIR_V && !fv));
+            const bool take_h = !take_d && fh && (prev == DIR_H || (prev == DIR_D && !fd) || (prev == DIR_V && !fv));
+            const uint64_t dir = take_d ? DIR_D : (take_h ? DIR_H : DIR_V);
+            t |= dir << (2u * (prev * 8u + i));
+        }
+    return t;
+}
+constexpr uint64_t WALK_TABLE = walk_table();
+
 struct AlignParams {
     const wamd_dist_task* tasks;
     const wamd_dist_result* dist;
@@ -651,8 +668,8 @@ __global__ __launch_bounds__(BLOCK, (PHASE == 1 && NW <= 4 ? WAMD_WALK_WAVES : 1
 #endif
         uint32_t read_pos = valid ? m : 0, pos = valid ? end_pos : 0;
         uint32_t c_val = ed, events = 0, nsteps = 0, pacc = 0;
-        int prev_dir = DIR_D;
-        bool in_indel = false;
+        uint32_t prev_dir = DIR_D;
+        uint32_t in_indel = 0;   // 0 / 1
         double score = 0;
         // ---- stage the read and the genome symbols under the recomputed columns ------------
         const int RDc = PHASE == 2 ? (int)ap.rd_cap : RD, GDc = PHASE == 2 ? (int)ap.gd_cap : GD;
@@ -710,16 +727,18 @@ __global__ __launch_bounds__(BLOCK, (PHASE == 1 && NW <= 4 ? WAMD_WALK_WAVES : 1
             const uint32_t x = staged_sym(st_gen, (uint32_t)g_origin, gd_n, ref_pos + col - 1);
             return x > 5u ? 5u : x;   // ref_copy_direct, sam.cpp:2372-2374
         };
-        auto push_step = [&](int dir) {
-            pacc |= (uint32_t)dir << (2 * (nsteps & 15u));
+        // step codes enter `pacc` from the top: after sixteen of them the first sits in bits 0..1
+        auto push_step = [&](uint32_t dir) {
+            pacc = (pacc >> 2) | (dir << 30);
             ++nsteps;
-            if ((nsteps & 15u) == 0) {
+            if ((nsteps & 15u) == 0)
                 path[(uint64_t)(nsteps / 16 - 1) * BLOCK + tid] = pacc;
-                pacc = 0;
-            }
         };
         const double c_match = ap.sc.match, c_mism = ap.sc.mismatch, c_do = ap.sc.gap_del_open,
                      c_de = ap.sc.gap_del_extend, c_io = ap.sc.gap_ins_open, c_ie = ap.sc.gap_ins_extend;
+        // the six of them, one per lane (see `step`)
+        const double cost_lane = tid == 0 ? c_match : (tid == 1 ? c_mism : (tid == 2 ? c_do : (tid == 3 ? c_de : (tid == 4 ? c_io : (tid == 5 ? c_ie : 0.0)))));
+        const int cost_lo = __double2loint(cost_lane), cost_hi = __double2hiint(cost_lane);
 
         if constexpr (PHASE == 2) {
             // totals of the walk, left in the result record by the first half
@@ -748,36 +767,36 @@ __global__ __launch_bounds__(BLOCK, (PHASE == 1 && NW <= 4 ? WAMD_WALK_WAVES : 1
                 for (int v = 0; v < 4; ++v)
                     dst[v] = src[v * BLOCK];
             };
+            // One move costs what the table says (six wave-uniform doubles, lane i of `cost_lane` holds entry i and
+            // lane 6 zero for lanes that sit a round out): fetched across lanes, not picked by a chain of selects.
+            //   0 match, 1 mismatch, 2 deletion opens, 3 extends, 4 insertion opens, 5 extends
             auto step = [&](const WT (&cur)[4], uint32_t s_) {
                 const int32_t oc = A - (int32_t)s_;
                 const uint32_t off_c = (HALF || oc > 0) ? (uint32_t)oc : 0u;   // banded windows keep sliding above row 0
                 bool pending = read_pos && pos;
-                while (__any(pending)) {
+                if (!__any(pending))
+                    return;
+                do {
                     const uint32_t b = ((pending ? read_pos : 1u) - 1u - off_c) & WMASK;
-                    const bool fdm = (cur[0] >> b) & 1u, fdx = (cur[1] >> b) & 1u;
-                    const bool from_h = (cur[2] >> b) & 1u, from_v = (cur[3] >> b) & 1u;
-                    const bool from_d = fdm || fdx;
-                    // D > H > V, but a move that continues the previous direction wins (LevMyers64.cpp:431-442)
-                    const bool take_d = from_d && (prev_dir == DIR_D || (prev_dir == DIR_H && !from_h) ||
-                                                   (prev_dir == DIR_V && !from_v));
-                    const bool take_h = !take_d && from_h && (prev_dir == DIR_H || (prev_dir == DIR_D && !from_d) ||
-                                                              (prev_dir == DIR_V && !from_v));
-                    const int dir = take_d ? DIR_D : (take_h ? DIR_H : DIR_V);
-                    const double cost_d = fdx ? c_mism : c_match;
-                    const double cost_h = in_indel ? c_de : c_do;
-                    const double cost_v = in_indel ? c_ie : c_io;
-                    const double cost = take_d ? cost_d : (take_h ? cost_h : cost_v);
+                    const uint32_t fdm = (uint32_t)(cur[0] >> b) & 1u, fdx = (uint32_t)(cur[1] >> b) & 1u;
+                    const uint32_t fh = (uint32_t)(cur[2] >> b) & 1u, fv = (uint32_t)(cur[3] >> b) & 1u;
+                    const uint32_t idx = (prev_dir << 3) | ((fdm | fdx) << 2) | (fh << 1) | fv;
+                    const uint32_t dir = (uint32_t)(WALK_TABLE >> (2u * idx)) & 3u;
+                    const uint32_t cidx = pending ? (dir ? 2u * dir + in_indel : fdx) : 6u;
+                    const double cost = __hiloint2double(__builtin_amdgcn_ds_bpermute((int)(cidx * 4u), cost_hi),
+                                                         __builtin_amdgcn_ds_bpermute((int)(cidx * 4u), cost_lo));
+                    score += cost;   // + 0.0 for a lane that is not pending
                     if (pending) {
-                        score += cost;
-                        events += (!take_d && !in_indel) ? 1u : 0u;
-                        in_indel = !take_d;
-                        read_pos -= take_h ? 0u : 1u;
-                        pos -= (take_d || take_h) ? 1u : 0u;
+                        const uint32_t gap = dir ? 1u : 0u;
+                        events += gap & (in_indel ^ 1u);
+                        in_indel = gap;
+                        read_pos -= (5u >> dir) & 1u;   // diagonal, vertical
+                        pos -= (3u >> dir) & 1u;        // diagonal, horizontal
                         prev_dir = dir;
-                        push_step(PHASE == 1 && take_d && fdx ? DIR_X : dir);
+                        push_step(PHASE == 1 && dir == DIR_D ? 3u * fdx : dir);   // DIR_X = 3: a diagonal step over a mismatch
                         pending = dir == DIR_V && read_pos != 0;
                     }
-                }
+                } while (__any(pending));
             };
             if constexpr (HALF) {
                 // eight columns at a time: reload the state kept before iteration F - 8(q+1), run the
@@ -901,7 +920,7 @@ __global__ __launch_bounds__(BLOCK, (PHASE == 1 && NW <= 4 ? WAMD_WALK_WAVES : 1
             }
         }
         if (PHASE != 2 && (nsteps & 15u))
-            path[(uint64_t)(nsteps / 16) * BLOCK + tid] = pacc;
+            path[(uint64_t)(nsteps / 16) * BLOCK + tid] = pacc >> (32u - 2u * (nsteps & 15u));
         const uint32_t begin_pos = pos;
         if constexpr (PHASE == 1) {   // hand over to the replay kernel
             if (li < count) {
