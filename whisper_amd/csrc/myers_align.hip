@@ -333,7 +333,9 @@ __global__ __launch_bounds__(BLOCK, (PHASE == 1 && NW <= 4 ? WAMD_WALK_WAVES : 1
             }
         };
         // one banded column: updates VPb / VNb, returns the four decision windows of the column
-        auto band_col = [&](uint32_t f, uint32_t c, uint32_t (&win)[4]) {
+        // CHECKED: some lane of the wave may see a symbol >= 4 in this group of eight columns (asked once per group,
+        // so that the common group is eight columns of straight-line code)
+        auto band_col = [&](auto checked, uint32_t f, uint32_t c, uint32_t (&win)[4]) {
             const uint32_t* S = reinterpret_cast<const uint32_t*>(lds_all) + tid;
             const uint32_t delay = F - n_cols;
             const bool act = valid && f >= delay;
@@ -342,7 +344,7 @@ __global__ __launch_bounds__(BLOCK, (PHASE == 1 && NW <= 4 ? WAMD_WALK_WAVES : 1
             const uint32_t a0 = sp[0], a1 = sp[BLOCK], a2 = sp[2 * BLOCK];
             uint64_t eq = ((uint64_t)__builtin_amdgcn_alignbit(a2, a1, sh) << 32) | __builtin_amdgcn_alignbit(a1, a0, sh);
             uint64_t we = eq;
-            if (__any(act && c >= 4u)) {   // N runs and other non-ACGT symbols
+            if constexpr (decltype(checked)::value) {   // N runs and other non-ACGT symbols
                 if (c >= 4u) {
                     // read row of bit 0
                     const int32_t r0 = (int32_t)f + (int32_t)s_col + (int32_t)m - 2 - (int32_t)ed - (int32_t)end_pos - 16 -
@@ -455,10 +457,18 @@ __global__ __launch_bounds__(BLOCK, (PHASE == 1 && NW <= 4 ? WAMD_WALK_WAVES : 1
                         const uint32_t t_hi = nibble_swap(raw[q]);
                         const uint32_t syms = __builtin_amdgcn_alignbit(t_hi, t_lo, tx_sh);
                         t_lo = t_hi;
+                        if (__any(valid && (syms & 0xccccccccu))) {
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            uint32_t win[4];
-                            band_col(fb + u, (syms >> (4 * u)) & 15u, win);
+                            for (int u = 0; u < 8; ++u) {
+                                uint32_t win[4];
+                                band_col(std::true_type{}, fb + u, (syms >> (4 * u)) & 15u, win);
+                            }
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                uint32_t win[4];
+                                band_col(std::false_type{}, fb + u, (syms >> (4 * u)) & 15u, win);
+                            }
                         }
                     }
                 }
@@ -825,9 +835,15 @@ __global__ __launch_bounds__(BLOCK, (PHASE == 1 && NW <= 4 ? WAMD_WALK_WAVES : 1
                         nsyms = __builtin_amdgcn_alignbit(t_hi, t_lo, tx_sh);
                     }
                     uint32_t D[8][4];
+                    if (__any(valid && (syms & 0xccccccccu))) {
 #pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        band_col(fb + u, (syms >> (4 * u)) & 15u, D[u]);
+                        for (int u = 0; u < 8; ++u)
+                            band_col(std::true_type{}, fb + u, (syms >> (4 * u)) & 15u, D[u]);
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            band_col(std::false_type{}, fb + u, (syms >> (4 * u)) & 15u, D[u]);
+                    }
 #pragma unroll
                     for (int u = 7; u >= 0; --u)
                         step(D[u], F - 1 - (fb + u));
