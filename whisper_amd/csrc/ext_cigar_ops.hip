@@ -1070,7 +1070,11 @@ __device__ wamd_sam_cigar_len sam_cigar_one(const uint8_t* ext, uint32_t ext_str
 {
     enum { Match, Mismatch, Insertion, Deletion, Begin, End, Clipping };
     uint32_t e = 0, c = 0, d = 0, b = 0;       // cursors: ext-CIGAR, CIGAR text, MD:Z, BAM operations
-    uint32_t counters[7] = {0, 0, 0, 0, 0, 0, 0};
+    // The reference keeps one counter per operation kind, bumps the current kind's at every step and clears the
+    // previous kind's at every change of kind: what it reads at a change - the previous kind's counter - is the
+    // length of the run that has just ended, so one running length serves (an array indexed by the kind would be
+    // a chain of selects per step here).  Matches and mismatches are counted by run_m instead, as there.
+    uint32_t run = 0, ended_run = 0;
     uint32_t run_m = 0, run_md = 0;            // cnt_match_mismatch, cnt_match_ignoring_insert
     int cur = Begin, prev = Begin;
     bool overflow = false;
@@ -1084,7 +1088,6 @@ __device__ wamd_sam_cigar_len sam_cigar_one(const uint8_t* ext, uint32_t ext_str
         }
         // inside a run of matches four more dots change three counts and nothing else (no flush: cur == prev)
         if (by4 && prev == Match && e + 8 <= ext_stride && str4(ext, e) == FOUR_DOTS) {
-            counters[Match] += 4;
             run_m += 4;
             run_md += 4;
             e += 4;
@@ -1117,7 +1120,8 @@ __device__ wamd_sam_cigar_len sam_cigar_one(const uint8_t* ext, uint32_t ext_str
                 cur = Mismatch;
             }
         }
-        ++counters[cur];
+        ended_run = run;
+        run = cur == prev ? run + 1 : 1;
         if (cur == Match) {
             ++run_m;
             ++run_md;
@@ -1128,11 +1132,11 @@ __device__ wamd_sam_cigar_len sam_cigar_one(const uint8_t* ext, uint32_t ext_str
             uint32_t count = 0, op = 0;
             bool flush = false;
             if (prev == Clipping) {
-                count = counters[Clipping], op = 4, flush = true;    // S_op
+                count = ended_run, op = 4, flush = true;    // S_op
             } else if (prev == Insertion) {
-                count = counters[Insertion], op = 1, flush = true;   // I_op
+                count = ended_run, op = 1, flush = true;   // I_op
             } else if (prev == Deletion) {
-                count = counters[Deletion], op = 2, flush = true;    // D_op
+                count = ended_run, op = 2, flush = true;    // D_op
             } else if ((prev == Match && cur != Mismatch) || (prev == Mismatch && cur != Match)) {
                 count = run_m, op = 0, flush = true;                 // M_op
                 run_m = 0;
@@ -1143,7 +1147,6 @@ __device__ wamd_sam_cigar_len sam_cigar_one(const uint8_t* ext, uint32_t ext_str
                 if (cb)
                     cb[b++] = count << 4 | op;
             }
-            counters[prev] = 0;
         }
         prev = cur;
     }
