@@ -1193,7 +1193,7 @@ enum { POST_ILLEGAL = 1, POST_BOUNDARY = 2, POST_PAIRS = 4, POST_SAM = 8,
        POST_LEN_IN_RESERVED = 16,   // lens[].reserved = length of the ext-CIGAR + 2 (finish_pairs' bookkeeping)
        POST_TWO_HALVES = 32 };      // test hook: never pack
 
-__global__ __launch_bounds__(64) void post_passes_kernel(uint32_t n, const wamd_clip_illegal_task* __restrict__ it,
+__global__ __launch_bounds__(64, 4) void post_passes_kernel(uint32_t n, const wamd_clip_illegal_task* __restrict__ it,
                                                          const wamd_clip_pair_task* __restrict__ pt,
                                                          wamd_clip_record* __restrict__ records, uint8_t* __restrict__ ext,
                                                          uint32_t ext_stride, const uint32_t* __restrict__ cap_hint,
