@@ -292,9 +292,10 @@ WAMD_API int wamd_ctx_set_max_text_len(wamd_ctx* ctx, uint32_t max_text_len);
  * {k + 1, 0}.  That is all the mapping stages consume (`cur_match <= max_mismatches`,
  * mapper/mapping_core_sa.cpp:237-241, 289-293), and it lets the library compute only the band
  * of diagonals an accepted alignment can use (Hyyro's banded form of the recurrence).
- * wamd_align[_dev] and wamd_finish_pairs[_dev] take their first pass the same way: accepted tasks are
- * aligned exactly as in the default mode, a rejected one reports ok = 0 with {k + 1, 0} (its callers
- * stop at dynamicProgramming's false, sam_matching.cpp:704-705 / 741-744). */
+ * wamd_align[_dev] takes its first pass the same way: accepted tasks are aligned exactly as in the default
+ * mode, a rejected one reports ok = 0 with {k + 1, 0} (its callers stop at dynamicProgramming's false,
+ * sam_matching.cpp:704-705 / 741-744).  wamd_finish_pairs[_dev] shows nothing of a rejected record's distance
+ * and always verifies this way, whatever the mode. */
 enum { WAMD_DISTANCE_EXACT = 0, WAMD_DISTANCE_ACCEPTED_ONLY = 1 };
 WAMD_API int wamd_ctx_set_distance_mode(wamd_ctx* ctx, int mode);
 /* What SetReference's ref_size / cur_offset arguments change between stages

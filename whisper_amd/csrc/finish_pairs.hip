@@ -300,9 +300,11 @@ int launch_finish_pairs(wamd_ctx* ctx, const wamd_reads* r, const wamd_finish_ta
     hipLaunchKernelGGL(finish_prepare_kernel, dim3(blocks), dim3(256), 0, s, rv, d_tasks, n, prm->flank, w.dt, w.ct,
                        ctx->d_flags);
     WAMD_HIP(hipGetLastError());
-    // CSamGenerator's verifier objects only ever see preprocessRawSeq: last_symbol stays 0 (LevMyers64.cpp:35)
+    // CSamGenerator's verifier objects only ever see preprocessRawSeq: last_symbol stays 0 (LevMyers64.cpp:35).
+    // fill_cigar_with_lev gives up where dynamicProgramming returns false (sam_matching.cpp:704-705) and nothing of
+    // a rejected record's distance reaches the output: the first pass always takes the banded kernels.
     int rc = launch_align(ctx, r, w.dt, n, 0, prm->enable_short_indel_refinement ? 1 : 0, w.ar, d_ext, ext_stride,
-                          w.align_ws, w.align_ws_bytes, s);
+                          w.align_ws, w.align_ws_bytes, s, WAMD_DISTANCE_ACCEPTED_ONLY);
     if (rc)
         return rc;
     rc = launch_indel_ext_cigar(ctx, r, w.ct, n, w.cr, d_ext, ext_stride, s);

@@ -1389,9 +1389,11 @@ static int launch_tb_class(int cls, const GenomeView& g, const ReadsView& rv, co
 
 int launch_align(wamd_ctx* ctx, const wamd_reads* r, const wamd_dist_task* d_tasks, uint32_t n,
                  int last_symbol, int refine, wamd_align_result* d_results, uint8_t* d_cigars,
-                 uint32_t cigar_stride, void* d_ws, uint64_t ws_bytes, hipStream_t s)
+                 uint32_t cigar_stride, void* d_ws, uint64_t ws_bytes, hipStream_t s, int distance_mode)
 {
     WAMD_HIP(hipSetDevice(ctx->device));
+    if (distance_mode < 0)
+        distance_mode = ctx->distance_mode;
     if ((cigar_stride & 3u) || ((uintptr_t)d_cigars & 3u) || ((uintptr_t)d_ws & 255u)) {
         set_error("wamd_align: cigar_stride must be a multiple of 4, buffers aligned (cigars 4, workspace 256)");
         return WAMD_ERR_INVALID_ARG;
@@ -1413,7 +1415,7 @@ int launch_align(wamd_ctx* ctx, const wamd_reads* r, const wamd_dist_task* d_tas
     // pass 1 follows the context's distance mode: fill_cigar_with_lev and find_pairs only go on when
     // dynamicProgramming returned true (sam_matching.cpp:704-705), so in accepted-only mode the rejected
     // tasks come back as {k + 1, 0}, not ok, from the banded kernels
-    rc = launch_distance(ctx, r, d_tasks, n, last_symbol, d_dist, ctx->distance_mode, s);
+    rc = launch_distance(ctx, r, d_tasks, n, last_symbol, d_dist, distance_mode, s);
     if (rc)
         return rc;
     const ReadsView rv = r->view();

@@ -143,7 +143,8 @@ int launch_levdiag(wamd_ctx* ctx, const wamd_reads* r, const wamd_levdiag_task* 
                    uint32_t n, uint32_t* d_results, hipStream_t s, const uint32_t* n_dev = nullptr);
 int launch_align(wamd_ctx* ctx, const wamd_reads* r, const wamd_dist_task* d_tasks, uint32_t n,
                  int last_symbol, int refine, wamd_align_result* d_results, uint8_t* d_cigars,
-                 uint32_t cigar_stride, void* d_ws, uint64_t ws_bytes, hipStream_t s);
+                 uint32_t cigar_stride, void* d_ws, uint64_t ws_bytes, hipStream_t s,
+                 int distance_mode = -1);   // -1: the context's; finish_pairs never reads a rejected task's distance
 uint64_t align_workspace_bytes(const wamd_reads* r, uint32_t n, uint32_t max_ed = 0);
 int launch_indel_match(wamd_ctx* ctx, const wamd_reads* r, const wamd_indel_task* d_tasks, uint32_t n,
                        const wamd_indel_params* prm, wamd_mapping* d_results, hipStream_t s);
