@@ -65,7 +65,9 @@ def cf_pass(oracle, packed, G, cur_offset, reads, cf, short, k):
 
 
 @pytest.mark.parametrize("k,cur_offset,min_len,n", [(5, 0, 150, 6000), (12, 17, 150, 5003), (7, 0, 250, 3000),
-                                                    (4, 9, 100, 4097), (1, 0, 150, 2000)])
+                                                    (4, 9, 100, 4097), (1, 0, 150, 2000),
+                                                    (6, 0, 300, 2000),    # M64 rule, 64-thread blocks of the exact kernel
+                                                    (3, 5, 40, 2500)])    # two dwords per vector: no banded kernels
 def test_filter_then_distance(ctx, oracle, k, cur_offset, min_len, n):
     codes, packed, reads_h, cf, dist, lev, short = candidates(n, 400 + k, k, min_len, cur_offset)
     G = codes.numel()
@@ -103,7 +105,9 @@ def test_filter_then_distance(ctx, oracle, k, cur_offset, min_len, n):
         ctx.set_reference_params(G, 0)
 
 
-@pytest.mark.parametrize("k,cur_offset,min_len,n", [(5, 0, 150, 6000), (2, 17, 150, 3001), (4, 0, 250, 3000), (6, 9, 100, 4000)])
+@pytest.mark.parametrize("k,cur_offset,min_len,n", [(5, 0, 150, 6000), (2, 17, 150, 3001), (4, 0, 250, 3000), (6, 9, 100, 4000),
+                                                    (4, 0, 300, 2000),    # above 256 symbols: the run-extension kernel alone
+                                                    (5, 0, 600, 1500)])
 def test_filter_then_levdiag(ctx, oracle, k, cur_offset, min_len, n):
     codes, packed, reads_h, cf, dist, lev, short = candidates(n, 500 + k, k, min_len, cur_offset)
     G = codes.numel()
