@@ -1318,14 +1318,22 @@ __global__ __launch_bounds__(64, 4) void post_passes_kernel(uint32_t n, const wa
             incl += o;
     }
     const uint32_t total = (uint32_t)__shfl((int)incl, 63);
-    const int halves = (total <= budget_dw && !(passes & POST_TWO_HALVES)) ? 1 : 2;
+    // lanes served together when the strings are not packed: as many (a power of two, pairs stay together) as fit
+    // the budget at the full stride - 32 unless the caller's stride is long (the launcher caps the budget so that
+    // the stride does not decide how many waves a CU holds)
+    uint32_t per = 32, per_sh = 5;
+    while (per > 2 && per * full_dw > budget_dw) {
+        per >>= 1;
+        --per_sh;
+    }
+    const int halves = (total <= budget_dw && !(passes & POST_TWO_HALVES)) ? 1 : (int)(64u / per);
     for (int h = 0; h < halves; ++h) {
         // lanes of this pass, where their strings start and how many dwords they hold
-        const bool mine = halves == 1 || (lane >> 5) == (uint32_t)h;
+        const bool mine = halves == 1 || (lane >> per_sh) == (uint32_t)h;
         uint32_t ndw = mine ? my_dw : 0u, off = incl - my_dw;
-        if (halves == 2) {
+        if (halves != 1) {
             ndw = (mine && live) ? full_dw : 0u;
-            off = (lane & 31u) * full_dw;
+            off = (lane & (per - 1u)) * full_dw;
         }
         const uint32_t cap = ndw * 4 < ext_stride ? ndw * 4 : ext_stride;   // bytes of the string the routines may use
         const uint32_t lim_dw = ndw < ext_stride / 4 ? ndw : ext_stride / 4;   // dwords that travel
@@ -1450,7 +1458,12 @@ static int launch_post_kernel(wamd_ctx* ctx, uint32_t n, const wamd_clip_illegal
         passes |= POST_TWO_HALVES;
     }
     // LDS of a wave: 32 strings at the full (odd) stride - what a half needs when the strings are not packed
-    const uint32_t budget_dw = 32u * ((ext_stride / 4) | 1u);
+    // ... capped at 11.4 KB (fourteen waves per CU; what 32 strings of 352 bytes take): longer strides are served
+    // in smaller groups when their strings do not pack
+    const uint32_t full_dw = (ext_stride / 4) | 1u;
+    uint32_t budget_dw = 32u * full_dw;
+    if (budget_dw > 2912u)
+        budget_dw = 2912u > 2u * full_dw ? 2912u : 2u * full_dw;
     hipLaunchKernelGGL(post_passes_kernel, dim3((n + 63) / 64), dim3(64), (size_t)budget_dw * 4, s, n, it, pt, rec, ext,
                        ext_stride, cap_hint, budget_dw, ctx->scoring, passes, cigars, cigar_stride, mdz, mdz_stride, bin,
                        bin_stride, lens, ctx->d_flags);
