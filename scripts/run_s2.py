@@ -12,7 +12,7 @@ from whisper_amd import api, synth  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 22
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 dev = torch.device("cuda", 0)
-codes = synth.make_genome(1 << 28, seed=0xC0FFEE, device=dev)
+codes = synth.make_genome(1 << int(os.environ.get("WAMD_S2_GENOME_LOG2", "28")), seed=0xC0FFEE, device=dev)
 packed = synth.pack_nibbles(codes)
 ctx = api.Context(packed, ref_size=codes.numel(), cur_offset=0, device=0)
 stream = torch.cuda.ExternalStream(ctx.stream(), device=dev)

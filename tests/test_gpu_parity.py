@@ -267,6 +267,7 @@ ALIGN_CASES = [
     (150, 26, 1427, 0, 1, 0),       # rescue window before the insert-size model is trained (sam.cpp:185-188)
     (250, 44, 1588, 0, 1, 0),       # the same at 250 bp: 500 + 7 * 125 + 2 * 44 ... and beyond
     (150, 26, 9000, 0, 0, 0),       # a window as long as the genome's N border allows
+    (700, 20, None, 0, 1, 0),       # reads too long for the replay's LDS rows: its form that writes straight to memory
 ]
 
 

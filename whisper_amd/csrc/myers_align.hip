@@ -227,6 +227,7 @@ struct AlignParams {
     int refine;
     int ascii;
     uint32_t rd_cap, gd_cap;   // replay kernel: staged read / genome dwords per lane (from the batch's longest read)
+    uint32_t rp_sw;            // staged replay: dwords of a lane's string row in LDS
 };
 
 // ---- pass 2b: windowed recompute + traceback + forward emission --------------------
@@ -1122,9 +1123,20 @@ __global__ __launch_bounds__(BLOCK, (PHASE == 1 && NW <= 4 ? WAMD_WALK_WAVES : 1
 // the opposite indel exactly three operations later with no edit in between, and a match behind it -
 // all of which is known at the NEXT edit (or at the end), where the six bytes are rewritten and
 // everything behind them moves down by three (nothing behind them has been written yet but dots).
-__global__ __launch_bounds__(256) void align_replay_kernel(GenomeView g, ReadsView rv, AlignParams ap)
+// STAGED (reads short enough for a wave's strings to fit in LDS; one wave per block): the string is built in
+// the lane's LDS row (an odd number of dwords: the lanes' rows start in different banks) and the finished
+// rows leave as the dots do in the other form - the wave writing its 64 slots together, 16 bytes a lane.
+// Of the direct form's 0.33 ms per 2^20 alignments 0.11 - 0.15 ms were the edits' byte stores (64 lines per
+// instruction): 0.21 ms with the rows in LDS, 0.18 ms with an edit's symbol asked for one edit ahead.
+// (Also staging the alignment's genome and code dwords - no memory access left in the loop - was slower,
+// 0.29 ms: 22 KB of LDS per wave leave seven waves per CU, and they wait for their first loads instead.)
+template <bool STAGED>
+__global__ __launch_bounds__(STAGED ? 64 : 256) void align_replay_kernel(GenomeView g, ReadsView rv, AlignParams ap)
 {
-    const uint32_t li = blockIdx.x * 256u + threadIdx.x;
+    extern __shared__ uint32_t replay_lds[];   // STAGED: [lane][rp_sw], the wave's strings
+    constexpr uint32_t BLOCK = STAGED ? 64u : 256u;
+    const uint32_t li = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
     const uint32_t count = *ap.count;
     const bool inside = li < count;   // lanes behind the list's end still help with the dots
     const uint32_t gid = inside ? ap.list[li] : 0u;
@@ -1132,35 +1144,38 @@ __global__ __launch_bounds__(256) void align_replay_kernel(GenomeView g, ReadsVi
     wamd_align_result h{};   // totals of the walk
     if (inside)
         h = ap.results[gid];
-    uint8_t* const slot = ap.cigars + (uint64_t)gid * ap.cigar_stride;
+    uint8_t* const gslot = ap.cigars + (uint64_t)gid * ap.cigar_stride;
+    uint32_t* const row = replay_lds + lane * ap.rp_sw;
+    uint8_t* const slot = STAGED ? reinterpret_cast<uint8_t*>(row) : gslot;
     const uint32_t nsteps = h.cigar_len;
     bool valid = inside && h.edit_distance != RESULT_ERROR;
-    if (valid && 2 * nsteps + 4 > ap.cigar_stride) {
+    // the string has nsteps + (indels) <= nsteps + ed bytes and its terminator
+    uint32_t need = valid ? (nsteps + h.edit_distance + 1u + 3u) & ~3u : 0u;   // <= 2 nsteps + 4
+    if (valid && (2 * nsteps + 4 > ap.cigar_stride || (STAGED && need > 4u * ap.rp_sw))) {
         raise_flag(ap.flags, FLAG_CIGAR);
         valid = false;
+        need = 0;
     }
     if (inside && !valid) {
         wamd_align_result r{};
         r.edit_distance = RESULT_ERROR;
         ap.results[gid] = r;
-        slot[0] = 0;
+        gslot[0] = 0;
     }
-    // ---- dots: the string has nsteps + (indels) <= nsteps + ed bytes ------------------------------
-    // A lane filling its own slot would touch a line of its own with every store (64 lines per
-    // instruction).  The wave fills its 64 slots together instead: 16-byte block j of the wave belongs to
-    // slot j / nb, so neighbouring lanes write neighbouring blocks of one slot.
-    {
-        const uint32_t lane = threadIdx.x & 63u;
-        const uint32_t need = valid ? (nsteps + h.edit_distance + 1u + 3u) & ~3u : 0u;   // <= 2 nsteps + 4 <= cigar_stride
-        uint32_t need_max = need;
+    uint32_t need_max = need;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const uint32_t other = (uint32_t)__shfl_xor((int)need_max, o);
-            need_max = other > need_max ? other : need_max;
-        }
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t other = (uint32_t)__shfl_xor((int)need_max, o);
+        need_max = other > need_max ? other : need_max;
+    }
+    // ---- dots ------------------------------------------------------------------------------------
+    // A lane filling its own slot in memory would touch a line of its own with every store (64 lines per
+    // instruction).  The wave serves its 64 slots together instead: 16-byte block j of the wave belongs to
+    // slot j / nb, so neighbouring lanes write neighbouring blocks of one slot.  (STAGED: the same loop
+    // carries the finished rows out at the end; here the lane only fills its LDS row.)
+    auto wave_out = [&](bool from_rows) {
         const uint32_t nb = (need_max + 15u) >> 4;            // blocks per slot (wave-uniform)
         const uint32_t inv = nb ? (1u << 20) / nb + 1u : 0u;   // j / nb = (j * inv) >> 20 for j < 64 nb <= 2^13
-        const wamd_u32x4 dots = {0x2e2e2e2eu, 0x2e2e2e2eu, 0x2e2e2e2eu, 0x2e2e2e2eu};
         for (uint32_t i = 0; i < nb; ++i) {
             const uint32_t j = i * 64u + lane;
             const uint32_t t = (j * inv) >> 20;
@@ -1168,33 +1183,57 @@ __global__ __launch_bounds__(256) void align_replay_kernel(GenomeView g, ReadsVi
             const uint32_t t_need = (uint32_t)__shfl((int)need, (int)t);
             const uint32_t t_gid = (uint32_t)__shfl((int)gid, (int)t);
             uint8_t* const dst = ap.cigars + (uint64_t)t_gid * ap.cigar_stride + off;
+            wamd_u32x4 v = {0x2e2e2e2eu, 0x2e2e2e2eu, 0x2e2e2e2eu, 0x2e2e2e2eu};
+            if (from_rows && off < t_need) {   // (rows are rp_sw dwords: the last block may reach past need, never past the row's use)
+                const uint32_t* const src = replay_lds + t * ap.rp_sw + (off >> 2);
+                const uint32_t left = (t_need - off) >> 2;
+                v.x = src[0];
+                v.y = left > 1u ? src[1] : 0u;
+                v.z = left > 2u ? src[2] : 0u;
+                v.w = left > 3u ? src[3] : 0u;
+            }
             if (off + 16u <= t_need) {
-                *reinterpret_cast<wamd_u32x4_a4*>(dst) = dots;
+                *reinterpret_cast<wamd_u32x4_a4*>(dst) = v;
             } else {
-                for (uint32_t b = off; b < t_need; b += 4u)
-                    *reinterpret_cast<uint32_t*>(dst + (b - off)) = 0x2e2e2e2eu;
+                const uint32_t piece[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (uint32_t c = 0; c < 4; ++c)
+                    if (off + 4u * c < t_need)
+                        *reinterpret_cast<uint32_t*>(dst + 4u * c) = piece[c];
             }
         }
+    };
+    if (STAGED) {
+        for (uint32_t d = 0; 4u * d < need_max; ++d)
+            if (4u * d < need)
+                row[d] = 0x2e2e2e2eu;
+    } else {
+        wave_out(false);
         // the edits below overwrite bytes that other lanes have just written: those stores first
         __threadfence_block();
     }
-    if (!valid)
-        return;
+    if (valid) {
     const wamd_dist_task task = ap.tasks[gid];
     const wamd_dist_result d = ap.dist[gid];
     const uint32_t m = rv.lens[task.read_idx];
     const bool rev = task.flags & WAMD_TASK_FLAG_REV_COMP;
     const uint8_t* const codes = rv.codes + rv.code_off[task.read_idx];
+    const uint32_t* const code_dwords = reinterpret_cast<const uint32_t*>(codes);   // reads start on dwords (reads_prepare.hip)
+    uint64_t gi = (uint64_t)task.ref_pos + h.begin_pos;         // next genome symbol
+    // raw dword holding genome symbol `at` / read code `at` (clamped into the genome like load_genome_dword)
+    auto fetch_raw = [&](bool from_read, uint64_t at) -> uint32_t {
+        const uint32_t dw = (uint32_t)(at >> 3);
+        const uint32_t* const src = from_read ? code_dwords + dw : g.dwords + (dw < g.last_dword ? dw : g.last_dword);
+        return *src;
+    };
     // decode = "ACGTNNXX" (LevMyers64.cpp:398)
     auto decode = [](uint32_t c) -> uint32_t { return (uint32_t)(0x58584e4e54474341ull >> (8 * (c & 7u))) & 0xffu; };
-    auto genome_letter = [&](uint64_t gi) -> uint32_t {   // ref_copy_direct clamps to N_ref (sam.cpp:2372-2374)
-        const uint32_t x = (load_genome_dword(g, (uint32_t)(gi >> 3)) >> (4u * ((uint32_t)gi & 7u))) & 15u;
+    auto genome_letter = [&](uint64_t at) -> uint32_t {   // ref_copy_direct clamps to N_ref (sam.cpp:2372-2374)
+        const uint32_t x = (nibble_swap(fetch_raw(false, at)) >> (4u * ((uint32_t)at & 7u))) & 15u;
         return decode(x > 5u ? 5u : x);
     };
-    const uint32_t* const code_dwords = reinterpret_cast<const uint32_t*>(codes);   // reads start on dwords (reads_prepare.hip)
 
     uint32_t cur = 0, ri = 0, opi = 0;                          // next byte, next read symbol, next operation
-    uint64_t gi = (uint64_t)task.ref_pos + h.begin_pos;         // next genome symbol
     // refinement: the last edit, the indel that may open the pattern, the pattern waiting for the match behind it
     int32_t prev_t = -1;
     bool open = false, pend = false;
@@ -1216,6 +1255,23 @@ __global__ __launch_bounds__(256) void align_replay_kernel(GenomeView g, ReadsVi
         score -= ap.sc.gap_ins_open + ap.sc.gap_del_open;
     };
 
+    // the edit whose symbol is on its way
+    bool e_have = false;
+    uint32_t e_raw = 0, e_sh = 0, e_cur = 0, e_k = 0;
+    auto emit = [&]() {
+        if (!e_have)
+            return;
+        const bool ins = e_k == DIR_V;
+        const uint32_t sym = (nibble_swap(e_raw) >> e_sh) & 15u;
+        const uint32_t oriented = rev ? rc_code(sym) : sym;
+        // copy_direct / convert_to_rev_comp: anything but ACGT is N_read (sam.cpp:2296-2347);
+        // ref_copy_direct clamps to N_ref (sam.cpp:2372-2374)
+        const uint32_t letter = decode(ins ? ((ap.ascii && oriented > 3u) ? 4u : oriented) : (sym > 5u ? 5u : sym));
+        slot[e_cur] = (uint8_t)(e_k == DIR_X ? letter : (ins ? (uint32_t)'#' : (uint32_t)'^'));
+        if (e_k != DIR_X)
+            slot[e_cur + 1] = (uint8_t)letter;
+        e_have = false;
+    };
     const uint32_t q_last = nsteps ? (nsteps - 1u) >> 4 : 0u;
     uint32_t w_next = nsteps ? path[(uint64_t)q_last * 64u] : 0u;
     for (uint32_t qq = 0; nsteps && qq <= q_last; ++qq) {
@@ -1235,6 +1291,12 @@ __global__ __launch_bounds__(256) void align_replay_kernel(GenomeView g, ReadsVi
             const uint32_t k = wl >> 30;
             wl <<= 2;
             left -= z + 1u;
+            // one fetch whatever the edit: the genome dword of a mismatch or deletion, the code dword of an insertion.
+            // It is asked for here and looked at one edit later (emit): the wait is the next edit's bookkeeping.
+            const bool ins = k == DIR_V;
+            const uint64_t at = ins ? (uint64_t)(rev ? m - 1u - ri : ri) : gi;
+            const uint32_t raw = fetch_raw(ins, at);
+            emit();
             if (ap.refine && !refined) {
                 if (pend) {
                     pend = false;
@@ -1255,19 +1317,11 @@ __global__ __launch_bounds__(256) void align_replay_kernel(GenomeView g, ReadsVi
                 g1 = gi;
                 prev_t = (int32_t)opi;
             }
-            // one fetch whatever the edit: the genome dword of a mismatch or deletion, the code dword of an insertion
-            const bool ins = k == DIR_V;
-            const uint64_t at = ins ? (uint64_t)(rev ? m - 1u - ri : ri) : gi;
-            const uint32_t dw = (uint32_t)(at >> 3);
-            const uint32_t* const src = ins ? code_dwords + dw : g.dwords + (dw < g.last_dword ? dw : g.last_dword);
-            const uint32_t sym = (nibble_swap(*src) >> (4u * ((uint32_t)at & 7u))) & 15u;
-            const uint32_t oriented = rev ? rc_code(sym) : sym;
-            // copy_direct / convert_to_rev_comp: anything but ACGT is N_read (sam.cpp:2296-2347);
-            // ref_copy_direct clamps to N_ref (sam.cpp:2372-2374)
-            const uint32_t letter = decode(ins ? ((ap.ascii && oriented > 3u) ? 4u : oriented) : (sym > 5u ? 5u : sym));
-            slot[cur] = (uint8_t)(k == DIR_X ? letter : (ins ? (uint32_t)'#' : (uint32_t)'^'));
-            if (k != DIR_X)
-                slot[cur + 1] = (uint8_t)letter;
+            e_have = true;
+            e_raw = raw;
+            e_sh = 4u * ((uint32_t)at & 7u);
+            e_cur = cur;
+            e_k = k;
             cur += k == DIR_X ? 1u : 2u;
             ri += k != DIR_H ? 1u : 0u;
             gi += ins ? 0u : 1u;
@@ -1278,6 +1332,7 @@ __global__ __launch_bounds__(256) void align_replay_kernel(GenomeView g, ReadsVi
         gi += left;
         opi += left;
     }
+    emit();
     if (pend && t2 + 1u < nsteps)
         refine_now();
     slot[cur] = 0;
@@ -1292,6 +1347,11 @@ __global__ __launch_bounds__(256) void align_replay_kernel(GenomeView g, ReadsVi
     r.refined = refined;
     r.reserved = 0;
     ap.results[gid] = r;
+    }
+    if (STAGED) {
+        __syncthreads();   // one wave per block: the rows are complete
+        wave_out(true);
+    }
 }
 
 // ---- host side -----------------------------------------------------------------------
@@ -1366,7 +1426,11 @@ static int launch_tb(const GenomeView& g, const ReadsView& rv, AlignParams ap, u
 {
     if constexpr (WW == 0) {
         hipLaunchKernelGGL((align_traceback_kernel<NW, WW, BLOCK, 1>), dim3(blocks), dim3(BLOCK), 0, s, g, rv, ap);
-        hipLaunchKernelGGL(align_replay_kernel, dim3((groups + 3u) / 4u ? (groups + 3u) / 4u : 1u), dim3(256), 0, s, g, rv, ap);
+        const uint32_t lds = 256u * ap.rp_sw;   // a wave's rows
+        if (lds <= 40u * 1024u)   // (four waves per CU at least; longer reads take the form without LDS)
+            hipLaunchKernelGGL(align_replay_kernel<true>, dim3(groups ? groups : 1u), dim3(64), lds, s, g, rv, ap);
+        else
+            hipLaunchKernelGGL(align_replay_kernel<false>, dim3((groups + 3u) / 4u ? (groups + 3u) / 4u : 1u), dim3(256), 0, s, g, rv, ap);
     } else {
         hipLaunchKernelGGL((align_traceback_kernel<NW, WW, BLOCK, 0>), dim3(blocks), dim3(BLOCK), 0, s, g, rv, ap);
     }
@@ -1445,6 +1509,9 @@ int launch_align(wamd_ctx* ctx, const wamd_reads* r, const wamd_dist_task* d_tas
         // alignment can span, from whatever nibble of a dword they start at
         ap.rd_cap = 0;   // the read comes straight from memory
         ap.gd_cap = (r->max_len + 30) / 8 + 2;
+        // staged replay (ed <= 14): a string of at most m + 29 bytes and its terminator, rounded up to dwords - an odd
+        // number of them
+        ap.rp_sw = ((r->max_len + 32u) >> 2) | 1u;
         const uint64_t per_block = L.per_block[cls];
         ap.slot_words = per_block / 8;
         uint64_t blocks64 = region / per_block;
