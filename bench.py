@@ -964,7 +964,7 @@ def main():
             out["roofline"]["traffic"] = meas["hbm_bytes_per_unit"] * n
         if "valu_insts_per_unit" in meas:
             out["roofline"]["measured_valu_frac"] = meas["valu_insts_per_unit"] * n / (kernel_ms * 1e-3) / PEAK_VALU_LANEOPS
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # (the contract: rank 0 at N = 1 only)
             threads = max(1, min(16, os.cpu_count() or 1))
             base, cpu_res = cpu_baseline(packed.cpu().numpy(), ref_size, blob, off, lens, tasks,
                                          min(args.cpu_sample, n), threads)
