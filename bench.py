@@ -388,6 +388,26 @@ def run_extras(ctx, device, genome_symbols, stream, n_small):
                        "workspace_bytes": wsb, "mean_ext_cigar_bytes": clen,
                        "roofline": roof_hbm(na, q(150) + q(180) + 16 + 40 + clen, ms,
                                             "myers_distance + align_classify + align_traceback x2")}
+    # the same call with the context in accepted-only mode: pass 1 is the banded kernel (no whole-column pass for
+    # tasks whose band fits); what the reference goes on with - the accepted tasks - must come back identical
+    cig = d_c.view(na, stride).cpu().numpy()
+    ctx.set_distance_mode(api.DISTANCE_ACCEPTED_ONLY)
+    ms_b = timed(lambda: ctx.align_dev(reads, d_t, na, d_r, d_c, stride, d_w, wsb, last_symbol=0, refine=1),
+                 tag="S4_align_accepted_only", units=na)
+    ctx.set_distance_mode(api.DISTANCE_EXACT)
+    res_b = d_r.cpu().numpy().view(api.ALIGN_RESULT)
+    cig_b = d_c.view(na, stride).cpu().numpy()
+    acc = res["ok"] == 1
+    same = bool((res_b[acc] == res[acc]).all() and (res_b["ok"][~acc] == 0).all())
+    for i in np.flatnonzero(acc)[:: max(1, int(acc.sum()) // 4096)]:   # strings up to their terminator, a sample
+        e = int(res["cigar_len"][i])
+        same = same and bool((cig_b[i, :e + 1] == cig[i, :e + 1]).all())
+    out["S4_align_accepted_only"] = {"shape": "S4 with the banded first pass (WAMD_DISTANCE_ACCEPTED_ONLY)", "tasks": na,
+                                     "total_ms": ms_b, "alignments_per_s": na / ms_b * 1e3,
+                                     "accepted_identical": same,
+                                     "roofline": roof_hbm(na, q(150) + q(180) + 16 + 40 + clen, ms_b,
+                                                          "myers_band + align_classify + align_traceback x2")}
+    del cig, cig_b, res_b
     reads.free()
     del d_t, d_r, d_w
 
