@@ -115,3 +115,33 @@ def test_shard_bins_partition():
     for world in (1, 2, 4, 8):
         seen = sorted(b for r in range(world) for b in gather.shard_bins(384, world, r))
         assert seen == list(range(384))
+
+
+def _run_bench(args, env_extra=None):
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, cwd=root,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+
+
+def test_bench_starts_its_own_ranks_and_refuses_a_cpu_run():
+    """`python bench.py --gpus 2` with no launcher starts two ranks as a child torch.distributed.run; on a machine
+    without a GPU each of them stops with the "needs a GPU" message (no CPU fallback), nothing reaches stdout and the
+    exit status is not 0.  (Skipped where a GPU is present: there the same command is a real two-rank run.)"""
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("a GPU is present")
+    p = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"])
+    assert p.returncode != 0
+    assert p.stdout.strip() == b""
+    assert p.stderr.count(b"bench.py needs a GPU") >= 2
+
+
+def test_bench_refuses_a_world_size_that_differs_from_gpus():
+    p = _run_bench(["--gpus", "2"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert p.returncode != 0
+    assert p.stdout.strip() == b""
+    assert b"--gpus 2 but the launcher started 1 rank" in p.stderr
