@@ -620,9 +620,26 @@ typedef struct wamd_finish_task {
     int32_t ref_size;              /* the chromosome's size + no_initial_Ns + no_final_Ns   */
     uint16_t err_edit_distance;
     uint8_t direct;                /* mapping.direction == genome_t::direct                 */
-    uint8_t distant;
-    uint32_t reserved[3];
+    uint8_t distant;               /* 0 / 1: fill_cigar's argument as the host computed it; WAMD_DISTANT_FROM_PAIR:  */
+                                   /* computed on the device as sam.cpp:1881-1884 does, see below                    */
+    int32_t isize_min;             /* WAMD_DISTANT_FROM_PAIR only: ceil(mean - getMyersDev) and floor(mean +          */
+    int32_t isize_max;             /* getMyersDev) of the insert-size model, the same in both slots of a pair        */
+    uint32_t flags;                /* WAMD_FINISH_*                                                                  */
 } wamd_finish_task;
+
+/* distant = WAMD_DISTANT_FROM_PAIR: isDistant of sam.cpp:1881-1884, `isize > mean + MyersDev || isize < mean -
+ * MyersDev` with isize = mapping_pair_t::calculateInsertSize (common/types.h:482-515) of the pair AS IT STANDS WHEN
+ * fill_cigar IS CALLED: for slot 2i both mappings as constructed (ref_length = read length, sam.cpp:1581), for
+ * slot 2i + 1 the first mapping after its own fill_cigar, clipIllegalPositions and clipBoundaryPositions have moved
+ * its position and length - which no host can know before the call.  isize is an int, so the two comparisons are
+ * exact against the integer bounds isize_min / isize_max.  (For the non-lev types the pair's chromosome and position
+ * are the task's, i.e. Translate(examined_start_pos): the constructor's unless the window start lies across a
+ * chromosome border.) */
+#define WAMD_DISTANT_FROM_PAIR 2u
+/* The host's Translate(examined_start_pos) failed for this non-lev record (a window start inside the N border in front
+ * of the first chromosome): fill_cigar_with_indel_matching then leaves mapping.pos and the chromosome alone
+ * (sam_matching.cpp:843-849); ref_seq_id / ref_seq_pos / ref_size are the constructor's. */
+#define WAMD_FINISH_NO_TRANSLATE 1u
 
 /* CParams fields the chain reads. */
 typedef struct wamd_finish_params {
@@ -640,8 +657,11 @@ enum {
 };
 
 /* The fields of mapping_desc_t the SAM record is written from (store_mapping_result,
- * sam.cpp:2013-2017).  ok = 0: fill_cigar could not align the record (the reference counts it in
- * stat_mapped_pe_errors and goes on with a null ext-CIGAR); the slot's outputs are then empty. */
+ * sam.cpp:2013-2017).  ok = 0: fill_cigar could not align the record.  The reference counts it in
+ * stat_mapped_pe_errors and goes on with a null ext-CIGAR, which clipBoundaryPositions (err_edit_distance != 0)
+ * and extract_cigar_and_mdz then dereference: it does not survive such a record (the mapping stage's error count
+ * rules it out).  Here the slot reports ok = 0 with empty outputs and stays out of the pair clipping; its mate is
+ * finished as usual. */
 typedef struct wamd_finish_result {
     double score;                  /* AS:i: is Double2PChar of it                            */
     uint32_t pos;                  /* mapping.pos after fill_cigar                           */

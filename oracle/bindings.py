@@ -71,7 +71,7 @@ def _sam_cigar(fn, ext_cigars, out_stride=None):
 FINISH_TASK = np.dtype([("read_idx", "<u4"), ("pos", "<u4"), ("type", "<u4"), ("penalty", "<u4"), ("matching_len1", "<u4"),
                         ("matching_len2", "<u4"), ("indel_len1", "<i4"), ("indel_len2", "<i4"), ("clipping_len", "<u4"),
                         ("ref_seq_id", "<i4"), ("ref_seq_pos", "<i4"), ("ref_size", "<i4"), ("err_edit_distance", "<u2"),
-                        ("direct", "u1"), ("distant", "u1"), ("reserved", "<u4", (3,))])
+                        ("direct", "u1"), ("distant", "u1"), ("isize_min", "<i4"), ("isize_max", "<i4"), ("flags", "<u4")])
 FINISH_RESULT = np.dtype([("score", "<f8"), ("pos", "<u4"), ("ref_seq_pos", "<i4"), ("ref_length", "<u2"),
                           ("err_edit_distance", "<u2"), ("num_events", "<u2"), ("left_clipping", "<u2"),
                           ("right_clipping", "<u2"), ("method", "<u2"), ("ext_cigar_len", "<u4"), ("cigar_len", "<u4"),
@@ -463,7 +463,7 @@ def _o_finish_pairs(self, genome, reads, offsets, lens, tasks, params=None, scor
 
 
 def _r_finish_pairs(self, genome, ref_size, desc, reads, offsets, lens, read_idx, wire, distant, stale_penalty,
-                    params=None, scoring=None, max_approx_indel_len=50, ext_stride=512):
+                    params=None, scoring=None, max_approx_indel_len=50, ext_stride=512, model=(500.0, 125.0)):
     """The reference's own chain from the wire records on: returns (rc, tasks as the generator constructs them,
     results, ext-CIGARs, CIGARs, MD:Z)."""
     prm = params or default_finish_params()
@@ -476,7 +476,8 @@ def _r_finish_pairs(self, genome, ref_size, desc, reads, offsets, lens, read_idx
                                          _p(offsets), _p(lens), C.c_uint32(n // 2), _p(_c(read_idx, np.uint32)),
                                          _p(_c(wire, np.uint8)), _p(_c(distant, np.uint8)),
                                          _p(_c(stale_penalty, np.uint32)), C.byref(prm), C.byref(sc),
-                                         C.c_uint32(max_approx_indel_len), _p(tasks), _p(res), _p(ext),
+                                         C.c_uint32(max_approx_indel_len), C.c_double(model[0]), C.c_double(model[1]),
+                                         _p(tasks), _p(res), _p(ext),
                                          C.c_uint32(ext.shape[1]), _p(cig), C.c_uint32(cig.shape[1]), _p(mdz),
                                          C.c_uint32(mdz.shape[1]))
     return rc, tasks, res, ext, cig, mdz

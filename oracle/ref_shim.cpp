@@ -15,6 +15,7 @@
  */
 #include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <memory>
@@ -738,7 +739,7 @@ REF_API int ref_finish_pairs_batch(const uint8_t* genome, uint32_t ref_size, con
                                    uint32_t n_pairs, const uint32_t* read_idx, const uint8_t* wire,
                                    const uint8_t* distant, const uint32_t* stale_penalty,
                                    const wamd_finish_params* prm, const wamd_scoring* sc, uint32_t max_approx_indel_len,
-                                   wamd_finish_task* tasks_out, wamd_finish_result* results, uint8_t* ext_cigars,
+                                   double model_mean, double model_dev, wamd_finish_task* tasks_out, wamd_finish_result* results, uint8_t* ext_cigars,
                                    uint32_t ext_stride, uint8_t* cigars, uint32_t cigar_stride, uint8_t* mdz,
                                    uint32_t mdz_stride)
 {
@@ -753,7 +754,7 @@ REF_API int ref_finish_pairs_batch(const uint8_t* genome, uint32_t ref_size, con
     box.params.enable_short_indel_refinement = prm->enable_short_indel_refinement != 0;
     box.params.max_approx_indel_len = max_approx_indel_len;
     scoring_t scoring = make_scoring(sc);
-    InsertSizeModel model(500.0, 125.0, 100, 10000, 4.0, 7.0, 7.0, scoring);
+    InsertSizeModel model(model_mean, model_dev, 100, 10000, 4.0, 7.0, 7.0, scoring);   /* sam.cpp:185-188 */
     CSoftClipping clip(max_query_len, max_text_len, 3, max_approx_indel_len, 0);
     clip.setReference(const_cast<uint8_t*>(genome), 0, 0);
     CIndelMatching im(&box.params);
@@ -828,6 +829,8 @@ REF_API int ref_finish_pairs_batch(const uint8_t* genome, uint32_t ref_size, con
                 if (desc.Translate(examined, ref_seq_name, pos2, id2, name)) {
                     ref_seq_id = id2;
                     ref_seq_pos = pos2;
+                } else {
+                    t.flags |= WAMD_FINISH_NO_TRANSLATE;
                 }
             }
             t.ref_seq_id = ref_seq_id;
@@ -837,23 +840,33 @@ REF_API int ref_finish_pairs_batch(const uint8_t* genome, uint32_t ref_size, con
             t.err_edit_distance = md[r].err_edit_distance;
             t.direct = cm.direction == genome_t::direct;
             t.distant = distant[slot];
+            /* isize is an int: `isize > mean + dev` <=> isize > floor(mean + dev), `isize < mean - dev` <=> isize < ceil(..) */
+            t.isize_max = (int32_t)std::floor(model.mean() + model.getMyersDev());
+            t.isize_min = (int32_t)std::ceil(model.mean() - model.getMyersDev());
         }
         mapping_pair_t mp(&md[0], &md[1]);
-        bool pair_ok = true;
-        /* sam.cpp:1871-1896 */
-        for (int r = 0; r < 2 && pair_ok; ++r) {
-            gen->fill_cigar(mp[r], name, seq[r], len[r], nullptr, distant[2 * i + r] != 0, true);
+        bool slot_ok[2] = {true, true};
+        /* sam.cpp:1871-1896.  A read fill_cigar cannot align keeps a null ext-CIGAR, which the reference then
+         * dereferences (clipBoundaryPositions with err_edit_distance != 0, extract_cigar_and_mdz): the calls it would
+         * not survive are skipped here, the mate is finished as the loop does. */
+        for (int r = 0; r < 2; ++r) {
+            bool is_distant = distant[2 * i + r] != 0;
+            if (distant[2 * i + r] == WAMD_DISTANT_FROM_PAIR) {   /* sam.cpp:1881-1884 */
+                int isize = mp.calculateInsertSize();
+                is_distant = isize > model.mean() + model.getMyersDev() || isize < model.mean() - model.getMyersDev();
+            }
+            gen->fill_cigar(mp[r], name, seq[r], len[r], nullptr, is_distant, true);
             const bool perfect = mp[r].method == MatchingMethod::Enumeration::Perfect ||
                                  mp[r].method == MatchingMethod::Enumeration::PerfectDistant;
-            if (!perfect && !mp[r].ext_cigar) {   /* stat_mapped_pe_errors: the reference goes on with a null ext-CIGAR */
-                pair_ok = false;
-                break;
+            if (!perfect && !mp[r].ext_cigar) {   /* stat_mapped_pe_errors */
+                slot_ok[r] = false;
+                continue;
             }
             clip.clipIllegalPositions(mp[r], model.getScoring(), desc.GetDescription(), pool);
             if (prm->enable_boundary_clipping)
                 clip.clipBoundaryPositions(mp[r], model.getScoring());
         }
-        if (pair_ok && prm->enable_paired_clipping)
+        if (slot_ok[0] && slot_ok[1] && prm->enable_paired_clipping)
             clip.clipOverlappingPairs(mp, model.getScoring(), pool);   /* sam.cpp:1898-1900 */
         for (int r = 0; r < 2; ++r) {
             const uint32_t slot = 2 * i + r;
@@ -864,7 +877,7 @@ REF_API int ref_finish_pairs_batch(const uint8_t* genome, uint32_t ref_size, con
             uint8_t* mz = mdz + (size_t)slot * mdz_stride;
             ec[0] = cg[0] = mz[0] = 0;
             mapping_desc_t& m = mp[r];
-            if (pair_ok) {
+            if (slot_ok[r]) {
                 o.ok = 1;
                 o.score = m.score;
                 o.pos = m.mapping.pos;

@@ -2337,6 +2337,25 @@ int wo_sam_cigar_batch(uint32_t n, const uint8_t* ext_cigars, uint32_t ext_strid
  * above with the glue of fill_cigar (sam_matching.cpp:667-686), fill_cigar_with_lev (689-752) and
  * fill_cigar_with_indel_matching (824-852).  Input: the descriptors as the generator constructs
  * them (sam.cpp:1555-1580); slot 2i = p.first, 2i + 1 = p.second. */
+/* mapping_pair_t::calculateInsertSize, common/types.h:482-515 */
+static int wo_insert_size(int32_t id0, int32_t pos0, int32_t len0, int direct0, int32_t id1, int32_t pos1, int32_t len1,
+                          int direct1)
+{
+    if (id0 != id1)
+        return 0x7fffffff;
+    int left_is_first;
+    if (pos0 < pos1)
+        left_is_first = 1;
+    else if (pos0 == pos1)
+        left_is_first = direct0 ? 1 : 0;
+    else
+        left_is_first = 0;
+    const int left_direct = left_is_first ? direct0 : direct1;
+    if (direct0 == direct1 || !left_direct)
+        return 0x7fffffff;
+    return left_is_first ? pos1 - pos0 + len1 : pos0 - pos1 + len0;
+}
+
 int wo_finish_pairs_batch(const uint8_t* genome, const uint8_t* reads, const uint64_t* offsets, const uint32_t* lens,
                           const wamd_finish_task* tasks, uint32_t n_pairs, const wamd_finish_params* prm,
                           const wamd_scoring* sc, wamd_finish_result* results, uint8_t* ext_cigars,
@@ -2351,24 +2370,33 @@ int wo_finish_pairs_batch(const uint8_t* genome, const uint8_t* reads, const uin
         wamd_clip_record rec[2];
         int perfect[2] = {0, 0}, method[2] = {WAMD_METHOD_UNMATCHED, WAMD_METHOD_UNMATCHED};
         uint32_t pos[2], events[2] = {0, 0};
-        int pair_ok = 1;
+        int slot_ok[2] = {1, 1};
+        for (int r = 0; r < 2; ++r) {   /* the two mappings as constructed, sam.cpp:1579-1581 */
+            const wamd_finish_task* t = &tasks[2 * i + r];
+            memset(&rec[r], 0, sizeof(rec[r]));
+            rec[r].ref_seq_pos = t->ref_seq_pos;
+            rec[r].ref_length = (uint16_t)lens[t->read_idx];
+            rec[r].err_edit_distance = t->err_edit_distance;
+            rec[r].score = -1;
+            pos[r] = t->pos;
+        }
         for (int r = 0; r < 2; ++r) {
             const uint32_t slot = 2 * i + r;
             const wamd_finish_task* t = &tasks[slot];
             uint8_t* ec = ext_cigars + (size_t)slot * ext_stride;
             const uint32_t m = lens[t->read_idx];
             ec[0] = 0;
-            memset(&rec[r], 0, sizeof(rec[r]));
-            rec[r].ref_seq_pos = t->ref_seq_pos;
-            rec[r].ref_length = (uint16_t)m;          /* sam.cpp:1578 */
-            rec[r].err_edit_distance = t->err_edit_distance;
-            rec[r].score = -1;
-            pos[r] = t->pos;
-            if (!pair_ok)
-                continue;
+            int distant = t->distant;
+            if (distant == (int)WAMD_DISTANT_FROM_PAIR) {   /* sam.cpp:1881-1884: the pair as it stands now */
+                const wamd_finish_task* t0 = &tasks[2 * i];
+                const wamd_finish_task* t1 = &tasks[2 * i + 1];
+                const int isize = wo_insert_size(t0->ref_seq_id, rec[0].ref_seq_pos, rec[0].ref_length, t0->direct,
+                                                 t1->ref_seq_id, rec[1].ref_seq_pos, rec[1].ref_length, t1->direct);
+                distant = isize > t->isize_max || isize < t->isize_min;
+            }
             if (t->err_edit_distance == 0 && t->penalty == 0) {   /* sam_matching.cpp:670-680 */
                 perfect[r] = 1;
-                method[r] = t->distant ? WAMD_METHOD_PERFECT_DISTANT : WAMD_METHOD_PERFECT;
+                method[r] = distant ? WAMD_METHOD_PERFECT_DISTANT : WAMD_METHOD_PERFECT;
                 rec[r].score = m * sc->match;
             } else if (t->type == WAMD_MAP_LEV) {                  /* sam_matching.cpp:689-752 */
                 wamd_dist_task dt;
@@ -2385,7 +2413,11 @@ int wo_finish_pairs_batch(const uint8_t* genome, const uint8_t* reads, const uin
                 if (rc)
                     break;
                 if (!ar.ok) {
-                    pair_ok = 0;
+                    /* stat_mapped_pe_errors: the reference goes on with a null ext-CIGAR and dereferences it in
+                     * clipBoundaryPositions / extract_cigar_and_mdz - it does not survive this record.  Here the
+                     * slot is reported as not finished, its mate is finished as usual, the pair is not pair-clipped. */
+                    slot_ok[r] = 0;
+                    ec[0] = 0;
                     continue;
                 }
                 const int64_t delta = ((int64_t)dt.ref_pos + ar.begin_pos) - (int64_t)begin;
@@ -2394,7 +2426,7 @@ int wo_finish_pairs_batch(const uint8_t* genome, const uint8_t* reads, const uin
                 pos[r] = (uint32_t)((int64_t)t->pos + delta);
                 rec[r].ref_seq_pos = (int32_t)((int64_t)t->ref_seq_pos + delta);
                 rec[r].ref_length = (uint16_t)(ar.end_pos - ar.begin_pos);
-                method[r] = t->distant ? WAMD_METHOD_FROM_MAPPING_DISTANT : WAMD_METHOD_FROM_MAPPING;
+                method[r] = distant ? WAMD_METHOD_FROM_MAPPING_DISTANT : WAMD_METHOD_FROM_MAPPING;
                 events[r] = ar.num_events;
                 rec[r].score = ar.affine_score;
             } else {                                               /* sam_matching.cpp:824-852 */
@@ -2412,10 +2444,12 @@ int wo_finish_pairs_batch(const uint8_t* genome, const uint8_t* reads, const uin
                 ct.flags = t->direct ? 0 : WAMD_TASK_FLAG_REV_COMP;
                 wo_indel_query(query, reads + offsets[t->read_idx], m, WAMD_READS_ASCII, !t->direct);
                 if (!wo_indel_ext_cigar(genome, query, m, &ct, sc, &cr, ec)) {
-                    pair_ok = 0;
+                    slot_ok[r] = 0;
+                    ec[0] = 0;
                     continue;
                 }
-                pos[r] = ct.examined_start_pos;
+                if (!(t->flags & WAMD_FINISH_NO_TRANSLATE))       /* sam_matching.cpp:843-848 */
+                    pos[r] = ct.examined_start_pos;
                 rec[r].score = cr.score;
                 rec[r].err_edit_distance = cr.err_edit_distance;
                 rec[r].ref_length = cr.ref_length;
@@ -2436,7 +2470,7 @@ int wo_finish_pairs_batch(const uint8_t* genome, const uint8_t* reads, const uin
         }
         if (rc)
             break;
-        if (pair_ok && prm->enable_paired_clipping) {   /* sam.cpp:1898-1900 */
+        if (slot_ok[0] && slot_ok[1] && prm->enable_paired_clipping) {   /* sam.cpp:1898-1900 */
             wamd_clip_pair_task pt;
             for (int r = 0; r < 2; ++r) {
                 pt.ref_seq_id[r] = tasks[2 * i + r].ref_seq_id;
@@ -2457,7 +2491,7 @@ int wo_finish_pairs_batch(const uint8_t* genome, const uint8_t* reads, const uin
             uint8_t* mz = mdz + (size_t)slot * mdz_stride;
             memset(o, 0, sizeof(*o));
             cg[0] = mz[0] = 0;
-            if (!pair_ok) {
+            if (!slot_ok[r]) {
                 ec[0] = 0;
                 continue;
             }

@@ -5,6 +5,23 @@ from whisper_amd import synth
 
 _GENOMES = {}
 
+# non-default scoring_t values (user flags -match, -mismatch, -gap-*, -clipping: mapper/params.h:111-192):
+# "asym": insertion and deletion costs differ (SURVEY appendix A hazards 8, 9); "odd": no value is a multiple
+# of 0.2, so sums are not exact in binary and one decimal of AS:i: can round either way (hazard 11)
+SCORING_VALUES = {
+    "asym": (2.0, -3.0, -4.0, -0.6, -6.0, -0.2, -4.0),
+    "odd": (1.0, -4.3, -5.7, -0.37, -4.9, -0.53, -7.1),
+}
+
+
+def scoring(name, module=None):
+    """A Scoring struct (oracle.bindings' by default, whisper_amd.api's when module=api) or None for the default."""
+    if name in (None, "default"):
+        return None
+    if module is None:
+        from oracle import bindings as module
+    return module.Scoring(*SCORING_VALUES[name])
+
 
 def genome(n_symbols=1 << 20, seed=1):
     key = (n_symbols, seed)
@@ -225,7 +242,7 @@ def indel_cigar_tasks(match_tasks, mappings):
     return t
 
 
-def clip_workload(n, m, seed, gen=None):
+def clip_workload(n, m, seed, gen=None, scoring=None):
     """ext-CIGARs with noisy ends (what clipBoundaryPositions clips) produced by aligning
     reads whose first / last symbols are junk; returns (records, cigars) as the caller of
     clipBoundaryPositions holds them after fill_cigar_with_lev."""
@@ -249,7 +266,7 @@ def clip_workload(n, m, seed, gen=None):
     tasks = synth.distance_tasks(rd, m, k)
     orc = ob.Oracle()
     stride = 4 * ((2 * (m + k) + 8 + 3) // 4)
-    rc, res, cig = orc.align(packed, blob, off, lens, 1, tasks, 0, 1, cigar_stride=stride)
+    rc, res, cig = orc.align(packed, blob, off, lens, 1, tasks, 0, 1, cigar_stride=stride, scoring=scoring)
     ok = np.nonzero(res["ok"])[0]
     rec = np.zeros(len(ok), ob.CLIP_RECORD)
     rec["score"] = res["affine_score"][ok]
@@ -333,13 +350,13 @@ def ext_cigar_pool(oracle, n=3000, seed=11, stride=512):
     return np.ascontiguousarray(np.concatenate(pool))
 
 
-def clip_illegal_workload(oracle, n, seed, m=150):
+def clip_illegal_workload(oracle, n, seed, m=150, scoring=None):
     """Inputs of clipIllegalPositions (soft_clipping.cpp:592-729): aligned records (some already
     boundary-clipped, some perfect matches without an ext-CIGAR) placed so that they hang over the
     start of their chromosome, over its end, over both, or not at all."""
     from oracle import bindings as ob
-    rec, cig = clip_workload(n, m, seed)
-    _, rec_b, cig_b = oracle.clip_boundary(rec, cig)
+    rec, cig = clip_workload(n, m, seed, scoring=scoring)
+    _, rec_b, cig_b = oracle.clip_boundary(rec, cig, scoring)
     rng = np.random.default_rng(seed)
     n = len(rec)
     use_b = rng.random(n) < 0.3
@@ -355,7 +372,7 @@ def clip_illegal_workload(oracle, n, seed, m=150):
     rec["err_edit_distance"][perfect] = 0
     rec["left_clipping"][perfect] = 0
     rec["right_clipping"][perfect] = 0
-    rec["score"][perfect] = float(m)
+    rec["score"][perfect] = float(m) * (scoring.match if scoring is not None else 1.0)
     rec["cigar_len"] = [len(bytes(c).split(b"\0")[0]) for c in cig]
     kind = rng.integers(0, 4, n)
     over_l = rng.integers(0, 40, n)
@@ -368,12 +385,12 @@ def clip_illegal_workload(oracle, n, seed, m=150):
     return tasks, rec, np.ascontiguousarray(cig)
 
 
-def clip_pairs_workload(oracle, n_pairs, seed, m=150):
+def clip_pairs_workload(oracle, n_pairs, seed, m=150, scoring=None):
     """Inputs of clipOverlappingPairs (soft_clipping.cpp:997-1044): pairs of aligned records, most of
     them with the reverse read left of and overlapping the forward read, plus the cases the routine
     leaves alone (other chromosome, a clipped mate, proper order, no overlap) and perfect matches."""
     from oracle import bindings as ob
-    rec, cig = clip_workload(2 * n_pairs + 64, m, seed)
+    rec, cig = clip_workload(2 * n_pairs + 64, m, seed, scoring=scoring)
     n_pairs = min(n_pairs, len(rec) // 2)
     rec, cig = rec[:2 * n_pairs].copy(), np.ascontiguousarray(cig[:2 * n_pairs])
     rng = np.random.default_rng(seed + 1)
@@ -389,7 +406,7 @@ def clip_pairs_workload(oracle, n_pairs, seed, m=150):
                 cig[q] = 0
                 rec["ref_length"][q] = m
                 rec["err_edit_distance"][q] = 0
-                rec["score"][q] = float(m)
+                rec["score"][q] = float(m) * (scoring.match if scoring is not None else 1.0)
         la = int(rec["ref_length"][a])
         swap = bool(rng.integers(0, 2))            # which of first / second is the left one
         l, r = (b, a) if swap else (a, b)
@@ -510,11 +527,16 @@ def translate(desc, raw_pos):
     return True, j - 1, int(raw_pos - c[1] + c[2] - c[4] + 1)
 
 
-def finish_tasks(desc, read_idx, lens, mappings, direct, distant, stale_penalty=None, scoring=(1.0, -5.0, -5.0, -0.4, -5.0, -0.4)):
-    """mapping_desc_t as store_mapped_pair_reads constructs it from a record (sam.cpp:1555-1580,
+def finish_tasks(desc, read_idx, lens, mappings, direct, distant, stale_penalty=None, scoring=None, isize=(-375, 1375)):
+    """isize: ceil / floor of mean -+ getMyersDev of the insert-size model (default: the untrained model, 500 -+ 7 * 125).
+    mapping_desc_t as store_mapped_pair_reads constructs it from a record (sam.cpp:1555-1580,
     common/types.h:371-425): the input of wamd_finish_pairs."""
     from whisper_amd import api
-    match, mismatch, ins_o, ins_e, del_o, del_e = scoring
+    if scoring is None:
+        match, mismatch, ins_o, ins_e, del_o, del_e = 1.0, -5.0, -5.0, -0.4, -5.0, -0.4
+    else:
+        match, mismatch, ins_o, ins_e, del_o, del_e = (scoring.match, scoring.mismatch, scoring.gap_ins_open,
+                                                       scoring.gap_ins_extend, scoring.gap_del_open, scoring.gap_del_extend)
     n = len(read_idx)
     t = np.zeros(n, api.FINISH_TASK)
 
@@ -531,6 +553,7 @@ def finish_tasks(desc, read_idx, lens, mappings, direct, distant, stale_penalty=
         if not ok:
             spos = 0
         ty, nm = int(mp["type"]), int(mp["no_mismatches"]) & 0x3f
+        flags = 0
         if ty == 0:
             ed, pen = nm, int(stale_penalty[i]) if stale_penalty is not None else 0
         else:
@@ -544,6 +567,8 @@ def finish_tasks(desc, read_idx, lens, mappings, direct, distant, stale_penalty=
             ok2, sid2, spos2 = translate(desc, int(mp["pos"]) if direct[i] else int(mp["pos"]) - (m - 1))
             if ok2:
                 sid, spos = sid2, spos2
+            else:
+                flags = 1      # WAMD_FINISH_NO_TRANSLATE: mapping.pos and the chromosome stay (sam_matching.cpp:843-849)
         # what the wire record carries per type (results.cpp:161-275): the rest deserialises as 0
         carried = {0: (), 1: ("matching_len1", "indel_len1"), 2: ("matching_len1", "matching_len2", "indel_len1", "indel_len2"),
                    3: ("matching_len1", "clipping_len", "indel_len1"), 4: ("matching_len1", "clipping_len", "indel_len1"),
@@ -552,11 +577,15 @@ def finish_tasks(desc, read_idx, lens, mappings, direct, distant, stale_penalty=
              for f in ("matching_len1", "matching_len2", "indel_len1", "indel_len2", "clipping_len")}
         t[i] = (read_idx[i], mp["pos"], ty, pen, v["matching_len1"], v["matching_len2"], v["indel_len1"],
                 v["indel_len2"], v["clipping_len"], sid, spos, int(desc[sid, 0] + desc[sid, 2] + desc[sid, 3]),
-                ed, direct[i], distant[i], (0, 0, 0))
+                ed, direct[i], distant[i], isize[0], isize[1], flags)
     return t
 
 
-def finish_workload(oracle, n_pairs, seed, m=150, flank=6, gen=None):
+FINISH_MODEL = (330.0, 12.0)       # an insert-size model that calls part of finish_workload's pairs distant
+FINISH_ISIZE = (246, 414)          # ceil(mean - 7 dev), floor(mean + 7 dev): getMyersDev = 7 sigma (sam.cpp:185-188)
+
+
+def finish_workload(oracle, n_pairs, seed, m=150, flank=6, gen=None, scoring=None, from_pair_frac=0.0):
     """Pairs as store_mapped_pair_reads holds them once it has picked one: perfect matches, lev records with
     substitutions / short indels / the refinement pattern, indel-matcher records of every type, junk ends (boundary
     clipping), mappings over a chromosome's end or before its first base (illegal positions), reverse reads left of
@@ -574,7 +603,10 @@ def finish_workload(oracle, n_pairs, seed, m=150, flank=6, gen=None):
 
     # a pool of indel-matcher records (direct-strand Match on reads carrying one long indel or junk ends)
     _, _, (iblob, ioff, ilens), itasks = indel_workload(max(64, n_pairs), m, seed + 1, gen=(codes, packed))
-    _, imap = oracle.indel_match(packed, iblob, ioff, ilens, 0, itasks, ob.default_indel_params(0.6))
+    iprm = ob.default_indel_params(0.6)
+    if scoring is not None:
+        iprm.scoring = scoring
+    _, imap = oracle.indel_match(packed, iblob, ioff, ilens, 0, itasks, iprm)
     ipool = [j for j in np.nonzero(imap["found"])[0]]
     icodes = np.zeros((len(ilens), m), np.uint8)
     ib = iblob.reshape(len(ilens), -1)
@@ -679,6 +711,9 @@ def finish_workload(oracle, n_pairs, seed, m=150, flank=6, gen=None):
     distant = (rng.random(2 * n_pairs) < 0.1).astype(np.uint8)
     stale = np.zeros(2 * n_pairs, np.uint32)
     stale[lev] = np.where(rng.random(len(lev)) < 0.05, 3, 0)   # a lev record deserialised after a non-lev one
+    if from_pair_frac > 0:     # isDistant left to the device (WAMD_DISTANT_FROM_PAIR), both slots of a pair
+        rng2 = np.random.default_rng(seed + 77)
+        distant[np.repeat(rng2.random(n_pairs) < from_pair_frac, 2)] = 2
     return (codes, packed), (blob, off, lens), desc, read_idx, mappings, direct, distant, stale
 
 

@@ -130,6 +130,23 @@ def make_finish(ref, codes, packed, ref_size):
                             flank=6, ext_stride=512)
         print(name, "methods", np.bincount(res["method"], minlength=27), "clipped",
               int(((res["left_clipping"] > 0) | (res["right_clipping"] > 0)).sum()))
+    # round 3: isDistant computed inside the chain for 60 % of the pairs (WAMD_DISTANT_FROM_PAIR; a model of 330 +- 7 * 12
+    # makes part of them distant) and every ninth lev record claiming fewer errors than it has (fill_cigar_with_lev fails:
+    # the slot is reported as not finished, the mate is finished)
+    (_, _), (blob, off, lens), desc, ridx, maps, direct, distant, stale = common.finish_workload(
+        orc, 300, 8102, m=150, gen=(codes, packed), from_pair_frac=0.6)
+    lev = np.nonzero((maps["type"] == 0) & (maps["no_mismatches"] > 2))[0]
+    maps["no_mismatches"][lev[::9]] = 1
+    _, wire, sizes = ref.serialize(maps, direct)
+    rc, tasks, res, ext, cig, mdz = ref.finish_pairs(packed, ref_size, desc, blob, off, lens, ridx, wire, distant, stale,
+                                                     ext_stride=512, model=common.FINISH_MODEL)
+    assert rc == 0 and 5 < (res["ok"] == 0).sum() < 100
+    w = [int(res[f].max()) + 1 for f in ("ext_cigar_len", "cigar_len", "mdz_len")]
+    np.savez_compressed(os.path.join(HERE, "finish_m150_frompair.npz"), kind="finish", blob=blob, off=off, lens=lens,
+                        desc=desc, read_idx=ridx, wire=wire, wire_sizes=sizes, distant=distant, stale_penalty=stale,
+                        tasks=tasks, results=res, ext_cigars=ext[:, :w[0]], cigars=cig[:, :w[1]], mdz=mdz[:, :w[2]],
+                        flank=6, ext_stride=512)
+    print("finish_m150_frompair methods", np.bincount(res["method"], minlength=27), "not finished", int((res["ok"] == 0).sum()))
 
 
 def make_groups(ref):
@@ -220,6 +237,81 @@ def make_round2(ref, codes, packed, ref_size):
     print("dist_m250_k7 accepted", int((res["edit_distance"] <= 7).sum()), "of", 600)
 
 
+def make_scoring(ref, codes, packed, ref_size):
+    """Round 3: every routine that reads a score, under two non-default scoring_t (common.SCORING_VALUES: one
+    asymmetric in insertion / deletion costs, one whose values are not multiples of 0.2), from the reference's own
+    objects: getExtCigar + refine_ext_cigar, Match + GetExtCigarNew, clipBoundaryPositions, clipIllegalPositions,
+    CSoftClipping::getExtCigar and the finish chain (mapping_desc_t's indel_to_mismatch_score included)."""
+    orc = bindings.Oracle()
+    seed = 9000
+    for sc_name in ("asym", "odd"):
+        sc = common.scoring(sc_name)
+        scv = np.array(common.SCORING_VALUES[sc_name], np.float64)
+        seed += 10
+        for name, m, k, W, n in (("align_m150_k13_w177", 150, 13, 177, 600), ("align_m150_k26_w660", 150, 26, 660, 300)):
+            rd = synth.make_reads(codes, n, m, k, seed + (W % 7))
+            blob, off, lens = common.host_reads(rd, 1)
+            tasks = synth.distance_tasks(rd, m, k, W, 0)
+            stride = 4 * ((2 * (m + k) + 8 + 3) // 4)
+            rc, res, cig = ref.align(packed, ref_size, blob, off, lens, 1, tasks, 0, 1, scoring=sc, cigar_stride=stride)
+            assert rc == 0
+            np.savez_compressed(os.path.join(HERE, "%s_sc_%s.npz" % (name, sc_name)), kind="align", blob=blob, off=off,
+                                lens=lens, encoding=1, last_symbol=0, refine=1, tasks=tasks, results=res, cigars=cig,
+                                cigar_stride=stride, scoring=scv)
+            print(name, sc_name, "ok", int(res["ok"].sum()), "refined", int(res["refined"].sum()), "of", n)
+        _, _, (blob, off, lens), tasks = common.planted_refine_workload(200, 150, 12, seed + 1, gen=(codes, packed))
+        stride = 4 * ((2 * (150 + 12) + 8 + 3) // 4)
+        rc, res, cig = ref.align(packed, ref_size, blob, off, lens, 1, tasks, 0, 1, scoring=sc, cigar_stride=stride)
+        np.savez_compressed(os.path.join(HERE, "align_refine_planted_m150_sc_%s.npz" % sc_name), kind="align", blob=blob,
+                            off=off, lens=lens, encoding=1, last_symbol=0, refine=1, tasks=tasks, results=res, cigars=cig,
+                            cigar_stride=stride, scoring=scv)
+        print("align_refine_planted", sc_name, "refined", int(res["refined"].sum()))
+        _, _, (blob, off, lens), tasks = common.indel_workload(600, 150, seed + 2, gen=(codes, packed))
+        prm = bindings.default_indel_params(0.6)
+        prm.scoring = sc
+        rc, res = ref.indel_match(packed, blob, off, lens, 0, tasks, prm)
+        ct = common.indel_cigar_tasks(tasks, res)
+        rc, cres, ccig = ref.indel_ext_cigar(packed, blob, off, lens, 0, ct, scoring=sc, cigar_stride=512)
+        direction = (np.arange(len(res)) % 3 != 0).astype(np.uint8)
+        rc, wire, sizes = ref.serialize(res, direction)
+        np.savez_compressed(os.path.join(HERE, "indel_m150_sc_%s.npz" % sc_name), kind="indel", blob=blob, off=off, lens=lens,
+                            encoding=0, min_clipped_factor=0.6, tasks=tasks, results=res, cigar_tasks=ct,
+                            cigar_results=cres, cigars=ccig, cigar_stride=512, direction=direction, wire=wire,
+                            wire_sizes=sizes, scoring=scv)
+        print("indel", sc_name, "found", int(res["found"].sum()), "insertions", int((ct["indel_len1"] < 0).sum()))
+        rec, cig = common.clip_workload(600, 150, seed + 3, gen=(codes, packed), scoring=sc)
+        rc, rec2, cig2 = ref.clip_boundary(rec, cig, sc)
+        np.savez_compressed(os.path.join(HERE, "clip_m150_sc_%s.npz" % sc_name), kind="clip", records=rec, cigars=cig,
+                            out_records=rec2, out_cigars=cig2, scoring=scv)
+        print("clip", sc_name, "changed", int((cig2 != cig).any(axis=1).sum()), "of", len(rec))
+        t, rec, cig = common.clip_illegal_workload(orc, 500, seed=seed + 4, scoring=sc)
+        rc, rec2, cig2 = ref.clip_illegal(t, rec, cig, sc)
+        assert rc == 0
+        np.savez_compressed(os.path.join(HERE, "clipillegal_m150_sc_%s.npz" % sc_name), kind="clipillegal", tasks=t,
+                            records=rec, cigars=cig, out_records=rec2, out_cigars=cig2, scoring=scv)
+        print("clipillegal", sc_name, "clipped", int((rec2["no_clippings"] > 0).sum()), "of", len(rec))
+        _, _, (blob, off, lens), tasks = common.softclip_workload(400, seed=seed + 5, W=700, encoding=1, gen=(codes, packed))
+        prm = bindings.default_softclip_params(fresh_object=0)
+        rc, res, cig = ref.softclip_match(packed, blob, off, lens, 1, tasks, prm, sc, cigar_stride=384)
+        assert rc == 0
+        np.savez_compressed(os.path.join(HERE, "softclip_m150_w700_sc_%s.npz" % sc_name), kind="softclip", blob=blob, off=off,
+                            lens=lens, encoding=1, tasks=tasks, results=res, cigars=cig, cigar_stride=384, fresh_object=0,
+                            max_query_len=151, max_mismatches=12, scoring=scv)
+        print("softclip", sc_name, "found", int(res["found"].sum()))
+        (_, _), (blob, off, lens), desc, ridx, maps, direct, distant, stale = common.finish_workload(
+            orc, 250, seed + 6, m=150, gen=(codes, packed), scoring=sc)
+        _, wire, sizes = ref.serialize(maps, direct)
+        rc, tasks, res, ext, cig, mdz = ref.finish_pairs(packed, ref_size, desc, blob, off, lens, ridx, wire, distant,
+                                                         stale, scoring=sc, ext_stride=512)
+        assert rc == 0 and res["ok"].all()
+        w = [int(res[f].max()) + 1 for f in ("ext_cigar_len", "cigar_len", "mdz_len")]
+        np.savez_compressed(os.path.join(HERE, "finish_m150_sc_%s.npz" % sc_name), kind="finish", blob=blob, off=off,
+                            lens=lens, desc=desc, read_idx=ridx, wire=wire, wire_sizes=sizes, distant=distant,
+                            stale_penalty=stale, tasks=tasks, results=res, ext_cigars=ext[:, :w[0]], cigars=cig[:, :w[1]],
+                            mdz=mdz[:, :w[2]], flank=6, ext_stride=512, scoring=scv)
+        print("finish", sc_name, "methods", np.bincount(res["method"], minlength=27))
+
+
 def main():
     ref = bindings.Reference()
     codes = synth.make_genome(GENOME_SYMBOLS, seed=GENOME_SEED)
@@ -230,6 +322,9 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "finish":
         make_finish(ref, codes, packed, ref_size)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "scoring":
+        make_scoring(ref, codes, packed, ref_size)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "round2":
         make_round2(ref, codes, packed, ref_size)
@@ -318,6 +413,7 @@ def main():
                         out_records=rec2, out_cigars=cig2)
     print("clip_m150 changed", int((cig2 != cig).any(axis=1).sum()), "of", len(rec))
     make_round2(ref, codes, packed, ref_size)
+    make_scoring(ref, codes, packed, ref_size)
 
 
 if __name__ == "__main__":

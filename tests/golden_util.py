@@ -31,3 +31,10 @@ def load(name):
 
 def cigar_bytes(cig, i):
     return bytes(cig[i]).split(b"\0")[0]
+
+
+def scoring(z, module):
+    """The fixture's scoring_t as module.Scoring (module = oracle.bindings or whisper_amd.api), None = the defaults."""
+    if "scoring" not in z.files:
+        return None
+    return module.Scoring(*[float(v) for v in z["scoring"]])

@@ -1,5 +1,7 @@
 """HIP path (through the C-ABI) against the committed fixtures = outputs of the
 reference's own compiled objects."""
+import contextlib
+
 import numpy as np
 import pytest
 
@@ -7,6 +9,19 @@ import golden_util as gu
 from whisper_amd import api
 
 pytestmark = pytest.mark.gpu
+
+
+@contextlib.contextmanager
+def scored(ctx, z):
+    """Fixtures generated under a non-default scoring_t carry it: wamd_ctx_set_scoring for the test's calls."""
+    sc = gu.scoring(z, api)
+    if sc is not None:
+        ctx.set_scoring(sc)
+    try:
+        yield sc
+    finally:
+        if sc is not None:
+            ctx.set_scoring(api.default_scoring())
 
 
 @pytest.fixture(scope="module")
@@ -54,8 +69,9 @@ def test_cf_filter(ctx, name):
 def test_align(ctx, name):
     z = gu.load(name)
     reads = ctx.upload_reads(z["blob"], z["off"], z["lens"], 1)
-    got, cig = ctx.align(reads, z["tasks"], int(z["last_symbol"]), int(z["refine"]),
-                         cigar_stride=int(z["cigar_stride"]))
+    with scored(ctx, z):
+        got, cig = ctx.align(reads, z["tasks"], int(z["last_symbol"]), int(z["refine"]),
+                             cigar_stride=int(z["cigar_stride"]))
     reads.free()
     want = z["results"]
     for f in want.dtype.names:
@@ -71,9 +87,10 @@ def test_indel_match_cigar_and_records(ctx, name):
     z = gu.load(name)
     enc = int(z["encoding"])
     reads = ctx.upload_reads(z["blob"], z["off"], z["lens"], enc, orientations=1)
-    got = ctx.indel_match(reads, z["tasks"], api.default_indel_params(float(z["min_clipped_factor"])))
+    got = ctx.indel_match(reads, z["tasks"], api.default_indel_params(float(z["min_clipped_factor"]), gu.scoring(z, api)))
     np.testing.assert_array_equal(got, z["results"])
-    cres, ccig = ctx.indel_ext_cigar(reads, z["cigar_tasks"], cigar_stride=int(z["cigar_stride"]))
+    with scored(ctx, z):
+        cres, ccig = ctx.indel_ext_cigar(reads, z["cigar_tasks"], cigar_stride=int(z["cigar_stride"]))
     reads.free()
     np.testing.assert_array_equal(cres, z["cigar_results"])
     for i in range(len(cres)):
@@ -87,7 +104,8 @@ def test_indel_match_cigar_and_records(ctx, name):
 @pytest.mark.parametrize("name", gu.cases("clip"))
 def test_clip_boundary(ctx, name):
     z = gu.load(name)
-    rec, cig = ctx.clip_boundary(z["records"], z["cigars"])
+    with scored(ctx, z):
+        rec, cig = ctx.clip_boundary(z["records"], z["cigars"])
     want = z["out_records"]
     for f in want.dtype.names:
         if f not in ("no_clippings", "reserved"):
@@ -123,7 +141,8 @@ def _check_clip_l(z, rec, cig, skip):
 @pytest.mark.parametrize("name", gu.cases("clipillegal"))
 def test_clip_illegal(ctx, name):
     z = gu.load(name)
-    rec, cig = ctx.clip_illegal(z["tasks"], z["records"], z["cigars"])
+    with scored(ctx, z):
+        rec, cig = ctx.clip_illegal(z["tasks"], z["records"], z["cigars"])
     _check_clip_l(z, rec, cig, ())
 
 
@@ -139,7 +158,8 @@ def test_softclip_match(ctx, name):
     z = gu.load(name)
     prm = api.default_softclip_params(int(z["max_query_len"]), int(z["max_mismatches"]), int(z["fresh_object"]))
     reads = ctx.upload_reads(z["blob"], z["off"], z["lens"], int(z["encoding"]), orientations=3)
-    res, cig = ctx.softclip_match(reads, z["tasks"], prm, cigar_stride=int(z["cigar_stride"]))
+    with scored(ctx, z):
+        res, cig = ctx.softclip_match(reads, z["tasks"], prm, cigar_stride=int(z["cigar_stride"]))
     reads.free()
     np.testing.assert_array_equal(res, z["results"])
     for i in range(len(res)):
@@ -153,7 +173,8 @@ def test_finish_pairs(ctx, name):
     import common
     z = gu.load(name)
     reads = ctx.upload_reads(z["blob"], z["off"], z["lens"], 1, orientations=3)
-    got = ctx.finish_pairs(reads, z["tasks"], api.default_finish_params(int(z["flank"])), ext_stride=int(z["ext_stride"]))
+    with scored(ctx, z):
+        got = ctx.finish_pairs(reads, z["tasks"], api.default_finish_params(int(z["flank"])), ext_stride=int(z["ext_stride"]))
     reads.free()
     common.same_finish_output(got, (z["results"], z["ext_cigars"], z["cigars"], z["mdz"]))
     # AS:i: is Double2PChar of the score (utils.h:276-286): one decimal, identical because the doubles are

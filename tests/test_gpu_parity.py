@@ -584,13 +584,38 @@ def test_finish_pairs_chain(ctx, oracle, seed, m, flank):
     # the fused passes without the per-slot length hints: every wave serves its slots in two halves at the full stride
     # (what it also does when the packed strings of a wave do not fit its LDS)
     rc, *want = oracle.finish_pairs(packed, blob, off, lens, tasks, ob.default_finish_params(flank), ext_stride=768)
-    os.environ["WAMD_POST_NO_HINTS"] = "1"
+    ctx.set_test_hooks(1)
     try:
         got = ctx.finish_pairs(reads, tasks, api.default_finish_params(flank), ext_stride=768)
     finally:
-        del os.environ["WAMD_POST_NO_HINTS"]
+        ctx.set_test_hooks(0)
     common.same_finish_output(got, want)
     reads.free()
+
+
+@pytest.mark.parametrize("seed,m", [(43, 150), (44, 250)])
+def test_finish_pairs_distant_from_pair_and_failing_reads(ctx, oracle, seed, m):
+    """WAMD_DISTANT_FROM_PAIR: isDistant of sam.cpp:1881-1884 computed on the device - for the second read of a pair
+    from the first one's position and length after ITS alignment and clipping passes - under an insert-size model
+    that calls part of the pairs distant; and reads fill_cigar_with_lev cannot align: that slot alone is not
+    finished, its mate is."""
+    (codes, packed), (blob, off, lens), desc, ridx, maps, direct, distant, stale = common.finish_workload(
+        oracle, 1500, seed, m=m, flank=7, from_pair_frac=0.7)
+    lev = np.nonzero((maps["type"] == 0) & (maps["no_mismatches"] > 2))[0]
+    maps["no_mismatches"][lev[::11]] = 1
+    tasks = common.finish_tasks(desc, ridx, lens, maps, direct, distant, stale, isize=common.FINISH_ISIZE)
+    from oracle import bindings as ob
+    rc, *want = oracle.finish_pairs(packed, blob, off, lens, tasks, ob.default_finish_params(7), ext_stride=768)
+    bad = want[0]["ok"] == 0
+    assert rc == 0 and 20 < bad.sum() < 400 and want[0]["ok"][np.nonzero(bad)[0] ^ 1].sum() > 10
+    fp = (tasks["distant"] == 2) & ~bad
+    dist = np.isin(want[0]["method"], (1, 3))
+    assert (fp & dist).sum() > 100 and (fp & ~dist).sum() > 100
+    assert (dist[0::2] != dist[1::2])[fp[0::2] & fp[1::2]].sum() > 0    # the mate's answer follows the first read's alignment
+    reads = ctx.upload_reads(blob, off, lens, 1, orientations=3)
+    got = ctx.finish_pairs(reads, tasks, api.default_finish_params(7), ext_stride=768)
+    reads.free()
+    common.same_finish_output(got, want)
 
 
 def test_finish_pairs_dev_stays_on_the_device(ctx, oracle):
@@ -603,7 +628,7 @@ def test_finish_pairs_dev_stays_on_the_device(ctx, oracle):
     tasks["err_edit_distance"][lev[0]] = 0          # claims fewer errors than the read has: fill_cigar_with_lev fails
     tasks["penalty"][lev[0]] = 1
     rc, *want = oracle.finish_pairs(packed, blob, off, lens, tasks, ext_stride=512)
-    assert rc == 0 and want[0]["ok"].sum() == len(tasks) - 2
+    assert rc == 0 and want[0]["ok"].sum() == len(tasks) - 1 and want[0]["ok"][lev[0] ^ 1] == 1   # the mate is finished
     dev = torch.device("cuda", 0)
     n = len(tasks)
     reads = ctx.upload_reads(blob, off, lens, 1, orientations=3)

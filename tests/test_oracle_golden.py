@@ -6,6 +6,11 @@ import pytest
 import golden_util as gu
 
 
+def _ob():
+    from oracle import bindings
+    return bindings
+
+
 @pytest.mark.parametrize("name", gu.cases("distance"))
 def test_distance(oracle, name):
     packed, _ = gu.load_genome()
@@ -32,7 +37,7 @@ def test_align(oracle, name):
     z = gu.load(name)
     rc, res, cig = oracle.align(packed, z["blob"], z["off"], z["lens"], 1, z["tasks"],
                                 int(z["last_symbol"]), int(z["refine"]),
-                                cigar_stride=int(z["cigar_stride"]))
+                                cigar_stride=int(z["cigar_stride"]), scoring=gu.scoring(z, _ob()))
     assert rc == 0
     want = z["results"]
     for f in want.dtype.names:   # affine_score included: same doubles added in the same order
@@ -48,10 +53,13 @@ def test_indel_match_cigar_and_records(oracle, name):
     z = gu.load(name)
     enc = int(z["encoding"])
     prm = bindings.default_indel_params(float(z["min_clipped_factor"]))
+    sc = gu.scoring(z, bindings)
+    if sc is not None:
+        prm.scoring = sc
     rc, res = oracle.indel_match(packed, z["blob"], z["off"], z["lens"], enc, z["tasks"], prm)
     np.testing.assert_array_equal(res, z["results"])
     rc, cres, ccig = oracle.indel_ext_cigar(packed, z["blob"], z["off"], z["lens"], enc, z["cigar_tasks"],
-                                            cigar_stride=int(z["cigar_stride"]))
+                                            scoring=sc, cigar_stride=int(z["cigar_stride"]))
     np.testing.assert_array_equal(cres, z["cigar_results"])
     np.testing.assert_array_equal(ccig, z["cigars"])
     rc, wire, sizes = oracle.serialize(z["results"], z["direction"])
@@ -62,7 +70,7 @@ def test_indel_match_cigar_and_records(oracle, name):
 @pytest.mark.parametrize("name", gu.cases("clip"))
 def test_clip_boundary(oracle, name):
     z = gu.load(name)
-    rc, rec, cig = oracle.clip_boundary(z["records"], z["cigars"])
+    rc, rec, cig = oracle.clip_boundary(z["records"], z["cigars"], gu.scoring(z, _ob()))
     want = z["out_records"]
     for f in want.dtype.names:
         if f != "no_clippings":      # not a field of the reference's mapping_desc_t
@@ -125,7 +133,7 @@ def _check_clip_l(z, rec, cig, skip):
 @pytest.mark.parametrize("name", gu.cases("clipillegal"))
 def test_clip_illegal(oracle, name):
     z = gu.load(name)
-    rc, rec, cig = oracle.clip_illegal(z["tasks"], z["records"], z["cigars"])
+    rc, rec, cig = oracle.clip_illegal(z["tasks"], z["records"], z["cigars"], gu.scoring(z, _ob()))
     assert rc == 0
     _check_clip_l(z, rec, cig, ())
 
@@ -145,7 +153,7 @@ def test_softclip_match(oracle, name):
     packed, _ = gu.load_genome()
     prm = ob.default_softclip_params(int(z["max_query_len"]), int(z["max_mismatches"]), int(z["fresh_object"]))
     rc, res, cig = oracle.softclip_match(packed, z["blob"], z["off"], z["lens"], int(z["encoding"]), z["tasks"], prm,
-                                         cigar_stride=int(z["cigar_stride"]))
+                                         gu.scoring(z, ob), cigar_stride=int(z["cigar_stride"]))
     assert rc == 0
     np.testing.assert_array_equal(res, z["results"])
     np.testing.assert_array_equal(cig, z["cigars"])
@@ -159,7 +167,7 @@ def test_finish_pairs(oracle, name):
     packed, _ = gu.load_genome()
     z = gu.load(name)
     prm = bindings.default_finish_params(int(z["flank"]))
-    rc, *got = oracle.finish_pairs(packed, z["blob"], z["off"], z["lens"], z["tasks"], prm,
+    rc, *got = oracle.finish_pairs(packed, z["blob"], z["off"], z["lens"], z["tasks"], prm, gu.scoring(z, bindings),
                                    ext_stride=int(z["ext_stride"]))
     assert rc == 0
     common.same_finish_output(got, (z["results"], z["ext_cigars"], z["cigars"], z["mdz"]))

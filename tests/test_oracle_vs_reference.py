@@ -267,6 +267,34 @@ def test_finish_pairs_chain(oracle, reference, seed, m):
     assert perfect_clipped.sum() > 5            # a perfect match that a clipping pass gave an ext-CIGAR keeps "<len>M"
 
 
+@pytest.mark.parametrize("seed,m", [(27, 150), (28, 100)])
+def test_finish_pairs_distant_from_pair_and_failing_reads(oracle, reference, seed, m):
+    """isDistant computed inside the chain (sam.cpp:1881-1884: for the second read from the first one's position and
+    length after its fill_cigar and clipping passes), and reads fill_cigar_with_lev cannot align: the mate is still
+    finished, the pair is not pair-clipped."""
+    (codes, packed), (blob, off, lens), desc, ridx, maps, direct, distant, stale = common.finish_workload(
+        oracle, 600, seed, m=m, from_pair_frac=0.6)
+    lev = np.nonzero((maps["type"] == 0) & (maps["no_mismatches"] > 2))[0]
+    maps["no_mismatches"][lev[::9]] = 1               # claims fewer errors than the read has: dynamicProgramming fails
+    _, wire, _ = oracle.serialize(maps, direct)
+    rc, tasks, res, ext, cig, mdz = reference.finish_pairs(packed, codes.numel(), desc, blob, off, lens, ridx, wire,
+                                                           distant, stale, ext_stride=768, model=common.FINISH_MODEL)
+    assert rc == 0
+    bad = res["ok"] == 0
+    assert 10 < bad.sum() < 200 and res["ok"][np.nonzero(bad)[0] ^ 1].sum() > 5      # mates of failing reads are finished
+    mine = common.finish_tasks(desc, ridx, lens, maps, direct, distant, stale, isize=common.FINISH_ISIZE)
+    for f in tasks.dtype.names:
+        np.testing.assert_array_equal(mine[f], tasks[f], err_msg=f)
+    rc, *got = oracle.finish_pairs(packed, blob, off, lens, tasks, ext_stride=768)
+    assert rc == 0
+    common.same_finish_output(got, (res, ext, cig, mdz))
+    fp = (tasks["distant"] == 2) & (res["ok"] == 1)
+    dist = np.isin(res["method"], (1, 3))
+    assert (fp & dist).sum() > 50 and (fp & ~dist & np.isin(res["method"], (0, 2))).sum() > 50
+    # the second read's answer follows the first one's alignment: some pairs differ between their two slots
+    assert (dist[0::2] != dist[1::2])[fp[0::2] & fp[1::2]].sum() > 0
+
+
 @pytest.mark.parametrize("seed,max_no_mappings,id_bytes", [(3, 1024, 5), (4, 8, 4), (5, 1, 8), (6, 3, 6)])
 def test_commit_and_result_groups(oracle, reference, seed, max_no_mappings, id_bytes):
     """Verified candidates -> candidate_mapping (construct<lev>, better) -> the heap gatherer's order -> the bytes

@@ -79,7 +79,7 @@ CLIP_RECORD = np.dtype([("score", "<f8"), ("ref_seq_pos", "<i4"), ("ref_length",
 FINISH_TASK = np.dtype([("read_idx", "<u4"), ("pos", "<u4"), ("type", "<u4"), ("penalty", "<u4"), ("matching_len1", "<u4"),
                         ("matching_len2", "<u4"), ("indel_len1", "<i4"), ("indel_len2", "<i4"), ("clipping_len", "<u4"),
                         ("ref_seq_id", "<i4"), ("ref_seq_pos", "<i4"), ("ref_size", "<i4"), ("err_edit_distance", "<u2"),
-                        ("direct", "u1"), ("distant", "u1"), ("reserved", "<u4", (3,))])
+                        ("direct", "u1"), ("distant", "u1"), ("isize_min", "<i4"), ("isize_max", "<i4"), ("flags", "<u4")])
 FINISH_RESULT = np.dtype([("score", "<f8"), ("pos", "<u4"), ("ref_seq_pos", "<i4"), ("ref_length", "<u2"),
                           ("err_edit_distance", "<u2"), ("num_events", "<u2"), ("left_clipping", "<u2"),
                           ("right_clipping", "<u2"), ("method", "<u2"), ("ext_cigar_len", "<u4"), ("cigar_len", "<u4"),
@@ -140,9 +140,14 @@ class IndelParams(C.Structure):
                 ("reserved", C.c_uint32)]
 
 
-def default_indel_params(min_clipped_factor=1.0):
+def default_scoring():
+    # mapper/params.h:145-154
+    return Scoring(1.0, -5.0, -5.0, -0.4, -5.0, -0.4, -6.0)
+
+
+def default_indel_params(min_clipped_factor=1.0, scoring=None):
     # mapper/params.h:145-158
-    return IndelParams(Scoring(1.0, -5.0, -5.0, -0.4, -5.0, -0.4, -6.0), min_clipped_factor, 0, 0)
+    return IndelParams(scoring or default_scoring(), min_clipped_factor, 0, 0)
 
 
 class WamdError(RuntimeError):
@@ -248,6 +253,10 @@ class Context:
 
     def set_scoring(self, sc):
         _check(lib().wamd_ctx_set_scoring(self.h, C.byref(sc)))
+
+    def set_test_hooks(self, hooks):
+        """Not part of the C-ABI header: 1 = post passes without length hints, 2 = LevDiag by run extension only."""
+        _check(lib().wamd_internal_set_test_hooks(self.h, C.c_uint32(hooks)))
 
     def set_max_text_len(self, v):
         _check(lib().wamd_ctx_set_max_text_len(self.h, C.c_uint32(v)))

@@ -7,8 +7,6 @@
 // ext-CIGARs produced by the align kernels need not travel to the host and back.
 #include <mutex>
 
-#include <stdlib.h>
-
 #include "wamd_internal.h"
 
 namespace wamd {
@@ -1026,6 +1024,8 @@ int launch_emit_lev_records_static(wamd_ctx* ctx, uint32_t n, const wamd_dist_ta
         set_error("wamd_emit_lev_records_static_dev: no static scratch on device %d", ctx->device);
         return WAMD_ERR_CAPACITY;
     }
+    if (n == 0)   // the entry point's check that this device has its scratch; nothing to launch
+        return WAMD_OK;
     return launch_emit_lev_records(ctx, n, d_tasks, d_results, d_record_pos, d_direction, d_records, d_count, ptr, s);
 }
 
@@ -1201,7 +1201,8 @@ __global__ __launch_bounds__(64, 4) void post_passes_kernel(uint32_t n, const wa
                                                          uint8_t* __restrict__ cigars, uint32_t cigar_stride,
                                                          uint8_t* __restrict__ mdz, uint32_t mdz_stride,
                                                          uint32_t* __restrict__ cigar_bin, uint32_t bin_stride,
-                                                         wamd_sam_cigar_len* __restrict__ lens, uint32_t* __restrict__ flags)
+                                                         wamd_sam_cigar_len* __restrict__ lens, int2* __restrict__ mid,
+                                                         uint32_t* __restrict__ flags)
 {
     extern __shared__ uint32_t post_lds[];
     const uint32_t lane = threadIdx.x;
@@ -1368,6 +1369,8 @@ __global__ __launch_bounds__(64, 4) void post_passes_kernel(uint32_t n, const wa
                 clip_illegal_one(d, it[slot], ec, cap, sc, flags);
             if (passes & POST_BOUNDARY)
                 clip_boundary_one(d, ec, cap, sc);
+            if (mid)   // where the mapping lies before the pair is clipped (finish_pairs: isDistant of the mate)
+                mid[slot] = make_int2(d.ref_seq_pos, (int)d.ref_length);
         }
         __syncthreads();   // every lane's string is as its own passes left it before a partner touches it
         if (passes & POST_PAIRS) {
@@ -1449,11 +1452,12 @@ static bool rows_can_stage(const void* slots, uint32_t stride)
 static int launch_post_kernel(wamd_ctx* ctx, uint32_t n, const wamd_clip_illegal_task* it, const wamd_clip_pair_task* pt,
                               wamd_clip_record* rec, uint8_t* ext, uint32_t ext_stride, const uint32_t* cap_hint,
                               uint32_t passes, uint8_t* cigars, uint32_t cigar_stride, uint8_t* mdz, uint32_t mdz_stride,
-                              uint32_t* bin, uint32_t bin_stride, wamd_sam_cigar_len* lens, hipStream_t s)
+                              uint32_t* bin, uint32_t bin_stride, wamd_sam_cigar_len* lens, hipStream_t s,
+                              int2* mid = nullptr)
 {
     if (n == 0)
         return WAMD_OK;
-    if (getenv("WAMD_POST_NO_HINTS")) {   // test hook: the two-halves path of every wave
+    if (ctx->test_hooks & HOOK_POST_NO_HINTS) {   // test hook: the two-halves path of every wave
         cap_hint = nullptr;
         passes |= POST_TWO_HALVES;
     }
@@ -1466,9 +1470,17 @@ static int launch_post_kernel(wamd_ctx* ctx, uint32_t n, const wamd_clip_illegal
         budget_dw = 2912u > 2u * full_dw ? 2912u : 2u * full_dw;
     hipLaunchKernelGGL(post_passes_kernel, dim3((n + 63) / 64), dim3(64), (size_t)budget_dw * 4, s, n, it, pt, rec, ext,
                        ext_stride, cap_hint, budget_dw, ctx->scoring, passes, cigars, cigar_stride, mdz, mdz_stride, bin,
-                       bin_stride, lens, ctx->d_flags);
+                       bin_stride, lens, mid, ctx->d_flags);
     WAMD_HIP(hipGetLastError());
     return WAMD_OK;
+}
+
+__global__ __launch_bounds__(256) void post_mid_kernel(uint32_t n, const wamd_clip_record* __restrict__ rec,
+                                                       int2* __restrict__ mid)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        mid[i] = make_int2(rec[i].ref_seq_pos, (int)rec[i].ref_length);
 }
 
 int launch_clip_boundary(wamd_ctx* ctx, uint32_t n, wamd_clip_record* d_records, uint8_t* d_cigars,
@@ -1514,17 +1526,21 @@ int launch_clip_pairs(wamd_ctx* ctx, uint32_t n_pairs, const wamd_clip_pair_task
 int launch_post_passes(wamd_ctx* ctx, uint32_t n, const wamd_clip_illegal_task* d_it, const wamd_clip_pair_task* d_pt,
                        wamd_clip_record* d_rec, uint8_t* d_ext, uint32_t ext_stride, const uint32_t* d_cap_hint,
                        int do_boundary, int do_pairs, uint8_t* d_cigars, uint32_t cigar_stride, uint8_t* d_mdz,
-                       uint32_t mdz_stride, wamd_sam_cigar_len* d_lens, hipStream_t s)
+                       uint32_t mdz_stride, wamd_sam_cigar_len* d_lens, int2* d_mid, hipStream_t s)
 {
     WAMD_HIP(hipSetDevice(ctx->device));
     if (rows_can_stage(d_ext, ext_stride) && (n & 1u) == 0)
         return launch_post_kernel(ctx, n, d_it, d_pt, d_rec, d_ext, ext_stride, d_cap_hint,
                                   POST_ILLEGAL | (do_boundary ? POST_BOUNDARY : 0) | (do_pairs ? POST_PAIRS : 0) | POST_SAM |
                                       POST_LEN_IN_RESERVED,
-                                  d_cigars, cigar_stride, d_mdz, mdz_stride, nullptr, 0, d_lens, s);
+                                  d_cigars, cigar_stride, d_mdz, mdz_stride, nullptr, 0, d_lens, s, d_mid);
     int rc = launch_clip_illegal(ctx, n, d_it, d_rec, d_ext, ext_stride, s);
     if (!rc && do_boundary)
         rc = launch_clip_boundary(ctx, n, d_rec, d_ext, ext_stride, s);
+    if (!rc && d_mid && n) {
+        hipLaunchKernelGGL(post_mid_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_rec, d_mid);
+        WAMD_HIP(hipGetLastError());
+    }
     if (!rc && do_pairs)
         rc = launch_clip_pairs(ctx, n / 2, d_pt, d_rec, d_ext, ext_stride, s);
     if (!rc)

@@ -30,6 +30,7 @@ struct FinishWs {
     wamd_clip_pair_task* pt;
     wamd_sam_cigar_len* lens;
     uint32_t* cap;   // per slot: bytes its ext-CIGAR can need in the post-passes (their LDS packing)
+    int2* mid;       // per slot: (ref_seq_pos, ref_length) between clipBoundaryPositions and clipOverlappingPairs
     void* align_ws;
     uint64_t align_ws_bytes;
     uint64_t total;
@@ -56,6 +57,7 @@ static FinishWs finish_layout(const wamd_reads* r, uint32_t n_pairs, char* base)
     w.pt = (wamd_clip_pair_task*)take((uint64_t)n_pairs * sizeof(wamd_clip_pair_task));
     w.lens = (wamd_sam_cigar_len*)take(n * sizeof(wamd_sam_cigar_len));
     w.cap = (uint32_t*)take(n * sizeof(uint32_t));
+    w.mid = (int2*)take(n * sizeof(int2));
     w.align_ws = base + off;
     w.align_ws_bytes = align_workspace_bytes(r, (uint32_t)n);
     w.total = off + w.align_ws_bytes;
@@ -124,6 +126,28 @@ __device__ __forceinline__ bool finish_slot_ok(uint32_t kind, const wamd_align_r
     return kind == FK_PERFECT || (kind == FK_LEV && a.ok && a.edit_distance != RESULT_ERROR) || (kind == FK_INDEL && c.ok);
 }
 
+// mapping_pair_t::calculateInsertSize (common/types.h:482-515) > mean + MyersDev || < mean - MyersDev, sam.cpp:1881-1884
+__device__ __forceinline__ bool finish_is_distant(int32_t id0, int32_t pos0, int32_t len0, bool direct0, int32_t id1,
+                                                  int32_t pos1, int32_t len1, bool direct1, int32_t isize_min,
+                                                  int32_t isize_max)
+{
+    int32_t isize = 0x7fffffff;
+    if (id0 == id1) {
+        const bool left_is_first = pos0 < pos1 || (pos0 == pos1 && direct0);
+        const bool left_direct = left_is_first ? direct0 : direct1;
+        if (direct0 != direct1 && left_direct)
+            isize = left_is_first ? pos1 - pos0 + len1 : pos0 - pos1 + len0;
+    }
+    return isize > isize_max || isize < isize_min;
+}
+
+__device__ __forceinline__ uint16_t finish_method(uint32_t kind, bool distant)
+{
+    if (kind == FK_PERFECT)
+        return distant ? WAMD_METHOD_PERFECT_DISTANT : WAMD_METHOD_PERFECT;
+    return distant ? WAMD_METHOD_FROM_MAPPING_DISTANT : WAMD_METHOD_FROM_MAPPING;
+}
+
 __global__ __launch_bounds__(256) void finish_merge_kernel(ReadsView rv, const wamd_finish_task* __restrict__ tasks,
                                                            uint32_t n, uint32_t flank, double match_score,
                                                            const wamd_align_result* __restrict__ ar,
@@ -139,19 +163,31 @@ __global__ __launch_bounds__(256) void finish_merge_kernel(ReadsView rv, const w
     if (i >= n)
         return;
     const wamd_finish_task t = tasks[i], tm = tasks[i ^ 1u];
-    const uint32_t kind = finish_kind(t, rv);
+    const uint32_t kind = finish_kind(t, rv), km = finish_kind(tm, rv);
     const wamd_align_result a = ar[i];
     const wamd_indel_cigar_result c = cr[i];
-    // the reference stops at the first read of the pair it cannot align (stat_mapped_pe_errors) - here the
-    // whole pair is then reported as not finished
-    const bool ok = finish_slot_ok(kind, a, c) && finish_slot_ok(finish_kind(tm, rv), ar[i ^ 1u], cr[i ^ 1u]);
+    // A read fill_cigar cannot align (stat_mapped_pe_errors, sam_matching.cpp:748-751) keeps a null ext-CIGAR in the
+    // reference, which clipBoundaryPositions and extract_cigar_and_mdz then dereference: it does not survive such a
+    // record.  Here that slot alone is reported as not finished; its mate goes through the chain as usual and the
+    // pair stays out of clipOverlappingPairs.
+    const bool ok = finish_slot_ok(kind, a, c);
+    const bool ok_mate = finish_slot_ok(km, ar[i ^ 1u], cr[i ^ 1u]);
     const uint32_t m = kind == FK_BAD ? 0u : rv.lens[t.read_idx];
+    const uint32_t mm = km == FK_BAD ? 0u : rv.lens[tm.read_idx];
+
+    // fill_cigar's `distant`: the host's, or (WAMD_DISTANT_FROM_PAIR) what sam.cpp:1881-1884 computes from the pair
+    // as it stands - for the first read both mappings as constructed (ref_length = read length, sam.cpp:1581); the
+    // second read's needs the first one's record after its clipping passes: finish_final_kernel settles that one
+    bool distant = t.distant == 1;
+    if (t.distant == WAMD_DISTANT_FROM_PAIR && !(i & 1u))
+        distant = finish_is_distant(t.ref_seq_id, t.ref_seq_pos, (int32_t)m, t.direct != 0, tm.ref_seq_id, tm.ref_seq_pos,
+                                    (int32_t)mm, tm.direct != 0, t.isize_min, t.isize_max);
 
     wamd_clip_record r{};
     wamd_finish_result o{};
     wamd_clip_illegal_task ti{};
     r.ref_seq_pos = t.ref_seq_pos;
-    r.ref_length = (uint16_t)m;   // sam.cpp:1578
+    r.ref_length = (uint16_t)m;   // sam.cpp:1581
     r.err_edit_distance = t.err_edit_distance;
     r.score = -1;
     o.pos = t.pos;
@@ -167,7 +203,7 @@ __global__ __launch_bounds__(256) void finish_merge_kernel(ReadsView rv, const w
         ti.ref_size = 0x7fffffff;
         ext[(uint64_t)i * ext_stride] = 0;
     } else if (kind == FK_PERFECT) {   // sam_matching.cpp:670-680
-        o.method = t.distant ? WAMD_METHOD_PERFECT_DISTANT : WAMD_METHOD_PERFECT;
+        o.method = finish_method(kind, distant);
         r.score = m * match_score;
         ti.perfect = 1;
         ext[(uint64_t)i * ext_stride] = 0;
@@ -179,11 +215,12 @@ __global__ __launch_bounds__(256) void finish_merge_kernel(ReadsView rv, const w
         o.pos = (uint32_t)((int64_t)t.pos + delta);
         r.ref_seq_pos = (int32_t)((int64_t)t.ref_seq_pos + delta);
         r.ref_length = (uint16_t)(a.end_pos - a.begin_pos);
-        o.method = t.distant ? WAMD_METHOD_FROM_MAPPING_DISTANT : WAMD_METHOD_FROM_MAPPING;
+        o.method = finish_method(kind, distant);
         o.num_events = (uint16_t)a.num_events;
         r.score = a.affine_score;
     } else {                           // sam_matching.cpp:840-848
-        o.pos = t.direct ? t.pos : t.pos - (m - 1);
+        if (!(t.flags & WAMD_FINISH_NO_TRANSLATE))
+            o.pos = t.direct ? t.pos : t.pos - (m - 1);
         r.score = c.score;
         r.err_edit_distance = c.err_edit_distance;
         r.ref_length = c.ref_length;
@@ -201,15 +238,14 @@ __global__ __launch_bounds__(256) void finish_merge_kernel(ReadsView rv, const w
     }
     if ((i & 1u) == 0) {   // clipOverlappingPairs' view of the pair, soft_clipping.cpp:997-1044
         wamd_clip_pair_task p{};
-        const uint32_t km = finish_kind(tm, rv);
         p.ref_seq_id[0] = t.ref_seq_id;
-        p.ref_seq_id[1] = ok ? tm.ref_seq_id : t.ref_seq_id + 1;   // an unfinished pair is left alone
+        p.ref_seq_id[1] = (ok && ok_mate) ? tm.ref_seq_id : t.ref_seq_id + 1;   // a pair with an unfinished read is left alone
         p.read_length[0] = (uint16_t)m;
-        p.read_length[1] = (uint16_t)(km == FK_BAD ? 0u : rv.lens[tm.read_idx]);
+        p.read_length[1] = (uint16_t)mm;
         p.direct[0] = t.direct;
         p.direct[1] = tm.direct;
         p.perfect[0] = ok && kind == FK_PERFECT;
-        p.perfect[1] = ok && km == FK_PERFECT;
+        p.perfect[1] = ok_mate && km == FK_PERFECT;
         pt[i >> 1] = p;
     }
 }
@@ -226,6 +262,9 @@ __device__ __forceinline__ uint32_t finish_put_decimal(uint8_t* dst, uint32_t v)
 
 __global__ __launch_bounds__(256) void finish_final_kernel(ReadsView rv, const wamd_finish_task* __restrict__ tasks,
                                                            uint32_t n, const wamd_clip_record* __restrict__ rec,
+                                                           const wamd_align_result* __restrict__ ar,
+                                                           const wamd_indel_cigar_result* __restrict__ cr,
+                                                           const int2* __restrict__ mid,
                                                            const wamd_sam_cigar_len* __restrict__ lens,
                                                            wamd_finish_result* __restrict__ results,
                                                            const uint8_t* __restrict__ ext, uint32_t ext_stride,
@@ -244,6 +283,22 @@ __global__ __launch_bounds__(256) void finish_final_kernel(ReadsView rv, const w
         results[i] = z;
         cg[0] = mz[0] = 0;
         return;
+    }
+    if ((i & 1u) && tasks[i].distant == WAMD_DISTANT_FROM_PAIR &&
+        (o.method == WAMD_METHOD_PERFECT || o.method == WAMD_METHOD_FROM_MAPPING)) {
+        // sam.cpp:1881-1884 for the second read: the first mapping as its own fill_cigar, clipIllegalPositions and
+        // clipBoundaryPositions left it (as constructed when it could not be aligned), this one as constructed
+        const wamd_finish_task t = tasks[i], t0 = tasks[i ^ 1u];
+        const uint32_t k0 = finish_kind(t0, rv);
+        const int32_t m1 = (int32_t)rv.lens[t.read_idx];
+        int32_t pos0 = t0.ref_seq_pos, len0 = k0 == FK_BAD ? 0 : (int32_t)rv.lens[t0.read_idx];
+        if (finish_slot_ok(k0, ar[i ^ 1u], cr[i ^ 1u])) {
+            pos0 = mid[i ^ 1u].x;
+            len0 = mid[i ^ 1u].y;
+        }
+        if (finish_is_distant(t0.ref_seq_id, pos0, len0, t0.direct != 0, t.ref_seq_id, t.ref_seq_pos, m1, t.direct != 0,
+                              t.isize_min, t.isize_max))
+            o.method = o.method == WAMD_METHOD_PERFECT ? WAMD_METHOD_PERFECT_DISTANT : WAMD_METHOD_FROM_MAPPING_DISTANT;
     }
     o.score = r.score;
     o.ref_seq_pos = r.ref_seq_pos;
@@ -314,10 +369,10 @@ int launch_finish_pairs(wamd_ctx* ctx, const wamd_reads* r, const wamd_finish_ta
                        ctx->scoring.match, w.ar, w.cr, w.rec, w.it, w.pt, d_results, d_ext, ext_stride, w.cap);
     WAMD_HIP(hipGetLastError());
     rc = launch_post_passes(ctx, n, w.it, w.pt, w.rec, d_ext, ext_stride, w.cap, prm->enable_boundary_clipping != 0,
-                            prm->enable_paired_clipping != 0, d_cigars, cigar_stride, d_mdz, mdz_stride, w.lens, s);
+                            prm->enable_paired_clipping != 0, d_cigars, cigar_stride, d_mdz, mdz_stride, w.lens, w.mid, s);
     if (rc)
         return rc;
-    hipLaunchKernelGGL(finish_final_kernel, dim3(blocks), dim3(256), 0, s, rv, d_tasks, n, w.rec, w.lens, d_results,
+    hipLaunchKernelGGL(finish_final_kernel, dim3(blocks), dim3(256), 0, s, rv, d_tasks, n, w.rec, w.ar, w.cr, w.mid, w.lens, d_results,
                        d_ext, ext_stride, d_cigars, cigar_stride, d_mdz, mdz_stride);
     WAMD_HIP(hipGetLastError());
     return WAMD_OK;

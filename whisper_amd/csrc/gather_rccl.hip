@@ -103,28 +103,67 @@ static int comm_finish(wamd_comm* c)
 {
     WAMD_HIP(hipSetDevice(c->ctx->device));
     WAMD_HIP(hipMalloc(&c->d_counts, (size_t)c->n_ranks * sizeof(uint32_t)));
-    WAMD_HIP(hipHostMalloc(&c->h_counts, (size_t)c->n_ranks * sizeof(uint32_t), hipHostMallocDefault));
+    const hipError_t e = hipHostMalloc(&c->h_counts, (size_t)c->n_ranks * sizeof(uint32_t), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void)hipFree(c->d_counts);
+        c->d_counts = nullptr;
+        c->h_counts = nullptr;
+        return hip_fail(e, "hipHostMalloc", __FILE__, __LINE__);
+    }
     return WAMD_OK;
 }
+
+// Inside ncclGroupStart / ncclGroupEnd nothing may return: a thread that leaves a group open has every later
+// collective queued behind it and never issued, while the other ranks have already posted theirs and wait.  Calls
+// between the two record the first failure and go on to ncclGroupEnd; the failure is reported after the group closed.
+struct GroupError {
+    int rc = WAMD_OK;
+    void hip(hipError_t e, const char* what)
+    {
+        if (e != hipSuccess && rc == WAMD_OK)
+            rc = hip_fail(e, what, __FILE__, __LINE__);
+    }
+    void rccl(ncclResult_t e, const char* what)
+    {
+        if (e != ncclSuccess && rc == WAMD_OK)
+            rc = rccl_fail(e, what);
+    }
+};
 
 // the gather of every local rank in `cs` (one entry per process, or all ranks of the node in one process)
 static int gather_impl(wamd_comm* const* cs, int n_local, const uint8_t* const* d_records, const uint32_t* const* d_count,
                        uint32_t record_bytes, uint32_t capacity, int root, uint8_t* d_out, uint32_t* counts_out,
                        void* const* streams)
 {
+    // everything that can be wrong on this rank alone is refused before the first collective is posted, so that a
+    // bad argument never leaves the other ranks waiting for this one
     if (n_local <= 0 || !cs || !d_records || !d_count || record_bytes == 0)
         return WAMD_ERR_INVALID_ARG;
+    for (int i = 0; i < n_local; ++i)
+        if (!cs[i] || !cs[i]->ctx || !cs[i]->comm || !d_count[i] || (!d_records[i] && capacity))
+            return WAMD_ERR_INVALID_ARG;
     const int n_ranks = cs[0]->n_ranks;
     if (root < 0 || root >= n_ranks)
         return WAMD_ERR_INVALID_ARG;
+    for (int i = 0; i < n_local; ++i) {
+        if (cs[i]->n_ranks != n_ranks)
+            return WAMD_ERR_INVALID_ARG;
+        if (cs[i]->rank == root && !d_out && capacity) {
+            set_error("wamd_gather_records: the root rank passes no output buffer");
+            return WAMD_ERR_INVALID_ARG;
+        }
+    }
     auto st = [&](int i) { return streams && streams[i] ? (hipStream_t)streams[i] : cs[i]->ctx->stream; };
     // 1. everybody learns everybody's count
+    GroupError ge;
     WAMD_RCCL(g_rccl.GroupStart(), "ncclGroupStart");
     for (int i = 0; i < n_local; ++i) {
-        WAMD_HIP(hipSetDevice(cs[i]->ctx->device));
-        WAMD_RCCL(g_rccl.AllGather(d_count[i], cs[i]->d_counts, 1, ncclUint32, cs[i]->comm, st(i)), "ncclAllGather");
+        ge.hip(hipSetDevice(cs[i]->ctx->device), "hipSetDevice");
+        ge.rccl(g_rccl.AllGather(d_count[i], cs[i]->d_counts, 1, ncclUint32, cs[i]->comm, st(i)), "ncclAllGather");
     }
-    WAMD_RCCL(g_rccl.GroupEnd(), "ncclGroupEnd");
+    ge.rccl(g_rccl.GroupEnd(), "ncclGroupEnd");
+    if (ge.rc)
+        return ge.rc;
     for (int i = 0; i < n_local; ++i) {
         WAMD_HIP(hipSetDevice(cs[i]->ctx->device));
         WAMD_HIP(hipMemcpyAsync(cs[i]->h_counts, cs[i]->d_counts, (size_t)n_ranks * sizeof(uint32_t),
@@ -134,15 +173,14 @@ static int gather_impl(wamd_comm* const* cs, int n_local, const uint8_t* const* 
         WAMD_HIP(hipSetDevice(cs[i]->ctx->device));
         WAMD_HIP(hipStreamSynchronize(st(i)));
     }
+    // every rank holds the same counts here, so a block beyond the capacity is refused by all of them alike and
+    // nobody posts a transfer
     const uint32_t* counts = cs[0]->h_counts;
-    uint64_t total = 0;
-    for (int r = 0; r < n_ranks; ++r) {
+    for (int r = 0; r < n_ranks; ++r)
         if (counts[r] > capacity) {
             set_error("wamd_gather_records: rank %d holds %u records, the blocks are sized for %u", r, counts[r], capacity);
             return WAMD_ERR_CAPACITY;
         }
-        total += counts[r];
-    }
     if (counts_out)
         for (int r = 0; r < n_ranks; ++r)
             counts_out[r] = counts[r];
@@ -150,29 +188,27 @@ static int gather_impl(wamd_comm* const* cs, int n_local, const uint8_t* const* 
     WAMD_RCCL(g_rccl.GroupStart(), "ncclGroupStart");
     for (int i = 0; i < n_local; ++i) {
         wamd_comm* c = cs[i];
-        WAMD_HIP(hipSetDevice(c->ctx->device));
+        ge.hip(hipSetDevice(c->ctx->device), "hipSetDevice");
         const size_t mine = (size_t)counts[c->rank] * record_bytes;
         if (c->rank != root) {
             if (mine)
-                WAMD_RCCL(g_rccl.Send(d_records[i], mine, ncclUint8, root, c->comm, st(i)), "ncclSend");
+                ge.rccl(g_rccl.Send(d_records[i], mine, ncclUint8, root, c->comm, st(i)), "ncclSend");
             continue;
         }
-        if (!d_out && total)
-            return WAMD_ERR_INVALID_ARG;
         uint64_t off = 0;
         for (int r = 0; r < n_ranks; ++r) {
             const size_t bytes = (size_t)counts[r] * record_bytes;
             if (bytes) {
                 if (r == root)
-                    WAMD_HIP(hipMemcpyAsync(d_out + off, d_records[i], bytes, hipMemcpyDeviceToDevice, st(i)));
+                    ge.hip(hipMemcpyAsync(d_out + off, d_records[i], bytes, hipMemcpyDeviceToDevice, st(i)), "hipMemcpyAsync");
                 else
-                    WAMD_RCCL(g_rccl.Recv(d_out + off, bytes, ncclUint8, r, c->comm, st(i)), "ncclRecv");
+                    ge.rccl(g_rccl.Recv(d_out + off, bytes, ncclUint8, r, c->comm, st(i)), "ncclRecv");
             }
             off += bytes;
         }
     }
-    WAMD_RCCL(g_rccl.GroupEnd(), "ncclGroupEnd");
-    return WAMD_OK;
+    ge.rccl(g_rccl.GroupEnd(), "ncclGroupEnd");
+    return ge.rc;
 }
 
 } // namespace wamd
@@ -248,8 +284,15 @@ int wamd_comm_create_all(wamd_ctx* const* ctxs, int n, wamd_comm** out)
         c->n_ranks = n;
         out[i] = c;
         rc = comm_finish(c);
-        if (rc)
+        if (rc) {   // nothing half-made is left behind: the wrapped handles, and the communicators not yet wrapped
+            for (int j = 0; j <= i; ++j) {
+                wamd_comm_destroy(out[j]);
+                out[j] = nullptr;
+            }
+            for (int j = i + 1; j < n; ++j)
+                (void)g_rccl.CommDestroy(comms[j]);
             return rc;
+        }
     }
     return WAMD_OK;
 }
@@ -281,7 +324,7 @@ int wamd_gather_records_all(wamd_comm* const* comms, int n, const uint8_t* const
                             const uint32_t* const* d_count, uint32_t record_bytes, uint32_t capacity, int root,
                             uint8_t* d_out, uint32_t* counts_out, void* const* streams)
 {
-    if (!comms || n < 1 || n != comms[0]->n_ranks)
+    if (!comms || n < 1 || !comms[0] || n != comms[0]->n_ranks)
         return WAMD_ERR_INVALID_ARG;
     return gather_impl(comms, n, d_records, d_count, record_bytes, capacity, root, d_out, counts_out, streams);
 }

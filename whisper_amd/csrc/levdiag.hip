@@ -707,7 +707,7 @@ int launch_levdiag(wamd_ctx* ctx, const wamd_reads* r, const wamd_levdiag_task* 
     const uint32_t need = (r->max_len + 7) / 8 + 2;
     // reads up to 256 symbols, uploaded in the direct orientation: the banded bit-vector kernel, then the
     // run-extension kernel for the lanes it deferred (none in practice: 16 us)
-    const bool band = (r->orientations & 1) && r->max_len <= 256 && !getenv("WAMD_LEVDIAG_RUNS");
+    const bool band = (r->orientations & 1) && r->max_len <= 256 && !(ctx->test_hooks & HOOK_LEVDIAG_RUNS);
     if (band) {
         int rc = r->words32 <= 5 ? launch_ld_band<5, 128>(ctx, r, d_tasks, n, d_results, s, n_dev)
                                  : launch_ld_band<8, 128>(ctx, r, d_tasks, n, d_results, s, n_dev);

@@ -674,9 +674,6 @@ __global__ __launch_bounds__(BLOCK, (PHASE == 1 && NW <= 4 ? WAMD_WALK_WAVES : 1
             return (uint32_t)(word >> (b & 63u)) & 1u;
         };
 
-#ifdef WAMD_EXP_FWD_ONLY
-        valid = false;
-#endif
         uint32_t read_pos = valid ? m : 0, pos = valid ? end_pos : 0;
         uint32_t c_val = ed, events = 0, nsteps = 0, pacc = 0;
         uint32_t prev_dir = DIR_D;
@@ -1013,9 +1010,6 @@ __global__ __launch_bounds__(BLOCK, (PHASE == 1 && NW <= 4 ? WAMD_WALK_WAVES : 1
         gf.init(st_gen, BLOCK, g_origin, gd_n, (int64_t)ref_pos + begin_pos);
         uint32_t hist = 0, ref_hist = 0;
         uint32_t pw = 0, pw_next = 0;
-#ifdef WAMD_EXP_NO_REPLAY
-        valid = false;
-#endif
         const uint32_t total = valid ? nsteps : 0;
         for (uint32_t k = 0; __any(k < total); ++k) {
             if (k < total) {

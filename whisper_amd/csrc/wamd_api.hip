@@ -296,6 +296,15 @@ int wamd_ctx_set_max_text_len(wamd_ctx* ctx, uint32_t max_text_len)
     return WAMD_OK;
 }
 
+// not part of include/whisper_amd.h: switches the tests use to reach code paths that ordinary inputs seldom take
+int wamd_internal_set_test_hooks(wamd_ctx* ctx, uint32_t hooks)
+{
+    if (!ctx)
+        return WAMD_ERR_INVALID_ARG;
+    ctx->test_hooks = hooks;
+    return WAMD_OK;
+}
+
 int wamd_ctx_set_distance_mode(wamd_ctx* ctx, int mode)
 {
     if (!ctx || (mode != WAMD_DISTANCE_EXACT && mode != WAMD_DISTANCE_ACCEPTED_ONLY))
@@ -1040,6 +1049,7 @@ int wamd_emit_lev_records_dev(wamd_ctx* ctx, uint32_t n, const wamd_dist_task* d
     if (!ctx || !d_count)
         return WAMD_ERR_INVALID_ARG;
     if (n == 0) {
+        WAMD_HIP(hipSetDevice(ctx->device));
         WAMD_HIP(hipMemsetAsync(d_count, 0, sizeof(uint32_t), pick(ctx, stream)));
         return WAMD_OK;
     }
@@ -1074,6 +1084,7 @@ int wamd_emit_result_groups_dev(wamd_ctx* ctx, uint32_t n_tasks, const wamd_comm
     if (!ctx || !d_out_bytes || !params)
         return WAMD_ERR_INVALID_ARG;
     if (n_reads == 0) {
+        WAMD_HIP(hipSetDevice(ctx->device));
         WAMD_HIP(hipMemsetAsync(d_out_bytes, 0, sizeof(uint32_t), pick(ctx, stream)));
         return WAMD_OK;
     }
@@ -1160,7 +1171,11 @@ int wamd_emit_lev_records_static_dev(wamd_ctx* ctx, uint32_t n, const wamd_dist_
 {
     if (!ctx || !d_count)
         return WAMD_ERR_INVALID_ARG;
-    if (n == 0) {
+    if (n == 0) {   // (an empty bin is still refused on a device that has no static scratch)
+        const int rc = launch_emit_lev_records_static(ctx, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+        if (rc)
+            return rc;
+        WAMD_HIP(hipSetDevice(ctx->device));
         WAMD_HIP(hipMemsetAsync(d_count, 0, sizeof(uint32_t), pick(ctx, stream)));
         return WAMD_OK;
     }

@@ -22,6 +22,11 @@ enum : uint32_t {
     FLAG_ARG = 1u << 5,        // malformed task (anchor outside read, k too large ...)
     FLAG_CIGAR = 1u << 6,      // cigar_stride too small for a task
 };
+// test hooks (wamd_ctx::test_hooks): code paths ordinary inputs seldom reach
+enum : uint32_t {
+    HOOK_POST_NO_HINTS = 1u << 0,   // post passes: ignore the callers' length hints, every wave in two halves
+    HOOK_LEVDIAG_RUNS = 1u << 1,    // LevDiag: the run-extension kernel for every read length
+};
 constexpr uint32_t RESULT_ERROR = 0xFFFFFFFFu;
 constexpr int BAND_SLOTS = 16;
 
@@ -75,6 +80,7 @@ struct wamd_ctx {
     uint32_t cur_offset;
     uint32_t max_text_len;
     int distance_mode;          // WAMD_DISTANCE_*
+    uint32_t test_hooks;        // wamd::HOOK_* (wamd_internal_set_test_hooks; 0 outside the tests)
     wamd_scoring scoring;
     uint32_t* d_flags;          // device error flags; behind them BAND_SLOTS pairs of "something was
                                 // deferred" words of the banded distance chain, one pair per stream
@@ -116,6 +122,8 @@ struct wamd_reads {
     hipEvent_t pm_event;
     wamd::ReadsView view() const;
 };
+
+extern "C" WAMD_API int wamd_internal_set_test_hooks(wamd_ctx* ctx, uint32_t hooks);
 
 namespace wamd {
 
@@ -163,7 +171,7 @@ int launch_serialize(wamd_ctx* ctx, uint32_t n, const wamd_mapping* d_mappings, 
 int launch_post_passes(wamd_ctx* ctx, uint32_t n, const wamd_clip_illegal_task* d_it, const wamd_clip_pair_task* d_pt,
                        wamd_clip_record* d_rec, uint8_t* d_ext, uint32_t ext_stride, const uint32_t* d_cap_hint,
                        int do_boundary, int do_pairs, uint8_t* d_cigars, uint32_t cigar_stride, uint8_t* d_mdz,
-                       uint32_t mdz_stride, wamd_sam_cigar_len* d_lens, hipStream_t s);
+                       uint32_t mdz_stride, wamd_sam_cigar_len* d_lens, int2* d_mid, hipStream_t s);
 
 int launch_cf_filter(wamd_ctx* ctx, const wamd_reads* r, const wamd_cf_task* d_tasks, uint32_t n,
                      uint32_t* d_results, hipStream_t s);
