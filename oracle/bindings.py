@@ -522,3 +522,30 @@ Oracle.commit = lambda self, tasks, indel=None: _commit(self.lib.wo_commit_batch
 Reference.commit = lambda self, tasks, indel=None: _commit(self.lib.ref_commit_batch, tasks, indel)
 Oracle.result_groups = lambda self, *a, **k: _groups(self.lib.wo_result_groups_batch, *a, **k)
 Reference.result_groups = lambda self, *a, **k: _groups(self.lib.ref_result_groups_batch, *a, **k)
+
+
+# ---- the suffix-array loops on the reference's own CMappingCore (mapping_core_sa.cpp:193-513)
+def _r_search_reads(self, genome, ref_size, reads, offsets, lens, sa_dir, sa_rc, seg, min_read_len, k, sensitive=0,
+                    enable_indels=0, max_indel=50, params=None, sa_skip=64, capacity=None):
+    """Returns (rc, ranges [n, 4], best [n, 2], pushed mappings, their strand, their read)."""
+    prm = params or default_indel_params()
+    n = len(lens)
+    sa_dir = np.ascontiguousarray(sa_dir, np.uint32)
+    sa_rc = np.ascontiguousarray(sa_rc, np.uint32)
+    cap = capacity or (64 * n + 1024)
+    ranges = np.zeros((n, 4), np.uint32)
+    best = np.zeros((n, 2), np.uint32)
+    pushed = np.zeros(cap, MAPPING)
+    pdir = np.zeros(cap, np.uint8)
+    pread = np.zeros(cap, np.uint32)
+    cnt = C.c_uint32(0)
+    rc = self.lib.ref_search_reads_batch(_p(genome), C.c_uint32(ref_size), _p(reads), _p(offsets), _p(lens), C.c_uint32(n),
+                                         _p(sa_dir), C.c_uint32(len(sa_dir)), _p(sa_rc), C.c_uint32(len(sa_rc)),
+                                         C.c_uint32(seg[0]), C.c_uint32(seg[1]), C.c_uint32(min_read_len), C.c_uint32(k),
+                                         C.c_int(sensitive), C.c_int(enable_indels), C.c_uint32(max_indel), C.byref(prm),
+                                         C.c_uint32(sa_skip), _p(ranges), _p(best), _p(pushed), _p(pdir), _p(pread),
+                                         C.c_uint32(cap), C.byref(cnt))
+    return rc, ranges, best, pushed[:cnt.value].copy(), pdir[:cnt.value].copy(), pread[:cnt.value].copy()
+
+
+Reference.search_reads = _r_search_reads

@@ -525,6 +525,175 @@ REF_API int ref_cf_batch(const uint8_t* genome, uint32_t ref_size, uint32_t cur_
 }
 
 
+/* ---- the suffix-array loops themselves: CMappingCore::search_in_unknown_range_dir_and_rc and
+ * search_in_known_range_dir_and_rc (mapping_core_sa.cpp:193-353, 359-513), with binary_sa_search (:516-580) and
+ * check_matching_part (mapping_core_str_comp.cpp:315-380), run on CMappingCore storage that is never constructed:
+ * only the members those routines read are set (reference, anchor segment, verifier objects, the CF vectors, the
+ * two match_positions vectors - zeroed storage is a valid empty std::vector).  What this function does around them
+ * is the non-malicious path of findMismatches_dir_and_rc (mapping_core_diff_len_reads.cpp:71-208; that routine
+ * itself cannot be linked: its malicious-group branch needs the prebuilt asmlib) and the per-read set-up of
+ * process_reads (mapping_core.cpp:857-968): reads arrive sorted by their anchor, a read whose anchor equals the
+ * previous one's re-walks the range the previous read found (known range), the others search on from where the last
+ * range ended.  Output: per read and strand the range [start, last) of suffix-array entries the loop verified and
+ * the best penalty it returned, and every candidate_mapping_t the loops pushed to dir_match_positions /
+ * rc_match_positions, in push order. */
+REF_API int ref_search_reads_batch(const uint8_t* genome, uint32_t ref_size, const uint8_t* reads, const uint64_t* offsets,
+                                   const uint32_t* lens, uint32_t n_reads, const uint32_t* sa_dir, uint32_t sa_dir_size,
+                                   const uint32_t* sa_rc, uint32_t sa_rc_size, uint32_t start_pos, uint32_t end_pos,
+                                   uint32_t min_read_len, uint32_t max_mismatches, int sensitive, int enable_indels,
+                                   uint32_t max_approx_indel_len, const wamd_indel_params* prm, uint32_t sa_skip,
+                                   uint32_t* ranges /* n_reads x 4 */, uint32_t* best /* n_reads x 2 */,
+                                   wamd_mapping* pushed, uint8_t* pushed_direct, uint32_t* pushed_read,
+                                   uint32_t capacity, uint32_t* n_pushed)
+{
+    uint32_t max_len = 0;
+    for (uint32_t i = 0; i < n_reads; ++i)
+        max_len = std::max(max_len, lens[i]);
+    MappingCoreBox box(genome, ref_size, start_pos);   /* CUR_OFFSET = start_pos, mapping_core.cpp:110 */
+    CMappingCore* mc = box.get();
+    /* the verifier objects as the constructor makes them (mapping_core.cpp:154-191) */
+    Verifiers v(max_len + 8, max_len + 2 * max_mismatches + 2, max_mismatches, const_cast<uint8_t*>(genome), ref_size,
+                start_pos);
+    CParams params;
+    fill_params(params, &prm->scoring, prm->min_clipped_factor);
+    CIndelMatching im_dir(&params), im_rc(&params);
+    im_dir.SetReference(const_cast<uint8_t*>(genome), 0, 0);
+    im_rc.SetReference(const_cast<uint8_t*>(genome), 0, 0);
+    mc->levMyers64 = v.m64.get();
+    mc->levMyers128 = v.m128.get();
+    mc->levMyers256 = v.m256.get();
+    mc->edit_dist = v.lev_diag.get();
+    mc->indel_matching_dir = &im_dir;
+    mc->indel_matching_rc = &im_rc;
+    mc->start_pos = start_pos;
+    mc->end_pos = end_pos;
+    mc->predef_match_length = end_pos - start_pos;
+    mc->min_read_len = min_read_len;
+    mc->sensitive_mode = sensitive != 0;
+    mc->enable_mapping_indels = enable_indels != 0;
+    mc->max_approx_indel_len = max_approx_indel_len;
+    mc->sa_dir_skip = sa_skip;
+    mc->sa_rc_skip = sa_skip;
+    mc->CF_vector_128b_SSE_dir_gen.resize(sa_dir_size, 0);
+    mc->CF_vector_128b_SSE_rc_gen.resize(sa_rc_size, 0);
+
+    std::vector<uint8_t> data, data_sft, rc, rc_sft, prev_anchor;
+    uint32_t sa_start[2] = {0, 0}, sa_last[2] = {0, 0};
+    uint32_t out = 0;
+    int status = 0;
+    auto pack = [](const std::vector<uint8_t>& codes, std::vector<uint8_t>& d, std::vector<uint8_t>& sft) {
+        const uint32_t m = (uint32_t)codes.size();
+        d.assign(m / 2 + 4, 0);
+        sft.assign(m / 2 + 4, 0);
+        for (uint32_t j = 0; j < m; ++j)
+            d[j >> 1] |= (uint8_t)((j & 1) ? codes[j] : codes[j] << 4);
+        sft[0] = d[0] >> 4;   /* CReadsDeliverer::Pop, reads.cpp:381-391 */
+        for (uint32_t j = 1; j <= m / 2 + 1; ++j)
+            sft[j] = (uint8_t)(((d[j - 1] & 0xf) << 4) + (d[j] >> 4));
+    };
+    for (uint32_t r = 0; r < n_reads; ++r) {
+        const uint32_t m = lens[r];
+        const uint8_t* src = reads + offsets[r];
+        std::vector<uint8_t> codes(m), rcodes(m);
+        for (uint32_t j = 0; j < m; ++j)
+            codes[j] = (uint8_t)shim_nib(src, j);
+        for (uint32_t j = 0; j < m; ++j) {   /* reverse_read, mapping_core.cpp:1063-1108: A<->T, C<->G, N stays */
+            const uint8_t c = codes[m - 1 - j];
+            rcodes[j] = c < 4 ? (uint8_t)(3 - c) : c;
+        }
+        pack(codes, data, data_sft);
+        pack(rcodes, rc, rc_sft);
+        ranges[4 * r] = ranges[4 * r + 1] = ranges[4 * r + 2] = ranges[4 * r + 3] = 0;
+        best[2 * r] = best[2 * r + 1] = max_mismatches + 1;
+        if (m < end_pos)   /* mapping_core.cpp:857 */
+            continue;
+        if (mc->sensitive_mode && mc->enable_mapping_indels) {   /* mapping_core.cpp:869-873 */
+            im_dir.Preprocess(data.data(), m, genome_t::direct);
+            im_rc.Preprocess(data.data(), m, genome_t::rev_comp);
+        }
+        mc->dir_match_positions.clear();
+        mc->rc_match_positions.clear();
+        std::vector<uint8_t> anchor(codes.begin() + start_pos, codes.begin() + end_pos);
+        const bool matching_part_is_new = r == 0 || anchor != prev_anchor;   /* mapping_core.cpp:929-949 */
+        prev_anchor = anchor;
+        const bool is_short_read = m < min_read_len;
+        for (int strand = 0; strand < 2; ++strand) {
+            const bool dir_flag = strand == 0;
+            uint8_t* p = dir_flag ? data.data() : rc.data();
+            uint8_t* p_sft = dir_flag ? data_sft.data() : rc_sft.data();
+            uint32_t* sa = const_cast<uint32_t*>(dir_flag ? sa_dir : sa_rc);
+            const uint32_t sa_size = dir_flag ? sa_dir_size : sa_rc_size;
+            uint32_t no_of_mismatches = max_mismatches + 1;
+            /* mapping_core_diff_len_reads.cpp:113-126 / 160-175: the read's CF vector */
+            auto pattern_cf = [&]() {
+                if (is_short_read)
+                    return;
+                if (dir_flag) {
+                    mc->calculate_CF_128b_SSE_for_a_pattern(p, p_sft, min_read_len, start_pos, end_pos,
+                                                            mc->CF_value_SSE_for_a_dir_pattern);
+                } else {
+                    const uint32_t diff_len = m - min_read_len;
+                    if (diff_len & 1)
+                        mc->calculate_CF_128b_SSE_for_a_pattern(p_sft + (diff_len >> 1) + 1, p + (diff_len >> 1), min_read_len,
+                                                                min_read_len - end_pos, min_read_len - start_pos,
+                                                                mc->CF_value_SSE_for_a_rc_pattern);
+                    else
+                        mc->calculate_CF_128b_SSE_for_a_pattern(p + (diff_len >> 1), p_sft + (diff_len >> 1), min_read_len,
+                                                                min_read_len - end_pos, min_read_len - start_pos,
+                                                                mc->CF_value_SSE_for_a_rc_pattern);
+                }
+            };
+            if (matching_part_is_new) {   /* :87-151 */
+                uint32_t cur = sa_last[strand];
+                if (cur < sa_size) {
+                    int32_t cmp = mc->check_matching_part(p, p_sft, m, sa[cur], dir_flag);
+                    if (cmp < 0) {
+                        uint32_t move_size = 0;
+                        cmp = mc->binary_sa_search(p, p_sft, m, mc->predef_match_length, sa + cur, sa_size - cur, &move_size,
+                                                   dir_flag);
+                        cur += move_size;
+                    }
+                    if (cmp == 0) {
+                        sa_start[strand] = cur;
+                        pattern_cf();
+                        no_of_mismatches = mc->search_in_unknown_range_dir_and_rc(p, p_sft, m, sa, sa_size, sa_start[strand],
+                                                                                  &sa_last[strand], dir_flag, max_mismatches);
+                    } else {
+                        sa_start[strand] = cur;
+                        sa_last[strand] = cur;
+                    }
+                }
+            } else {                       /* :153-205, never inside a malicious group here */
+                pattern_cf();
+                no_of_mismatches = mc->search_in_known_range_dir_and_rc(p, p_sft, m, sa, sa_size, sa_start[strand],
+                                                                        sa_last[strand], dir_flag, max_mismatches);
+            }
+            ranges[4 * r + 2 * strand] = sa_start[strand];
+            ranges[4 * r + 2 * strand + 1] = sa_last[strand];
+            best[2 * r + strand] = no_of_mismatches;
+            const std::vector<candidate_mapping_t>& got = dir_flag ? mc->dir_match_positions : mc->rc_match_positions;
+            for (const candidate_mapping_t& cm : got) {
+                if (out >= capacity) {
+                    status = WAMD_ERR_CAPACITY;
+                    break;
+                }
+                to_pod(cm, true, pushed[out]);
+                pushed_direct[out] = cm.direction == genome_t::direct;
+                pushed_read[out] = r;
+                ++out;
+            }
+        }
+    }
+    *n_pushed = out;
+    /* the vectors live in storage whose destructor never runs */
+    std::vector<Vec16c>().swap(mc->CF_vector_128b_SSE_dir_gen);
+    std::vector<Vec16c>().swap(mc->CF_vector_128b_SSE_rc_gen);
+    std::vector<candidate_mapping_t>().swap(mc->dir_match_positions);
+    std::vector<candidate_mapping_t>().swap(mc->rc_match_positions);
+    return status;
+}
+
+
 /* ---- ext-CIGAR -> SAM CIGAR / BAM operations / MD:Z: CSamGenerator members that touch no
  * member data (sam.cpp:805-928, 932-1051), called on the unconstructed box. */
 REF_API int ref_sam_cigar_batch(uint32_t n, const uint8_t* ext_cigars, uint32_t ext_stride, uint8_t* cigars,

@@ -791,3 +791,157 @@ def gpu_result_groups(ctx, tasks, indel, read_first, read_ids, id_bytes, max_no_
     nb = int(d_nb.item())
     return (d_c.cpu().numpy().view(api.MAPPING)[:n], d_out.cpu().numpy()[:min(nb, cap)], d_off.cpu().numpy()[:nr].view(np.uint32),
             flags, d_out.cpu().numpy())
+
+
+# ---- the suffix-array loops (mapping_core_sa.cpp:193-513) ---------------------------------------------------------
+def suffix_array(codes, key_len=64, clean_len=32):
+    """Positions of `codes` (numpy, one code per symbol) in the order of their suffixes, as the reference's index holds
+    them for one strand; suffixes that meet a non-ACGT symbol within clean_len symbols are left out."""
+    n = len(codes)
+    bad = (codes > 3).astype(np.int64)
+    cs = np.concatenate([[0], np.cumsum(bad)])
+    pos = np.arange(0, n - key_len)
+    pos = pos[cs[pos + clean_len] - cs[pos] == 0]
+    win = np.lib.stride_tricks.sliding_window_view(codes, key_len)[pos]
+    order = np.lexsort(win.T[::-1])          # the last key is the primary one
+    return pos[order].astype(np.uint32)
+
+
+def sa_loop_genome(seed, n_symbols=1 << 15, families=48):
+    """A small genome with planted near-repeats (families of a 300-symbol segment copied to several places at 2 %
+    divergence): anchors then have several suffix-array entries, some of which verify and some of which do not."""
+    import torch
+    codes = synth.make_genome(n_symbols, seed=seed).numpy().copy()
+    rng = np.random.default_rng(seed)
+    lo, hi = synth.BOUNDARY_N_LEN + 400, len(codes) - synth.BOUNDARY_N_LEN - 800
+    for _ in range(families):
+        src = rng.integers(lo, hi)
+        seg = codes[src:src + 300].copy()
+        seg[seg > 3] = 0
+        for _ in range(rng.integers(2, 7)):
+            dst = rng.integers(lo, hi)
+            s2 = seg.copy()
+            mut = rng.random(300) < 0.02
+            s2[mut] = (s2[mut] + rng.integers(1, 4, mut.sum())) & 3
+            codes[dst:dst + 300] = s2
+    t = torch.from_numpy(codes)
+    return t, synth.pack_nibbles(t).numpy()
+
+
+def sa_loop_workload(seed, n_loci, per_locus, m, k, seg, min_read_len=None):
+    """Reads for the suffix-array loops: n_loci loci on either strand, per_locus reads each (same anchor: the second and
+    later ones take search_in_known_range), 0 .. k + 2 edits outside the anchor segment `seg` (substitutions, now and
+    then a short indel), reads of min_read_len .. min_read_len + 3 symbols, sorted by anchor as the bins deliver them.
+    Returns (codes, packed, reads (blob, off, lens), sa_dir, sa_rc)."""
+    import torch
+    codes_t, packed = sa_loop_genome(seed)
+    codes = codes_t.numpy()
+    G = len(codes)
+    comp = np.array([3, 2, 1, 0, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15], np.uint8)
+    rc_codes = comp[codes[::-1]]
+    sa_dir, sa_rc = suffix_array(codes), suffix_array(rc_codes)
+    rng = np.random.default_rng(seed + 1)
+    fl, fr = seg
+    min_read_len = min_read_len or m
+    reads = []
+    for _ in range(n_loci):
+        strand = rng.integers(0, 2)
+        text = rc_codes if strand else codes
+        while True:
+            p = int(rng.integers(synth.BOUNDARY_N_LEN + 60, G - synth.BOUNDARY_N_LEN - m - 80))
+            if text[p - 20:p + m + 30].max() <= 3:
+                break
+        for _ in range(per_locus):
+            mi = min_read_len + int(rng.integers(0, 4))
+            r = list(text[p:p + mi + 12])
+            for _ in range(int(rng.integers(0, k + 3))):
+                z = int(rng.integers(0, mi))
+                if fl <= z < fr:
+                    continue
+                u = rng.random()
+                if u < 0.8:
+                    r[z] = (r[z] + int(rng.integers(1, 4))) & 3
+                elif u < 0.9 and z > fr:
+                    del r[z]
+                elif z > fr:
+                    r.insert(z, int(rng.integers(0, 4)))
+            reads.append(np.array(r[:mi], np.uint8))
+    reads.sort(key=lambda r: bytes(r[fl:fr]))
+    blob, off, lens = mixed_reads(reads, 0)
+    return codes_t, packed, (blob, off, lens), sa_dir, sa_rc
+
+
+def sa_loop_tasks(ranges, lens, sa_dir, sa_rc, ref_size, seg, min_read_len, k, max_indel):
+    """One task of every kind per suffix-array entry the loops verified (ranges: n_reads x 4 = dir start, dir last, rc
+    start, rc last), in the loops' order: a read's direct-strand entries, then its reverse-strand ones.  Reads are
+    uploaded twice - n reads as they are, then their reverse complements: CEditDist::LevDiag takes the reverse read
+    itself on the other strand (mapping_core_sa.cpp:291), the other verifiers the read in rev_comp orientation.
+    Returns (cf, dist, lev, indel, commit skeleton, read_first)."""
+    from oracle import bindings as ob
+    fl, fr = seg
+    n = len(lens)
+    rows = []
+    read_first = [0]
+    for r in range(n):
+        for strand in (0, 1):
+            s, e = int(ranges[r, 2 * strand]), int(ranges[r, 2 * strand + 1])
+            sa = sa_rc if strand else sa_dir
+            rows += [(r, strand, int(sa[i])) for i in range(s, e)]
+        read_first.append(len(rows))
+    c = len(rows)
+    rd = np.array([x[0] for x in rows], np.int64)
+    st = np.array([x[1] for x in rows], np.int64)
+    sp = np.array([x[2] for x in rows], np.int64)
+    m = lens[rd].astype(np.int64) if c else np.zeros(0, np.int64)
+    direct = st == 0
+    cf = np.zeros(c, ob.CF_TASK)
+    cf["read_idx"] = rd
+    cf["position"] = sp
+    cf["read_offset"] = np.where(direct, 0, m - min_read_len)
+    cf["pattern_len"] = np.where(m < min_read_len, 0, min_read_len)      # 0 = short read: no filter
+    cf["fixed_left"] = np.where(direct, fl, min_read_len - fr)
+    cf["fixed_right"] = np.where(direct, fr, min_read_len - fl)
+    cf["dir_gen_flag"] = direct
+    cf["flags"] = ~direct
+    start = np.where(direct, sp - fl, ref_size - sp - m + fl)               # genome symbol under the oriented read's first
+    dist = np.zeros(c, ob.DIST_TASK)
+    dist["read_idx"] = rd
+    dist["ref_pos"] = (start - k).astype(np.uint32)
+    dist["max_distance_in_ref"] = m + 2 * k
+    dist["max_ed"] = k
+    dist["flags"] = ~direct
+    lev = np.zeros(c, ob.LEVDIAG_TASK)
+    lev["read_idx"] = np.where(direct, rd, n + rd)
+    lev["position_in_text"] = sp
+    lev["fixed_left"] = np.where(direct, fl, m - fr)
+    lev["fixed_right"] = np.where(direct, fr, m - fl)
+    lev["max_mismatches"] = k
+    lev["dir_gen_flag"] = direct
+    indel = np.zeros(c, ob.INDEL_TASK)
+    indel["read_idx"] = rd
+    indel["ref_pos"] = start.astype(np.uint32)
+    indel["max_indel_size"] = max_indel
+    indel["fixed_segment_pos"] = np.where(direct, fl, m - fr)
+    indel["fixed_segment_size"] = fr - fl
+    indel["max_no_mismatches"] = k
+    indel["flags"] = ~direct
+    commit = np.zeros(c, ob.COMMIT_TASK)
+    commit["lev_pos"] = np.where(direct, sp - fl, ref_size - (sp - fl) - 1).astype(np.uint32)
+    commit["max_mismatches"] = k
+    commit["pattern_len"] = m
+    commit["direct"] = direct
+    return cf, dist, lev, indel, commit, np.array(read_first, np.uint32)
+
+
+def with_reverse_reads(reads):
+    """(blob, off, lens) of nibble reads followed by their reverse complements (reverse_read, mapping_core.cpp:1063-1108)."""
+    import torch
+    blob, off, lens = reads
+    out = []
+    for i in range(len(lens)):
+        b = blob[int(off[i]):int(off[i]) + (int(lens[i]) + 1) // 2]
+        c = np.zeros(2 * len(b), np.uint8)
+        c[0::2], c[1::2] = b >> 4, b & 15
+        out.append(c[:int(lens[i])])
+    rc = [synth.rev_comp(torch.from_numpy(c.copy())).numpy() for c in out]
+    return mixed_reads(out + rc, 0)

@@ -312,6 +312,63 @@ def make_scoring(ref, codes, packed, ref_size):
         print("finish", sc_name, "methods", np.bincount(res["method"], minlength=27))
 
 
+def make_sa_loops(ref):
+    """Round 3: what the reference's own suffix-array loops (CMappingCore::search_in_unknown_range_dir_and_rc /
+    search_in_known_range_dir_and_rc, mapping_core_sa.cpp:193-513, with binary_sa_search and check_matching_part) push
+    to dir / rc_match_positions for sorted reads over a genome with near-repeats, and the bytes the reference's heap
+    gatherer + results collector make of those pushes.  The fixture carries one task of every kind per suffix-array entry
+    the loops verified (tests/common.py: sa_loop_tasks), so the GPU box needs neither the suffix array nor the reference."""
+    orc = bindings.Oracle()
+    for name, seed, m, k, segi, sensitive in (("saloop_m150_k5_seg2", 8301, 150, 5, 2, 0),
+                                              ("saloop_m150_k12_seg3_sens", 8302, 150, 12, 3, 1),
+                                              ("saloop_m100_k2_seg1", 8303, 100, 2, 1, 0)):
+        stage = int(k / 2.5) if sensitive else k
+        seg = common.stage_segments(m, stage)[segi]
+        codes, packed, reads, sa_dir, sa_rc = common.sa_loop_workload(seed, 260, 3, m, k, seg, min_read_len=m)
+        ref_size = codes.numel()
+        prm = bindings.default_indel_params(0.6)
+        rc, ranges, best, pushed, pdir, pread = ref.search_reads(packed, ref_size, *reads, sa_dir, sa_rc, seg, m, k,
+                                                                 sensitive=sensitive, enable_indels=sensitive, params=prm)
+        assert rc == 0
+        n = len(reads[2])
+        reads2 = common.with_reverse_reads(reads)
+        cf, dist, lev, indel, commit, read_first = common.sa_loop_tasks(ranges, reads[2], sa_dir, sa_rc, ref_size, seg, m, k, 50)
+        # the reference's pushes as a per-candidate array (found = pushed), for its own collector
+        committed = np.zeros(len(commit), bindings.MAPPING)
+        cand_read = np.repeat(np.arange(n), np.diff(read_first).astype(np.int64))
+        j = 0
+        for i in range(len(commit)):      # a push belongs to the next candidate of its read and strand with its position
+            if j < len(pushed) and pread[j] == cand_read[i] and pdir[j] == commit["direct"][i] and _same_locus(pushed[j], commit[i], m):
+                committed[i] = pushed[j]
+                committed[i]["found"] = 1
+                j += 1
+            else:
+                committed[i]["type"] = 8
+        assert j == len(pushed), (j, len(pushed))
+        read_ids = (np.arange(n, dtype=np.uint64) * 3 + (5 << 32)).astype(np.uint64)
+        gp = bindings.GroupParams(5, 4, 1024, 0)
+        commit_full = commit.copy()
+        commit_full["has_indel"] = sensitive
+        rc, group = ref.result_groups(commit_full, committed, read_first, read_ids, gp)
+        assert rc == 0
+        blob, off, lens = reads2
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), kind="saloop", packed=packed, ref_size=np.uint32(ref_size),
+                            blob=blob, off=off, lens=lens, n_reads=n, seg=np.array(seg, np.uint32), k=k, min_read_len=m,
+                            sensitive=sensitive, min_clipped_factor=0.6, cf=cf, dist=dist, lev=lev, indel=indel,
+                            commit=commit, read_first=read_first, read_ids=read_ids, ranges=ranges, best=best,
+                            pushed=pushed, pushed_direct=pdir, pushed_read=pread, group_bytes=group)
+        print(name, "reads", n, "candidates", len(commit), "pushed", len(pushed), "non-lev", int((pushed["type"] != 0).sum()),
+              "group bytes", len(group))
+
+
+def _same_locus(push, task, m):
+    """Does this push of the loops belong to this candidate?  A lev mapping carries the candidate's own position; Match's
+    mapping lies within max_approx_indel_len of it (and m - 1 further on the other strand, mapping_core_sa.cpp:320)."""
+    if push["type"] == 0:
+        return int(push["pos"]) == int(task["lev_pos"])
+    return abs(int(push["pos"]) - int(task["lev_pos"])) <= m + 64
+
+
 def main():
     ref = bindings.Reference()
     codes = synth.make_genome(GENOME_SYMBOLS, seed=GENOME_SEED)
@@ -322,6 +379,9 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "finish":
         make_finish(ref, codes, packed, ref_size)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "saloop":
+        make_sa_loops(ref)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "scoring":
         make_scoring(ref, codes, packed, ref_size)
@@ -414,6 +474,7 @@ def main():
     print("clip_m150 changed", int((cig2 != cig).any(axis=1).sum()), "of", len(rec))
     make_round2(ref, codes, packed, ref_size)
     make_scoring(ref, codes, packed, ref_size)
+    make_sa_loops(ref)
 
 
 if __name__ == "__main__":

@@ -186,3 +186,35 @@ def test_commit_and_result_groups(oracle, name):
     prm = bindings.GroupParams(int(z["id_bytes"]), int(z["mapping_counter_size"]), int(z["max_no_mappings"]), 0)
     rc, data = oracle.result_groups(z["tasks"], committed, z["read_first"], z["read_ids"], prm)
     assert rc == 0 and bytes(data) == bytes(z["group_bytes"])
+
+
+@pytest.mark.parametrize("name", gu.cases("saloop"))
+def test_sa_loops(oracle, name):
+    """The reference's own suffix-array loops (fixture: what CMappingCore::search_in_unknown_range_dir_and_rc /
+    search_in_known_range_dir_and_rc pushed, and the bytes its heap gatherer + collector made of that) against the loop
+    body composed from the pinned oracle functions - the composition the device entry points implement."""
+    from oracle import bindings as ob
+    z = gu.load(name)
+    packed, ref_size, k, fl = z["packed"], int(z["ref_size"]), int(z["k"]), int(z["seg"][0])
+    blob, off, lens = z["blob"], z["off"], z["lens"]
+    rc, val = oracle.cf_filter(packed, ref_size, fl, blob, off, lens, z["cf"])
+    passed = (z["cf"]["pattern_len"] == 0) | (val <= 4 * k)
+    if k < 7:      # lev_alg_thr, common/defs.h:108
+        rc, ed = oracle.levdiag(packed, ref_size, fl, blob, off, lens, z["lev"])
+    else:
+        rc, res = oracle.distance(packed, blob, off, lens, 0, z["dist"], -1)
+        ed = res["edit_distance"]
+    commit = z["commit"].copy()
+    commit["lev_errors"] = np.where(passed, ed, k + 1)
+    im = None
+    if int(z["sensitive"]):
+        commit["has_indel"] = 1
+        rc, im = oracle.indel_match(packed, blob, off, lens, 0, z["indel"], ob.default_indel_params(float(z["min_clipped_factor"])))
+    rc, committed = oracle.commit(commit, im)
+    kept = committed["found"] == 1
+    for f in ("type", "pos", "no_mismatches", "matching_len1", "matching_len2", "indel_len1", "indel_len2", "clipping_len",
+              "penalty"):
+        np.testing.assert_array_equal(committed[f][kept], z["pushed"][f], err_msg=f)
+    np.testing.assert_array_equal(commit["direct"][kept], z["pushed_direct"])
+    rc, group = oracle.result_groups(commit, committed, z["read_first"], z["read_ids"], ob.GroupParams(5, 4, 1024, 0))
+    assert rc == 0 and bytes(group) == bytes(z["group_bytes"])

@@ -311,3 +311,77 @@ def test_commit_and_result_groups(oracle, reference, seed, max_no_mappings, id_b
     rc2, gb = reference.result_groups(t, a, read_first, read_ids, prm)
     assert rc1 == 0 and rc2 == 0 and len(ga) > 20000
     assert bytes(ga) == bytes(gb)
+
+
+def sa_loop_expected(oracle, packed, ref_size, reads2, n, tasks, k, start_pos, lev_alg, sensitive, prm=None):
+    """What the loop body leaves per suffix-array entry, composed from the pinned oracle functions exactly as
+    mapping_core_sa.cpp:223-344 composes them: CF filter (unless the read is short), LevDiag below lev_alg_thr = 7 else
+    dynamicProgramming, Match in sensitive mode, construct<lev> / better / the penalty test."""
+    cf, dist, lev, indel, commit, read_first = tasks
+    blob, off, lens = reads2
+    rc, val = oracle.cf_filter(packed, ref_size, start_pos, blob, off, lens, cf)
+    assert rc == 0
+    passed = (cf["pattern_len"] == 0) | (val <= 4 * k)
+    if lev_alg:
+        rc, ed = oracle.levdiag(packed, ref_size, start_pos, blob, off, lens, lev)
+    else:
+        rc, res = oracle.distance(packed, blob, off, lens, 0, dist, -1)
+        ed = res["edit_distance"]
+    assert rc == 0
+    commit = commit.copy()
+    commit["lev_errors"] = np.where(passed, ed, k + 1)
+    im = None
+    if sensitive:
+        commit["has_indel"] = 1
+        rc, im = oracle.indel_match(packed, blob, off, lens, 0, indel, prm)
+        assert rc == 0
+    rc, committed = oracle.commit(commit, im)
+    assert rc == 0
+    return commit, committed, passed
+
+
+SA_LOOP_CASES = [
+    # seed, m, k, stage segment index, sensitive (k is then stage_major * 2.5: M256 + CIndelMatching::Match)
+    (1, 150, 5, 2, 0), (2, 150, 2, 0, 0), (3, 150, 12, 3, 1), (4, 100, 10, 1, 1), (5, 150, 5, 5, 0), (6, 250, 17, 4, 1),
+]
+
+
+@pytest.mark.parametrize("seed,m,k,segi,sensitive", SA_LOOP_CASES)
+def test_sa_loops_against_the_composed_oracle(oracle, reference, seed, m, k, segi, sensitive):
+    """CMappingCore::search_in_unknown_range_dir_and_rc / search_in_known_range_dir_and_rc themselves, on a real
+    suffix array of a genome with near-repeats: every candidate_mapping_t they push to dir / rc_match_positions, in
+    order, and the best penalty they return, against the composition the device entry points implement."""
+    from oracle import bindings as ob
+    stage = int(k / 2.5) if sensitive else k
+    seg = common.stage_segments(m, stage)[segi]
+    codes, packed, reads, sa_dir, sa_rc = common.sa_loop_workload(seed, 220, 3, m, k, seg, min_read_len=m)
+    ref_size = codes.numel()
+    prm = ob.default_indel_params(0.6 if seed & 1 else 1.0)
+    rc, ranges, best, pushed, pdir, pread = reference.search_reads(packed, ref_size, *reads, sa_dir, sa_rc, seg, m, k,
+                                                                  sensitive=sensitive, enable_indels=sensitive, params=prm)
+    assert rc == 0
+    n = len(reads[2])
+    span = (ranges[:, 1] - ranges[:, 0]).astype(np.int64) + (ranges[:, 3] - ranges[:, 2])
+    assert (span > 1).sum() > n // 10 and (span == 0).sum() < n // 3          # repeats: several entries per anchor
+    reads2 = common.with_reverse_reads(reads)
+    tasks = common.sa_loop_tasks(ranges, reads[2], sa_dir, sa_rc, ref_size, seg, m, k, 50)
+    commit, committed, passed = sa_loop_expected(oracle, packed, ref_size, reads2, n, tasks, k, seg[0], k < 7, sensitive, prm)
+    kept = committed["found"] == 1
+    assert kept.sum() > n // 2 and (~kept).sum() > 50 and (~passed).sum() > 10
+    # the loops' pushes = the kept candidates, in task order
+    want = committed[kept]
+    np.testing.assert_array_equal(pdir, commit["direct"][kept])
+    read_of = np.repeat(np.arange(n), np.diff(tasks[5]).astype(np.int64))
+    np.testing.assert_array_equal(pread, read_of[kept])
+    for f in ("type", "pos", "no_mismatches", "matching_len1", "matching_len2", "indel_len1", "indel_len2", "clipping_len",
+              "penalty"):
+        np.testing.assert_array_equal(pushed[f], want[f], err_msg=f)
+    if sensitive:
+        assert (want["type"] != 0).sum() > 5
+    # best_match of either strand: the smallest penalty among its candidates, kept or not (mapping_core_sa.cpp:334-335)
+    for r in range(n):
+        lo, hi = int(tasks[5][r]), int(tasks[5][r + 1])
+        for strand, d in ((0, 1), (1, 0)):
+            sel = np.arange(lo, hi)[commit["direct"][lo:hi] == d]
+            pen = [int(committed["penalty"][i]) for i in sel if committed["found"][i]]
+            assert int(best[r, strand]) == min(pen + [k + 1]), (r, strand)
