@@ -1,10 +1,8 @@
-// ext_cigar_ops.hip - the linear passes of the post-processing half of the path:
+// ext_cigar_ops.hip - record-shaped passes of the post-processing half of the path:
 //   * CIndelMatching::GetExtCigarNew   (mapper/indels.cpp:938-957, 680-935)
-//   * CSoftClipping::clipBoundaryPositions (mapper/soft_clipping.cpp:827-994)
 //   * candidate_mapping_t::serialize   (mapper/results.cpp:161-217)
-// One record per lane.  All three are byte-stream scans with a handful of double adds
-// in a fixed order, so they are HBM/latency bound; they exist on the device so that
-// ext-CIGARs produced by the align kernels need not travel to the host and back.
+//   * accepted candidates -> mapping records (row K)
+// One record per lane.  (The clipping passes and extract_cigar_and_mdz live in post_passes.hip.)
 #include <mutex>
 
 #include "wamd_internal.h"
@@ -322,502 +320,6 @@ __global__ __launch_bounds__(64) void indel_ext_cigar_kernel(GenomeView gv, Read
     results[gid] = r;
 }
 
-__device__ __forceinline__ bool is_alpha(uint32_t c) { return ((c | 32u) - 'a') < 26u; }
-
-// Strings by the dword.  Most of an ext-CIGAR is runs of '.', and a lane walking its string byte by byte pays a whole
-// state-machine step per symbol; where the next four bytes are dots the routines below take them in one step (what
-// four steps of the reference's loop would do to their state is written out at each site).  `str4` reads four
-// bytes at any offset of a string whose base is dword-aligned; callers keep e + 8 <= the string's capacity.
-constexpr uint32_t FOUR_DOTS = 0x2E2E2E2Eu;
-__device__ __forceinline__ bool str_aligned(const uint8_t* s) { return ((uintptr_t)s & 3u) == 0; }
-__device__ __forceinline__ uint32_t str4(const uint8_t* s, uint32_t e)
-{
-    const uint32_t* w = reinterpret_cast<const uint32_t*>(s) + (e >> 2);
-    return __builtin_amdgcn_alignbyte(w[1], w[0], e & 3u);
-}
-
-// strlen bounded by the slot: whole dwords while none of their bytes is zero
-__device__ __forceinline__ uint32_t bounded_len(const uint8_t* ec, uint32_t stride)
-{
-    uint32_t l = 0;
-    if (str_aligned(ec)) {
-        const uint32_t* w = reinterpret_cast<const uint32_t*>(ec);
-        while (l + 4 <= stride) {
-            const uint32_t v = w[l >> 2];
-            if ((v - 0x01010101u) & ~v & 0x80808080u)
-                break;
-            l += 4;
-        }
-    }
-    while (l < stride && ec[l])
-        ++l;
-    return l;
-}
-
-// One record: the body of clipBoundaryPositions.  `ec` may point to global memory or to an LDS copy of the slot.
-__device__ void clip_boundary_one(wamd_clip_record& d, uint8_t* ec, uint32_t cigar_stride, const wamd_scoring& sc)
-{
-    d.no_clippings = 0;
-
-    auto length = [&]() { return bounded_len(ec, cigar_stride); };
-    if (d.err_edit_distance == 0) {
-        d.cigar_len = length();
-        return;
-    }
-    int mini_pos = -1, maxi_pos = -1;
-    double mini = 1.7976931348623157e308, maxi = -1.7976931348623157e308, cur = 0;
-    const double left_penalty = d.left_clipping > 0 ? 0 : sc.clipping;
-    const double right_penalty = d.right_clipping > 0 ? 0 : sc.clipping;
-    uint32_t in = d.left_clipping;
-    bool in_indel = false;
-    int pos;
-    // four dots at once: with a positive match score the running score rises through them, so only the first can
-    // be a new minimum and only the last a new maximum (the comparisons are strict); the sums are taken one by one
-    const bool by4 = str_aligned(ec) && sc.match > 0;
-    for (pos = 0; in < cigar_stride && ec[in] && ec[in] != '$'; ++pos) {   // 849-890
-        if (by4 && in + 8 <= cigar_stride && str4(ec, in) == FOUR_DOTS) {
-            cur += sc.match;
-            if (cur < mini) {
-                mini_pos = pos;
-                mini = cur;
-            }
-            cur += sc.match;
-            cur += sc.match;
-            cur += sc.match;
-            pos += 3;
-            in += 4;
-            in_indel = false;
-            if (cur > maxi) {
-                maxi_pos = pos;
-                maxi = cur;
-            }
-            continue;
-        }
-        const uint32_t c = ec[in];
-        if (c == '.') {
-            cur += sc.match;
-            in_indel = false;
-            ++in;
-        } else if (c == '#') {
-            cur += in_indel ? sc.gap_ins_extend : sc.gap_ins_open;
-            in_indel = true;
-            in += 2;
-            ++pos;
-        } else if (c == '^') {
-            cur += in_indel ? sc.gap_del_extend : sc.gap_del_open;
-            in_indel = true;
-            in += 2;
-            ++pos;
-        } else if (is_alpha(c)) {
-            cur += sc.mismatch;
-            in_indel = false;
-            ++in;
-        } else {
-            ++in;
-        }
-        if (cur < mini) {
-            mini_pos = pos;
-            mini = cur;
-        }
-        if (cur > maxi) {
-            maxi_pos = pos;
-            maxi = cur;
-        }
-    }
-    if (mini_pos + 20 > maxi_pos) {
-        d.cigar_len = length();
-        return;
-    }
-    int no_clippings = 0;
-    if (maxi + right_penalty > cur) {   // right clipping, 898-941
-        ++no_clippings;
-        in = d.left_clipping + (uint32_t)maxi_pos + 1;
-        uint32_t out = in;
-        while (ec[in] && ec[in] != '$') {
-            const uint32_t c = ec[in];
-            if (c == '.') {
-                ec[out++] = '$';
-                ++in;
-                ++d.right_clipping;
-                --d.ref_length;
-            } else if (c == '#') {
-                ec[out++] = '$';
-                in += 2;
-                ++d.right_clipping;
-                --d.err_edit_distance;
-            } else if (c == '^') {
-                in += 2;
-                --d.ref_length;
-                --d.err_edit_distance;
-            } else if (is_alpha(c)) {
-                ec[out++] = '$';
-                ++in;
-                ++d.right_clipping;
-                --d.ref_length;
-                --d.err_edit_distance;
-            } else {
-                ++in;
-            }
-        }
-        while (ec[in])
-            ec[out++] = ec[in++];
-        ec[out] = 0;
-    }
-    if (mini < left_penalty) {   // left clipping, 944-991
-        ++no_clippings;
-        in = d.left_clipping;
-        uint32_t out = in;
-        const uint32_t guard = in + (uint32_t)mini_pos + 1;
-        while (in != guard) {
-            const uint32_t c = ec[in];
-            if (c == '.') {
-                ec[out++] = '$';
-                ++in;
-                ++d.left_clipping;
-                ++d.ref_seq_pos;
-                --d.ref_length;
-            } else if (c == '#') {
-                ec[out++] = '$';
-                in += 2;
-                ++d.left_clipping;
-                --d.err_edit_distance;
-            } else if (c == '^') {
-                in += 2;
-                ++d.ref_seq_pos;
-                --d.ref_length;
-                --d.err_edit_distance;
-            } else if (is_alpha(c)) {
-                ec[out++] = '$';
-                ++in;
-                ++d.left_clipping;
-                ++d.ref_seq_pos;
-                --d.ref_length;
-                --d.err_edit_distance;
-            } else {
-                ++in;
-            }
-        }
-        while (ec[in])
-            ec[out++] = ec[in++];
-        ec[out] = 0;
-    }
-    // 993
-    d.score = (0.0 > maxi ? 0.0 : maxi) - (0.0 < mini ? 0.0 : mini) + no_clippings * sc.clipping;
-    d.no_clippings = (uint32_t)no_clippings;
-    d.cigar_len = length();
-}
-
-__global__ __launch_bounds__(256) void clip_boundary_kernel(uint32_t n, wamd_clip_record* __restrict__ records,
-                                                            uint8_t* __restrict__ cigars, uint32_t cigar_stride,
-                                                            wamd_scoring sc)
-{
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= n)
-        return;
-    wamd_clip_record d = records[gid];
-    clip_boundary_one(d, cigars + (uint64_t)gid * cigar_stride, cigar_stride, sc);
-    records[gid] = d;
-}
-
-// ---- row L: clipIllegalPositions (soft_clipping.cpp:592-729) ---------------------------------
-// One record per lane.  The three loops of the reference, byte for byte - including the tail
-// loop that does not advance its input on an ordinary symbol and so pads with '$' up to
-// read_length, and the '$' of an earlier clipping being scored as a mismatch.
-__device__ void clip_illegal_one(wamd_clip_record& d, const wamd_clip_illegal_task& t, uint8_t* ec, uint32_t stride,
-                                 const wamd_scoring& sc, uint32_t* flags)
-{
-    const int32_t ref_size = t.ref_size;
-    const int32_t mapping_last = d.ref_seq_pos + (int32_t)d.ref_length - 1;   // 596
-    const int read_length = t.read_length;
-    int to_left = 0, to_right = 0;
-    int i_read = 0, i_ref = d.ref_seq_pos;
-    d.no_clippings = 0;
-    if (d.ref_seq_pos <= 0)   // 604-610
-        to_left = -d.ref_seq_pos + 1;
-    if (mapping_last > ref_size)
-        to_right = mapping_last - ref_size;
-    if (!to_left && !to_right) {
-        d.cigar_len = bounded_len(ec, stride);
-        return;
-    }
-    if ((uint32_t)read_length + 1 > stride) {
-        raise_flag(flags, FLAG_CIGAR);
-        return;
-    }
-    if (t.perfect) {   // 614-618
-        for (int i = 0; i < read_length; ++i)
-            ec[i] = '.';
-        ec[read_length] = 0;
-    }
-    d.left_clipping = (uint16_t)(d.left_clipping + to_left);   // 620-625
-    d.right_clipping = (uint16_t)(d.right_clipping + to_right);
-    d.ref_length = (uint16_t)(d.ref_length - (to_left + to_right));
-    d.ref_seq_pos += to_left;
-    d.err_edit_distance = 0;
-    double score = 0;
-    d.no_clippings = (uint32_t)((to_left != 0) + (to_right != 0));
-
-    uint32_t in = 0, out = 0;
-    const uint32_t lim = stride - 1;
-    bool bad = false;
-    auto at = [&](uint32_t i) -> uint32_t { return i < stride ? ec[i] : 0u; };
-    uint32_t c;
-    while (i_ref < 1 && (c = at(in)) != 0) {   // 632-652
-        if (c == '^') {
-            in += 2;
-            ++i_ref;
-        } else if (c == '#') {
-            in += 2;
-            ec[out++] = '$';
-            ++i_read;
-        } else {
-            ++in;
-            ec[out++] = '$';
-            ++i_read;
-            ++i_ref;
-        }
-    }
-    bool gap_opened = false;
-    while (i_read < read_length && i_ref <= ref_size && (c = at(in)) != 0) {   // 655-703
-        if (c == '^' || c == '#') {
-            if (in + 1 >= lim) {
-                bad = true;
-                break;
-            }
-            ec[out++] = (uint8_t)c;
-            ec[out++] = ec[in + 1];
-            in += 2;
-            d.err_edit_distance++;
-            if (c == '^') {
-                ++i_ref;
-                score += gap_opened ? sc.gap_del_extend : sc.gap_del_open;
-            } else {
-                ++i_read;
-                score += gap_opened ? sc.gap_ins_extend : sc.gap_ins_open;
-            }
-            gap_opened = true;
-        } else {
-            if (c == '.')
-                score += sc.match;
-            else {
-                score += sc.mismatch;
-                d.err_edit_distance++;
-            }
-            ec[out++] = (uint8_t)c;
-            ++in;
-            ++i_read;
-            ++i_ref;
-            gap_opened = false;
-        }
-    }
-    while (!bad && i_read < read_length && (c = at(in)) != 0) {   // 706-725
-        if (c == '^') {
-            in += 2;
-            ++i_ref;
-        } else if (c == '#') {
-            in += 2;
-            ec[out++] = '$';
-            ++i_read;
-        } else {   // 719-724: the input does not move
-            if (out >= lim) {
-                bad = true;
-                break;
-            }
-            ec[out++] = '$';
-            ++i_read;
-            ++i_ref;
-        }
-    }
-    if (out > lim)
-        out = lim;
-    ec[out] = 0;   // 727
-    if (bad)
-        raise_flag(flags, FLAG_ARG);
-    d.score = score;
-    d.cigar_len = out;
-}
-
-__global__ __launch_bounds__(256) void clip_illegal_kernel(uint32_t n, const wamd_clip_illegal_task* __restrict__ tasks,
-                                                           wamd_clip_record* __restrict__ records,
-                                                           uint8_t* __restrict__ cigars, uint32_t stride,
-                                                           wamd_scoring sc, uint32_t* __restrict__ flags)
-{
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= n)
-        return;
-    wamd_clip_record d = records[gid];
-    clip_illegal_one(d, tasks[gid], cigars + (uint64_t)gid * stride, stride, sc, flags);
-    records[gid] = d;
-}
-
-// ---- row L: clipOverlappingPairs with clipLeft / clipRight (soft_clipping.cpp:997-1151) -------
-// One pair per lane.  Returns false where the reference would run off the string.
-__device__ bool clip_left(wamd_clip_record& d, uint8_t* ec, uint32_t stride, int count)
-{
-    uint32_t in = d.left_clipping, out = in;
-    int clipped = 0;
-    auto at = [&](uint32_t i) -> uint32_t { return i < stride ? ec[i] : 0u; };
-    uint32_t c;
-    while (clipped < count || (clipped == count && at(in) == '#')) {
-        c = at(in);
-        if (c == '.') {
-            ec[out++] = '$';
-            ++in;
-            ++d.left_clipping;
-            ++d.ref_seq_pos;
-            --d.ref_length;
-            ++clipped;
-        } else if (c == '#') {
-            ec[out++] = '$';
-            in += 2;
-            ++d.left_clipping;
-            --d.err_edit_distance;
-        } else if (c == '^') {
-            in += 2;
-            ++d.ref_seq_pos;
-            --d.ref_length;
-            --d.err_edit_distance;
-            ++clipped;
-        } else if (is_alpha(c)) {
-            ec[out++] = '$';
-            ++in;
-            ++d.left_clipping;
-            ++d.ref_seq_pos;
-            --d.ref_length;
-            --d.err_edit_distance;
-            ++clipped;
-        } else {
-            return false;
-        }
-    }
-    if (out != in) {   // 1092-1097
-        while ((c = at(in)) != 0) {
-            ec[out++] = (uint8_t)c;
-            ++in;
-        }
-        ec[out] = 0;
-    }
-    return true;
-}
-
-__device__ bool clip_right(wamd_clip_record& d, uint8_t* ec, uint32_t stride, int count)
-{
-    const int len = (int)bounded_len(ec, stride);
-    int in = len - (int)d.right_clipping - 1, out = in + 1;
-    int clipped = 0;
-    auto prev = [&]() -> uint32_t { return in >= 1 ? ec[in - 1] : 0u; };
-    while (clipped < count || (clipped == count && prev() == '#')) {
-        if (in < 0)
-            return false;
-        const uint32_t c = ec[in];
-        if (c == '.') {
-            ec[--out] = '$';
-            --in;
-            ++d.right_clipping;
-            --d.ref_length;
-            ++clipped;
-        } else if (is_alpha(c)) {
-            const uint32_t p = prev();
-            if (p == '#') {
-                ec[--out] = '$';
-                in -= 2;
-                ++d.right_clipping;
-                --d.err_edit_distance;
-            } else if (p == '^') {
-                in -= 2;
-                --d.ref_length;
-                --d.err_edit_distance;
-                ++clipped;
-            } else {
-                ec[--out] = '$';
-                --in;
-                ++d.right_clipping;
-                --d.ref_length;
-                --d.err_edit_distance;
-                ++clipped;
-            }
-        } else {
-            return false;
-        }
-    }
-    ++in;   // 1144-1150: the string becomes [0, in) + [out, len)
-    if (in != out) {
-        while (out < len)
-            ec[in++] = ec[out++];
-        ec[in] = 0;
-    }
-    return true;
-}
-
-__device__ void clip_pair_one(const wamd_clip_pair_task& t, wamd_clip_record (&rec)[2], uint8_t* ec0, uint8_t* ec1,
-                              uint32_t stride, uint32_t* flags)
-{
-    uint8_t* ec[2] = {ec0, ec1};
-    rec[0].no_clippings = rec[1].no_clippings = 0;
-    bool touched = false;
-    if (t.ref_seq_id[0] == t.ref_seq_id[1] && !rec[0].left_clipping && !rec[0].right_clipping &&
-        !rec[1].left_clipping && !rec[1].right_clipping) {   // 999-1003
-        int left;   // 1005-1025
-        if (rec[0].ref_seq_pos < rec[1].ref_seq_pos)
-            left = 0;
-        else if (rec[0].ref_seq_pos == rec[1].ref_seq_pos)
-            left = t.direct[0] ? 0 : 1;
-        else
-            left = 1;
-        const int right = 1 - left;
-        // dynamic indexing of the two records would put them in scratch memory: select instead
-        wamd_clip_record l = left ? rec[1] : rec[0], r = left ? rec[0] : rec[1];
-        uint8_t *ecl = left ? ec[1] : ec[0], *ecr = left ? ec[0] : ec[1];
-        const bool left_direct = left ? t.direct[1] : t.direct[0];
-        if (!left_direct && l.ref_seq_pos + (int32_t)l.ref_length > r.ref_seq_pos) {   // 1028
-            bool ok = true;
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-                if (t.perfect[q]) {   // 1029-1036
-                    const uint32_t rl = t.read_length[q];
-                    if (rl + 1 > stride) {
-                        ok = false;
-                    } else {
-                        for (uint32_t i = 0; i < rl; ++i)
-                            ec[q][i] = '.';
-                        ec[q][rl] = 0;
-                    }
-                }
-            if (ok) {
-                const int to_left = r.ref_seq_pos - l.ref_seq_pos;   // 1038-1039
-                const int to_right = (r.ref_seq_pos + (int32_t)r.ref_length) - (l.ref_seq_pos + (int32_t)l.ref_length);
-                ok = clip_left(l, ecl, stride, to_left);
-                ok = clip_right(r, ecr, stride, to_right) && ok;
-            }
-            if (!ok)
-                raise_flag(flags, FLAG_ARG);
-            l.no_clippings = r.no_clippings = 1;
-            rec[0] = left ? r : l;
-            rec[1] = left ? l : r;
-            touched = true;
-        }
-        (void)right;
-    }
-    (void)touched;
-    rec[0].cigar_len = bounded_len(ec[0], stride);
-    rec[1].cigar_len = bounded_len(ec[1], stride);
-}
-
-__global__ __launch_bounds__(256) void clip_pairs_kernel(uint32_t n_pairs, const wamd_clip_pair_task* __restrict__ tasks,
-                                                         wamd_clip_record* __restrict__ records,
-                                                         uint8_t* __restrict__ cigars, uint32_t stride,
-                                                         uint32_t* __restrict__ flags)
-{
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= n_pairs)
-        return;
-    wamd_clip_record rec[2] = {records[2 * (uint64_t)gid], records[2 * (uint64_t)gid + 1]};
-    clip_pair_one(tasks[gid], rec, cigars + 2 * (uint64_t)gid * stride, cigars + (2 * (uint64_t)gid + 1) * stride, stride,
-                  flags);
-    records[2 * (uint64_t)gid] = rec[0];
-    records[2 * (uint64_t)gid + 1] = rec[1];
-}
-
 __device__ __forceinline__ uint8_t indel_size_encode(int32_t x)   // types.h:296-302
 {
     return x > 0 ? (uint8_t)x : (uint8_t)(-x + 128);
@@ -1045,519 +547,6 @@ int launch_indel_ext_cigar(wamd_ctx* ctx, const wamd_reads* r, const wamd_indel_
     hipLaunchKernelGGL(indel_ext_cigar_kernel, dim3((n + 63) / 64), dim3(64), (size_t)(qd + gd) * 256, s,
                        genome_view(ctx), r->view(), d_tasks, n, ctx->scoring, d_results, d_cigars, cigar_stride, qd, gd,
                        ctx->d_flags);
-    WAMD_HIP(hipGetLastError());
-    return WAMD_OK;
-}
-
-// ---- ext-CIGAR -> SAM CIGAR text, BAM operations, MD:Z (row X) ------------------------------
-// CSamGenerator::extract_cigar_and_mdz / extract_cigarbin_and_mdz (sam.cpp:805-928, 932-1051):
-// one state machine over the ext-CIGAR bytes; an operation is flushed when the state changes,
-// matches and mismatches share one 'M' run, MD:Z counts matches across insertions and writes
-// the count (also a 0) in front of every mismatch and of EVERY deleted base.
-__device__ __forceinline__ uint32_t put_decimal(uint8_t* dst, uint32_t v)
-{
-    uint32_t n = 1;
-    for (uint32_t t = v; t >= 10; t /= 10)
-        ++n;
-    for (uint32_t i = n; i-- > 0; v /= 10)
-        dst[i] = (uint8_t)('0' + v % 10);
-    return n;
-}
-
-__device__ wamd_sam_cigar_len sam_cigar_one(const uint8_t* ext, uint32_t ext_stride, uint8_t* cg, uint32_t cigar_stride,
-                                            uint8_t* md, uint32_t mdz_stride, uint32_t* cb, uint32_t bin_stride,
-                                            uint32_t* flags)
-{
-    enum { Match, Mismatch, Insertion, Deletion, Begin, End, Clipping };
-    uint32_t e = 0, c = 0, d = 0, b = 0;       // cursors: ext-CIGAR, CIGAR text, MD:Z, BAM operations
-    // The reference keeps one counter per operation kind, bumps the current kind's at every step and clears the
-    // previous kind's at every change of kind: what it reads at a change - the previous kind's counter - is the
-    // length of the run that has just ended, so one running length serves (an array indexed by the kind would be
-    // a chain of selects per step here).  Matches and mismatches are counted by run_m instead, as there.
-    uint32_t run = 0, ended_run = 0;
-    uint32_t run_m = 0, run_md = 0;            // cnt_match_mismatch, cnt_match_ignoring_insert
-    int cur = Begin, prev = Begin;
-    bool overflow = false;
-    const bool by4 = str_aligned(ext);
-    while (cur != End) {
-        const uint32_t ch = e < ext_stride ? ext[e] : 0u;   // a slot without a NUL ends at its stride
-        // 12 bytes of head room cover the longest single step (a count and two symbols)
-        if (c + 12 > cigar_stride || d + 14 > mdz_stride || (cb && b + 1 > bin_stride)) {
-            overflow = true;
-            break;
-        }
-        // inside a run of matches four more dots change three counts and nothing else (no flush: cur == prev)
-        if (by4 && prev == Match && e + 8 <= ext_stride && str4(ext, e) == FOUR_DOTS) {
-            run_m += 4;
-            run_md += 4;
-            e += 4;
-            continue;
-        }
-        if (ch == '$') {
-            cur = Clipping;
-            ++e;
-        } else if (ch == 0) {
-            cur = End;
-            if (run_md > 0)
-                d += put_decimal(md + d, run_md);
-        } else if (ch == '.') {
-            ++e;
-            cur = Match;
-        } else if (ch == '#') {
-            e += 2;
-            cur = Insertion;
-        } else {
-            d += put_decimal(md + d, run_md);
-            run_md = 0;
-            if (ch == '^') {
-                md[d++] = (uint8_t)ch;
-                md[d++] = e + 1 < ext_stride ? ext[e + 1] : 0;
-                e += 2;
-                cur = Deletion;
-            } else {
-                md[d++] = (uint8_t)ch;
-                ++e;
-                cur = Mismatch;
-            }
-        }
-        ended_run = run;
-        run = cur == prev ? run + 1 : 1;
-        if (cur == Match) {
-            ++run_m;
-            ++run_md;
-        } else if (cur == Mismatch) {
-            ++run_m;
-        }
-        if (cur != prev && prev != Begin) {
-            uint32_t count = 0, op = 0;
-            bool flush = false;
-            if (prev == Clipping) {
-                count = ended_run, op = 4, flush = true;    // S_op
-            } else if (prev == Insertion) {
-                count = ended_run, op = 1, flush = true;   // I_op
-            } else if (prev == Deletion) {
-                count = ended_run, op = 2, flush = true;    // D_op
-            } else if ((prev == Match && cur != Mismatch) || (prev == Mismatch && cur != Match)) {
-                count = run_m, op = 0, flush = true;                 // M_op
-                run_m = 0;
-            }
-            if (flush) {
-                c += put_decimal(cg + c, count);
-                cg[c++] = (uint8_t)(0x534e44494dull >> (8 * op));   // "MIDNS"[op]
-                if (cb)
-                    cb[b++] = count << 4 | op;
-            }
-        }
-        prev = cur;
-    }
-    if (overflow) {
-        raise_flag(flags, FLAG_CIGAR);
-        c = d = b = 0;
-    }
-    cg[c] = 0;
-    md[d] = 0;
-    wamd_sam_cigar_len l;
-    l.cigar_len = c;
-    l.mdz_len = d;
-    l.cigar_bin_len = b;
-    l.reserved = overflow ? 1u : 0u;
-    return l;
-}
-
-__global__ __launch_bounds__(256) void sam_cigar_kernel(uint32_t n, const uint8_t* __restrict__ ext_cigars,
-                                                        uint32_t ext_stride, uint8_t* __restrict__ cigars,
-                                                        uint32_t cigar_stride, uint8_t* __restrict__ mdz,
-                                                        uint32_t mdz_stride, uint32_t* __restrict__ cigar_bin,
-                                                        uint32_t bin_stride, wamd_sam_cigar_len* __restrict__ lens,
-                                                        uint32_t* __restrict__ flags)
-{
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= n)
-        return;
-    lens[gid] = sam_cigar_one(ext_cigars + (uint64_t)gid * ext_stride, ext_stride, cigars + (uint64_t)gid * cigar_stride,
-                              cigar_stride, mdz + (uint64_t)gid * mdz_stride, mdz_stride,
-                              cigar_bin ? cigar_bin + (uint64_t)gid * bin_stride : nullptr, bin_stride, flags);
-}
-
-// ---- rows L, B, L, X behind one another on an LDS copy of the ext-CIGARs --------------------------
-// clipIllegalPositions, clipBoundaryPositions, clipOverlappingPairs and extract_cigar_and_mdz
-// (sam.cpp:1889-1900, 2002-2007) for 64 consecutive slots (32 pairs) per wave - all four behind one another
-// (finish_pairs) or any one of them (the stand-alone entry points of these rows: on the slots in HBM every byte
-// a lane touches is its own cache line, and lines do not survive in L1 between a lane's accesses - 8 to 37 KB of
-// line traffic per 150-byte string).  The wave copies its slots from global memory into LDS with coalesced loads
-// (the slots are contiguous), every lane then runs the routines on its own copy - the per-record state machines
-// above, unchanged, so the bytes they produce are the same - and the wave writes the slots back once.  A lane's
-// copy starts at an odd dword stride, so lanes reading the same offset of their strings hit different banks.
-// Records travel between the two lanes of a pair by shuffles.
-enum { POST_ILLEGAL = 1, POST_BOUNDARY = 2, POST_PAIRS = 4, POST_SAM = 8,
-       POST_LEN_IN_RESERVED = 16,   // lens[].reserved = length of the ext-CIGAR + 2 (finish_pairs' bookkeeping)
-       POST_TWO_HALVES = 32 };      // test hook: never pack
-
-__global__ __launch_bounds__(64, 4) void post_passes_kernel(uint32_t n, const wamd_clip_illegal_task* __restrict__ it,
-                                                         const wamd_clip_pair_task* __restrict__ pt,
-                                                         wamd_clip_record* __restrict__ records, uint8_t* __restrict__ ext,
-                                                         uint32_t ext_stride, const uint32_t* __restrict__ cap_hint,
-                                                         uint32_t budget_dw, wamd_scoring sc, uint32_t passes,
-                                                         uint8_t* __restrict__ cigars, uint32_t cigar_stride,
-                                                         uint8_t* __restrict__ mdz, uint32_t mdz_stride,
-                                                         uint32_t* __restrict__ cigar_bin, uint32_t bin_stride,
-                                                         wamd_sam_cigar_len* __restrict__ lens, int2* __restrict__ mid,
-                                                         uint32_t* __restrict__ flags)
-{
-    extern __shared__ uint32_t post_lds[];
-    const uint32_t lane = threadIdx.x;
-    const uint32_t base = blockIdx.x * 64;
-    const uint32_t here = n - base < 64u ? n - base : 64u;   // slots of this wave (pairs stay together: base is even)
-    const uint32_t slot = base + lane;
-    const bool live = lane < here;
-    const uint32_t full_dw = (ext_stride / 4) | 1u;   // odd: lanes at the same offset of their strings hit different banks
-    // What a lane's string needs.  The wave packs its strings by their lengths: the LDS of a wave, not its
-    // registers, is what limits the waves per CU here.  A caller that knows how long the strings are (and can get: a
-    // clipping pass never lengthens one, a perfect match may receive read_length dots) says so per slot; otherwise
-    // the wave measures them, one slot after the other with the lanes side by side on its dwords.  Both strings of
-    // a pair get the room of the longer one (the pair routine takes one capacity).  When the packed strings do not
-    // fit the budget, the wave serves its 32 even / odd pairs in two halves at the full stride.
-    //
-    // Staging: a lane fetches ITS OWN slot, sixteen bytes at a time into registers (strings up to 16 * POST_CH
-    // bytes), all requests in flight at once - a loop in which the wave copies one slot after the other, coalesced
-    // as it is, waits for memory sixty-four times in a row, and that wait was most of these kernels' time.  The
-    // loop form remains for longer strings, unaligned strides and the two-halves case.
-    constexpr int POST_CH = 12;
-    const bool regs_ok = (ext_stride & 15u) == 0 && ((uintptr_t)ext & 15u) == 0;
-    wamd_u32x4 rg[POST_CH];
-    uint32_t my_dw = 0;
-    bool in_regs = regs_ok;   // (wave-uniform from here on)
-    if (cap_hint) {
-        uint32_t c = 0;
-        if (live) {
-            c = cap_hint[slot] < ext_stride ? cap_hint[slot] : ext_stride;
-            my_dw = ((c + 3) / 4) | 1u;
-            my_dw = my_dw > full_dw ? full_dw : my_dw;
-        }
-        {   // (a pair shares the longer capacity, see below: what is fetched must cover it)
-            const uint32_t other = (uint32_t)__shfl_xor((int)my_dw, 1);
-            my_dw = my_dw > other ? my_dw : (live ? other : 0u);
-        }
-        in_regs = regs_ok && !__any(live && my_dw * 4 > 16u * POST_CH);
-        if (in_regs) {
-            const wamd_u32x4* src = reinterpret_cast<const wamd_u32x4*>(ext + (uint64_t)(live ? slot : base) * ext_stride);
-#pragma unroll
-            for (int q = 0; q < POST_CH; ++q)
-                if (live && 16u * q < my_dw * 4 && 16u * q < ext_stride)
-                    rg[q] = src[q];
-        }
-    } else {
-        uint32_t my_len = ext_stride;   // bytes up to and including the dword that holds the NUL
-        bool found = false;
-        if (regs_ok) {
-            const wamd_u32x4* src = reinterpret_cast<const wamd_u32x4*>(ext + (uint64_t)(live ? slot : base) * ext_stride);
-#pragma unroll
-            for (int q = 0; q < POST_CH; ++q)
-                if (live && 16u * q < ext_stride)
-                    rg[q] = src[q];
-#pragma unroll
-            for (int q = 0; q < POST_CH; ++q)
-                if (live && !found && 16u * q < ext_stride) {
-                    const uint32_t w[4] = {rg[q].x, rg[q].y, rg[q].z, rg[q].w};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (!found && ((w[j] - 0x01010101u) & ~w[j] & 0x80808080u)) {
-                            found = true;
-                            my_len = 16u * q + 4u * j + 4u;
-                        }
-                }
-            if (ext_stride <= 16u * POST_CH)
-                found = true;   // the whole slot is in the registers
-        }
-        const bool measured = regs_ok && !__any(live && !found);
-        if (!measured) {   // the wave measures its slots one after the other, the lanes side by side on a slot's dwords
-            for (uint32_t sl = 0; sl < here; ++sl) {
-                const uint32_t* src = reinterpret_cast<const uint32_t*>(ext + (uint64_t)(base + sl) * ext_stride);
-                uint32_t len = ext_stride;
-                for (uint32_t i0 = 0; i0 < ext_stride / 4; i0 += 64) {
-                    const uint32_t i = i0 + lane;
-                    bool z = false;
-                    if (i < ext_stride / 4) {
-                        const uint32_t v = src[i];
-                        z = ((v - 0x01010101u) & ~v & 0x80808080u) != 0;
-                    }
-                    const uint64_t m = __ballot(z);
-                    if (m) {
-                        len = 4 * (i0 + (uint32_t)__builtin_ctzll(m)) + 4;
-                        break;
-                    }
-                }
-                if (lane == sl)
-                    my_len = len;
-            }
-        }
-        if (live) {
-            // a perfect match may be filled with read_length dots (clipIllegalPositions, 614-618), and the tail loop
-            // of that routine pads up to read_length
-            // (so may clipOverlappingPairs, 1029-1036)
-            uint32_t grow = (passes & POST_ILLEGAL) ? (uint32_t)it[slot].read_length + 1u : 0u;
-            if (passes & POST_PAIRS) {
-                const uint32_t g2 = (uint32_t)pt[slot >> 1].read_length[lane & 1u] + 1u;
-                grow = grow > g2 ? grow : g2;
-            }
-            uint32_t c = (my_len > grow ? my_len : grow) + 8u;
-            c = c < ext_stride ? c : ext_stride;
-            my_dw = ((c + 3) / 4) | 1u;
-            my_dw = my_dw > full_dw ? full_dw : my_dw;
-        }
-        in_regs = measured && !__any(live && my_dw * 4 > 16u * POST_CH && ext_stride > 16u * POST_CH);
-    }
-    {
-        const uint32_t other = (uint32_t)__shfl_xor((int)my_dw, 1);
-        my_dw = my_dw > other ? my_dw : (live ? other : 0u);
-    }
-    uint32_t incl = my_dw;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
-        if (lane >= (uint32_t)d)
-            incl += o;
-    }
-    const uint32_t total = (uint32_t)__shfl((int)incl, 63);
-    // lanes served together when the strings are not packed: as many (a power of two, pairs stay together) as fit
-    // the budget at the full stride - 32 unless the caller's stride is long (the launcher caps the budget so that
-    // the stride does not decide how many waves a CU holds)
-    uint32_t per = 32, per_sh = 5;
-    while (per > 2 && per * full_dw > budget_dw) {
-        per >>= 1;
-        --per_sh;
-    }
-    const int halves = (total <= budget_dw && !(passes & POST_TWO_HALVES)) ? 1 : (int)(64u / per);
-    for (int h = 0; h < halves; ++h) {
-        // lanes of this pass, where their strings start and how many dwords they hold
-        const bool mine = halves == 1 || (lane >> per_sh) == (uint32_t)h;
-        uint32_t ndw = mine ? my_dw : 0u, off = incl - my_dw;
-        if (halves != 1) {
-            ndw = (mine && live) ? full_dw : 0u;
-            off = (lane & (per - 1u)) * full_dw;
-        }
-        const uint32_t cap = ndw * 4 < ext_stride ? ndw * 4 : ext_stride;   // bytes of the string the routines may use
-        const uint32_t lim_dw = ndw < ext_stride / 4 ? ndw : ext_stride / 4;   // dwords that travel
-        const bool by_regs = in_regs && halves == 1;
-        if (by_regs) {
-#pragma unroll
-            for (int q = 0; q < POST_CH; ++q) {
-                const uint32_t w[4] = {rg[q].x, rg[q].y, rg[q].z, rg[q].w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (4u * q + j < lim_dw)
-                        post_lds[off + 4 * q + j] = w[j];
-            }
-        } else {
-            for (uint32_t sl = 0; sl < here; ++sl) {   // coalesced: the wave copies one string after the other
-                const uint32_t n_s = (uint32_t)__builtin_amdgcn_readlane((int)lim_dw, (int)sl);
-                if (!n_s)
-                    continue;
-                const uint32_t o_s = (uint32_t)__builtin_amdgcn_readlane((int)off, (int)sl);
-                const uint32_t* src = reinterpret_cast<const uint32_t*>(ext + (uint64_t)(base + sl) * ext_stride);
-                for (uint32_t i = lane; i < n_s; i += 64)
-                    post_lds[o_s + i] = src[i];
-            }
-        }
-        __syncthreads();
-        const bool act = live && mine;
-        uint8_t* ec = reinterpret_cast<uint8_t*>(post_lds + off);
-        wamd_clip_record d{};
-        if (act && (passes & (POST_ILLEGAL | POST_BOUNDARY | POST_PAIRS))) {
-            d = records[slot];
-            if (passes & POST_ILLEGAL)
-                clip_illegal_one(d, it[slot], ec, cap, sc, flags);
-            if (passes & POST_BOUNDARY)
-                clip_boundary_one(d, ec, cap, sc);
-            if (mid)   // where the mapping lies before the pair is clipped (finish_pairs: isDistant of the mate)
-                mid[slot] = make_int2(d.ref_seq_pos, (int)d.ref_length);
-        }
-        __syncthreads();   // every lane's string is as its own passes left it before a partner touches it
-        if (passes & POST_PAIRS) {
-            // the even lane of a pair takes its partner's record, clips both strings, hands the record back
-            uint32_t w[8], v[8];
-            memcpy(w, &d, 32);
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-                v[q] = (uint32_t)__shfl_down((int)w[q], 1);
-            const uint32_t off1 = (uint32_t)__shfl_down((int)off, 1);
-            wamd_clip_record rec[2];
-            rec[0] = d;
-            memcpy(&rec[1], v, 32);
-            if (act && !(lane & 1u) && lane + 1 < here)
-                clip_pair_one(pt[slot >> 1], rec, ec, reinterpret_cast<uint8_t*>(post_lds + off1), cap, flags);
-            memcpy(w, &rec[1], 32);
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-                v[q] = (uint32_t)__shfl_up((int)w[q], 1);
-            if (lane & 1u)
-                memcpy(&d, v, 32);
-            else
-                d = rec[0];
-            __syncthreads();
-        }
-        if (act) {
-            if (passes & POST_SAM) {
-                wamd_sam_cigar_len l = sam_cigar_one(ec, cap, cigars + (uint64_t)slot * cigar_stride, cigar_stride,
-                                                     mdz + (uint64_t)slot * mdz_stride, mdz_stride,
-                                                     cigar_bin ? cigar_bin + (uint64_t)slot * bin_stride : nullptr, bin_stride,
-                                                     flags);
-                // the length of the ext-CIGAR as the passes left it, + 2 (0 / 1 = not measured), for the caller's
-                // bookkeeping: here it costs LDS reads, from the slots in memory a line fetch per lane and byte
-                if (passes & POST_LEN_IN_RESERVED)
-                    l.reserved = bounded_len(ec, cap) + 2;
-                lens[slot] = l;
-            }
-            if (passes & (POST_ILLEGAL | POST_BOUNDARY | POST_PAIRS))
-                records[slot] = d;
-        }
-        __syncthreads();
-        if (passes & (POST_ILLEGAL | POST_BOUNDARY | POST_PAIRS)) {   // (extract_cigar_and_mdz only reads)
-            if (by_regs) {
-                uint32_t* dst = reinterpret_cast<uint32_t*>(ext + (uint64_t)(live ? slot : base) * ext_stride);
-#pragma unroll
-                for (int q = 0; q < POST_CH; ++q) {
-                    if (4u * q + 4u <= lim_dw) {
-                        wamd_u32x4 v = {post_lds[off + 4 * q], post_lds[off + 4 * q + 1], post_lds[off + 4 * q + 2],
-                                        post_lds[off + 4 * q + 3]};
-                        *reinterpret_cast<wamd_u32x4*>(dst + 4 * q) = v;
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (4u * q + j < lim_dw)
-                                dst[4 * q + j] = post_lds[off + 4 * q + j];
-                    }
-                }
-            } else {
-                for (uint32_t sl = 0; sl < here; ++sl) {
-                    const uint32_t n_s = (uint32_t)__builtin_amdgcn_readlane((int)lim_dw, (int)sl);
-                    if (!n_s)
-                        continue;
-                    const uint32_t o_s = (uint32_t)__builtin_amdgcn_readlane((int)off, (int)sl);
-                    uint32_t* dst = reinterpret_cast<uint32_t*>(ext + (uint64_t)(base + sl) * ext_stride);
-                    for (uint32_t i = lane; i < n_s; i += 64)
-                        dst[i] = post_lds[o_s + i];
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
-
-static bool rows_can_stage(const void* slots, uint32_t stride)
-{
-    return (stride & 3u) == 0 && stride >= 4 && stride <= 2000 && ((uintptr_t)slots & 3u) == 0;
-}
-
-static int launch_post_kernel(wamd_ctx* ctx, uint32_t n, const wamd_clip_illegal_task* it, const wamd_clip_pair_task* pt,
-                              wamd_clip_record* rec, uint8_t* ext, uint32_t ext_stride, const uint32_t* cap_hint,
-                              uint32_t passes, uint8_t* cigars, uint32_t cigar_stride, uint8_t* mdz, uint32_t mdz_stride,
-                              uint32_t* bin, uint32_t bin_stride, wamd_sam_cigar_len* lens, hipStream_t s,
-                              int2* mid = nullptr)
-{
-    if (n == 0)
-        return WAMD_OK;
-    if (ctx->test_hooks & HOOK_POST_NO_HINTS) {   // test hook: the two-halves path of every wave
-        cap_hint = nullptr;
-        passes |= POST_TWO_HALVES;
-    }
-    // LDS of a wave: 32 strings at the full (odd) stride - what a half needs when the strings are not packed
-    // ... capped at 11.4 KB (fourteen waves per CU; what 32 strings of 352 bytes take): longer strides are served
-    // in smaller groups when their strings do not pack
-    const uint32_t full_dw = (ext_stride / 4) | 1u;
-    uint32_t budget_dw = 32u * full_dw;
-    if (budget_dw > 2912u)
-        budget_dw = 2912u > 2u * full_dw ? 2912u : 2u * full_dw;
-    hipLaunchKernelGGL(post_passes_kernel, dim3((n + 63) / 64), dim3(64), (size_t)budget_dw * 4, s, n, it, pt, rec, ext,
-                       ext_stride, cap_hint, budget_dw, ctx->scoring, passes, cigars, cigar_stride, mdz, mdz_stride, bin,
-                       bin_stride, lens, mid, ctx->d_flags);
-    WAMD_HIP(hipGetLastError());
-    return WAMD_OK;
-}
-
-__global__ __launch_bounds__(256) void post_mid_kernel(uint32_t n, const wamd_clip_record* __restrict__ rec,
-                                                       int2* __restrict__ mid)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n)
-        mid[i] = make_int2(rec[i].ref_seq_pos, (int)rec[i].ref_length);
-}
-
-int launch_clip_boundary(wamd_ctx* ctx, uint32_t n, wamd_clip_record* d_records, uint8_t* d_cigars,
-                         uint32_t cigar_stride, hipStream_t s)
-{
-    WAMD_HIP(hipSetDevice(ctx->device));
-    if (rows_can_stage(d_cigars, cigar_stride))
-        return launch_post_kernel(ctx, n, nullptr, nullptr, d_records, d_cigars, cigar_stride, nullptr, POST_BOUNDARY,
-                                  nullptr, 0, nullptr, 0, nullptr, 0, nullptr, s);
-    hipLaunchKernelGGL(clip_boundary_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_records, d_cigars,
-                       cigar_stride, ctx->scoring);
-    WAMD_HIP(hipGetLastError());
-    return WAMD_OK;
-}
-
-int launch_clip_illegal(wamd_ctx* ctx, uint32_t n, const wamd_clip_illegal_task* d_tasks, wamd_clip_record* d_records,
-                        uint8_t* d_cigars, uint32_t cigar_stride, hipStream_t s)
-{
-    WAMD_HIP(hipSetDevice(ctx->device));
-    if (rows_can_stage(d_cigars, cigar_stride))
-        return launch_post_kernel(ctx, n, d_tasks, nullptr, d_records, d_cigars, cigar_stride, nullptr, POST_ILLEGAL,
-                                  nullptr, 0, nullptr, 0, nullptr, 0, nullptr, s);
-    hipLaunchKernelGGL(clip_illegal_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_tasks, d_records, d_cigars,
-                       cigar_stride, ctx->scoring, ctx->d_flags);
-    WAMD_HIP(hipGetLastError());
-    return WAMD_OK;
-}
-
-int launch_clip_pairs(wamd_ctx* ctx, uint32_t n_pairs, const wamd_clip_pair_task* d_tasks, wamd_clip_record* d_records,
-                      uint8_t* d_cigars, uint32_t cigar_stride, hipStream_t s)
-{
-    WAMD_HIP(hipSetDevice(ctx->device));
-    if (rows_can_stage(d_cigars, cigar_stride) && n_pairs <= 0x7fffffffu)
-        return launch_post_kernel(ctx, 2 * n_pairs, nullptr, d_tasks, d_records, d_cigars, cigar_stride, nullptr, POST_PAIRS,
-                                  nullptr, 0, nullptr, 0, nullptr, 0, nullptr, s);
-    hipLaunchKernelGGL(clip_pairs_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, s, n_pairs, d_tasks, d_records,
-                       d_cigars, cigar_stride, ctx->d_flags);
-    WAMD_HIP(hipGetLastError());
-    return WAMD_OK;
-}
-
-// the fused form when half a wave's slots fit LDS (64 KB: ext_stride up to 2000), else the four kernels in turn
-int launch_post_passes(wamd_ctx* ctx, uint32_t n, const wamd_clip_illegal_task* d_it, const wamd_clip_pair_task* d_pt,
-                       wamd_clip_record* d_rec, uint8_t* d_ext, uint32_t ext_stride, const uint32_t* d_cap_hint,
-                       int do_boundary, int do_pairs, uint8_t* d_cigars, uint32_t cigar_stride, uint8_t* d_mdz,
-                       uint32_t mdz_stride, wamd_sam_cigar_len* d_lens, int2* d_mid, hipStream_t s)
-{
-    WAMD_HIP(hipSetDevice(ctx->device));
-    if (rows_can_stage(d_ext, ext_stride) && (n & 1u) == 0)
-        return launch_post_kernel(ctx, n, d_it, d_pt, d_rec, d_ext, ext_stride, d_cap_hint,
-                                  POST_ILLEGAL | (do_boundary ? POST_BOUNDARY : 0) | (do_pairs ? POST_PAIRS : 0) | POST_SAM |
-                                      POST_LEN_IN_RESERVED,
-                                  d_cigars, cigar_stride, d_mdz, mdz_stride, nullptr, 0, d_lens, s, d_mid);
-    int rc = launch_clip_illegal(ctx, n, d_it, d_rec, d_ext, ext_stride, s);
-    if (!rc && do_boundary)
-        rc = launch_clip_boundary(ctx, n, d_rec, d_ext, ext_stride, s);
-    if (!rc && d_mid && n) {
-        hipLaunchKernelGGL(post_mid_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_rec, d_mid);
-        WAMD_HIP(hipGetLastError());
-    }
-    if (!rc && do_pairs)
-        rc = launch_clip_pairs(ctx, n / 2, d_pt, d_rec, d_ext, ext_stride, s);
-    if (!rc)
-        rc = launch_sam_cigar(ctx, n, d_ext, ext_stride, d_cigars, cigar_stride, d_mdz, mdz_stride, nullptr, 0, d_lens, s);
-    return rc;
-}
-
-int launch_sam_cigar(wamd_ctx* ctx, uint32_t n, const uint8_t* d_ext, uint32_t ext_stride, uint8_t* d_cigars,
-                     uint32_t cigar_stride, uint8_t* d_mdz, uint32_t mdz_stride, uint32_t* d_bin, uint32_t bin_stride,
-                     wamd_sam_cigar_len* d_lens, hipStream_t s)
-{
-    WAMD_HIP(hipSetDevice(ctx->device));
-    if (rows_can_stage(d_ext, ext_stride))
-        return launch_post_kernel(ctx, n, nullptr, nullptr, nullptr, const_cast<uint8_t*>(d_ext), ext_stride, nullptr, POST_SAM,
-                                  d_cigars, cigar_stride, d_mdz, mdz_stride, d_bin, bin_stride, d_lens, s);
-    hipLaunchKernelGGL(sam_cigar_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_ext, ext_stride, d_cigars,
-                       cigar_stride, d_mdz, mdz_stride, d_bin, bin_stride, d_lens, ctx->d_flags);
     WAMD_HIP(hipGetLastError());
     return WAMD_OK;
 }
