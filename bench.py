@@ -46,6 +46,12 @@ LANE_OPS_EXACT = N_COLS * (DWORDS * 10 + 20)
 BAND_FS = (N_COLS + K_ERR - 64 + 7) // 8 * 8
 LANE_OPS_BAND = BAND_FS * 24 + (N_COLS - BAND_FS) * 44
 LANE_OPS_SURVEY_8D = (W + 1) * (((M - 1) // 64 + 1) * 40 + 8)
+# `roofline.algorithmic`: the recurrence alone - the ten (exact) or nine / ten (band) operations per 32-bit dword and
+# column that the Myers / Hyyro update cannot do without on this ISA, none of the kernel's bookkeeping (minimum
+# tracking, symbol fetch, loop control).  `frac` against this count is the distance from an algorithmic bound; `frac`
+# of the instruction-count model above is issue-slot utilisation.
+LANE_OPS_EXACT_RECURRENCE = N_COLS * DWORDS * 10
+LANE_OPS_BAND_RECURRENCE = BAND_FS * 2 * 9 + (N_COLS - BAND_FS) * 2 * 10
 # algorithmic bytes per task: 2-bit read + 2-bit window + 16 B task + 4 B result
 BYTES_PER_TASK = (M + 3) // 4 + (W + 3 + 3) // 4 + 16 + 4
 # MI355X: 256 CUs x 4 SIMD x 32 lanes/clk x 2.4 GHz (MI355X_MICROARCH.md: SIMD-32, 2400 MHz)
@@ -73,13 +79,14 @@ def roof_hbm(units, bytes_per_unit, ms, kernel=None):
 
 
 def measured_counters():
-    """Per-kernel PMC figures of the committed profile of this tree, if any (profiles/round2_counters.json):
+    """Per-kernel PMC figures of the committed profile of this tree, if any (profiles/round3_counters.json):
     HBM bytes per unit and VALU instructions per unit, keyed by the extras / roofline tag."""
-    f = os.path.join(ROOT, "profiles", "round2_counters.json")
-    try:
-        return json.load(open(f))
-    except Exception:
-        return {}
+    for name in ("round3_counters.json", "round2_counters.json"):
+        try:
+            return json.load(open(os.path.join(ROOT, "profiles", name)))
+        except Exception:
+            continue
+    return {}
 
 
 # ---- profile markers -------------------------------------------------------------------------------------------
@@ -938,6 +945,8 @@ def main():
                   "tasks": n, "kernel_ms": bms, "candidates_per_s": n / bms * 1e3,
                   "accepted_identical_rejected_clamped": same,
                   "roofline": roof_valu(n, LANE_OPS_BAND, bms, "myers_band_kernel<2,128>")}
+        banded["roofline"]["algorithmic"] = {"lane_ops_per_task": LANE_OPS_BAND_RECURRENCE,
+                                             "frac": n * LANE_OPS_BAND_RECURRENCE / (bms * 1e-3) / PEAK_VALU_LANEOPS}
         banded["roofline"]["hbm"] = {"achieved": n * BYTES_PER_TASK / (bms * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9,
                                      "unit": "GB/s", "frac": n * BYTES_PER_TASK / (bms * 1e-3) / PEAK_HBM}
 
@@ -974,6 +983,13 @@ def main():
         out["roofline"] = roof_valu(n, LANE_OPS_EXACT if exact else LANE_OPS_BAND, kernel_ms,
                                     "myers_distance_kernel<%d,256>" % DWORDS if exact else "myers_band_kernel<2,128>")
         out["roofline"]["kernel_ms"] = kernel_ms
+        alg = LANE_OPS_EXACT_RECURRENCE if exact else LANE_OPS_BAND_RECURRENCE
+        out["roofline"]["algorithmic"] = {"lane_ops_per_task": alg,
+                                          "achieved": n * alg / (kernel_ms * 1e-3) / 1e12,
+                                          "frac": n * alg / (kernel_ms * 1e-3) / PEAK_VALU_LANEOPS,
+                                          "note": "recurrence only (10 lane-ops per 32-bit dword and column; band: 9 "
+                                                  "sliding / 10 fixed), no bookkeeping: distance from an algorithmic "
+                                                  "bound, where `frac` above is issue-slot utilisation"}
         out["roofline"]["survey_8d"] = {"lane_ops_per_task": LANE_OPS_SURVEY_8D,
                                         "frac": n * LANE_OPS_SURVEY_8D / (kernel_ms * 1e-3) / PEAK_VALU_LANEOPS,
                                         "note": "SURVEY 8(d)'s count for the same task; not a lower bound on gfx950"}

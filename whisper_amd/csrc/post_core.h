@@ -117,27 +117,31 @@ PC_FN void set_len(Str& s, uint32_t len)
 // Returns 0, or PC_BAD_STRING when the string breaks the grammar (see the head of this file).
 PC_FN uint32_t digest(Str& s)
 {
+    // The byte tests assume 7-bit bytes (x + 0x7f sets bit 7 of a byte iff it is not 0, without a carry into the next
+    // one); a byte above 0x7f inside the string is refused, one behind the NUL can only disturb what lies behind it.
+    constexpr uint32_t H = 0x80808080u, L = 0x7f7f7f7fu;
     const uint32_t nd = s.cap / 4;
     uint32_t acc = 0, carry = 0, bad = 0;
     bool open = true;
     s.len = s.cap;
     for (uint32_t k = 0; k < nd; ++k) {
         const uint32_t w = s.dw[k];
-        const uint32_t z = zero_bytes(w);
-        const uint32_t dot = eq_bytes(w, 0x2e2e2e2eu);
-        const uint32_t mark = eq_bytes(w, 0x23232323u) | eq_bytes(w, 0x5e5e5e5eu);
-        uint32_t valid = open ? 0x80808080u : 0u;
+        const uint32_t z = ~(w + L) & H;                                        // bytes that are 0
+        const uint32_t not_dot = (w ^ 0x2e2e2e2eu) + L;                         // bit 7 of a byte: it is not '.'
+        const uint32_t mark = ~(((w ^ 0x23232323u) + L) & ((w ^ 0x5e5e5e5eu) + L)) & H;     // '#' or '^'
+        uint32_t valid = open ? H : 0u;
         if (open && z) {
             const uint32_t j = (uint32_t)__builtin_ctz(z) >> 3;     // first zero byte of this dword
-            valid = j ? 0x80808080u & ((1u << (8u * j)) - 1u) : 0u;
+            valid = j ? H & ((1u << (8u * j)) - 1u) : 0u;
             s.len = 4 * k + j;
             open = false;
             // a mark in front of the NUL has no symbol behind it
             bad |= j ? (mark >> (8u * (j - 1))) & 0x80u : carry;
         }
         const uint32_t pay = (mark << 8) | carry;
-        bad |= mark & pay & valid;                                  // two marks in a row
-        acc |= pack4(~(dot | pay) & valid) << (4u * (k & 7u));
+        bad |= ((mark & pay) | w) & valid;                          // two marks in a row; a byte above 0x7f
+        const uint32_t ev80 = not_dot & ~pay & valid;
+        acc |= (((ev80 >> 7) | (ev80 >> 14) | (ev80 >> 21) | (ev80 >> 28)) & 0xfu) << (4u * (k & 7u));
         if ((k & 7u) == 7u || k + 1 == nd) {
             s.ev[k >> 3] = acc;
             acc = 0;
