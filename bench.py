@@ -238,6 +238,114 @@ def boundary_costs(ctx, device, blob, off, lens, tasks, n):
     return out
 
 
+def boundary_compact(ctx, device, blob, off, lens, tasks, n, ref_size):
+    """The boundary as the host mapper would use it (never `value`): the suffix-array loops' compact submission form
+    (wamd_verify_sa_candidates: per read two 2-byte counts, per candidate its 4-byte suffix-array entry in, one byte
+    of errors out) for C candidates per read - each read's own S1 locus and C - 1 random ones, on the read's strand -
+    in bins of 2^19 reads, host buffers in, host buffers out.  Two rates: the bins' reads already resident, and the
+    reads of bin i + 1 uploaded by a second host thread (wamd_reads_upload_stream) beside the kernels of bin i, which is
+    what a mapper that fills the next bin while this one is verified sees."""
+    import threading
+    c = 8
+    k = K_ERR
+    fl, fr = synth.stage_segments(M, k)[1]
+    n_reads = n // c
+    bins = 4
+    per = n_reads // bins
+    rng = np.random.default_rng(1234)
+    out = {"candidates_per_read": c, "reads_per_bin": per, "bins": bins,
+           "form": "wamd_sa_batch + counts (2 x u16 per read) + SA entries (u32 per candidate) -> errors (u8 per candidate)"}
+    t = tasks[:n_reads]
+    rc = (t["flags"] & 1).astype(bool)
+    m = lens[:n_reads].astype(np.int64)
+    # the window start the S1 task has -> the suffix-array entry the loop would have had for it (mapping_core_sa.cpp:237, 289)
+    ref_pos = np.empty((n_reads, c), np.int64)
+    ref_pos[:, 0] = t["ref_pos"]
+    ref_pos[:, 1:] = rng.integers(1 << 16, ref_size - (1 << 16), (n_reads, c - 1))
+    sa = np.where(rc[:, None], ref_size - m[:, None] + fl - k - ref_pos, ref_pos + k + fl).astype(np.uint32)
+    counts = np.zeros((n_reads, 2), np.uint16)
+    counts[:, 0] = np.where(rc, 0, c)
+    counts[:, 1] = np.where(rc, c, 0)
+    p_counts, p_sa, p_err = api.PinnedBuffer(2 * n_reads, np.uint16), api.PinnedBuffer(n_reads * c, np.uint32), \
+        api.PinnedBuffer(n_reads * c, np.uint8)
+    p_counts.array[:] = counts.reshape(-1)
+    p_sa.array[:] = sa.reshape(-1)
+    o0, o1 = int(off[0]), int(off[n_reads - 1]) + (int(lens[n_reads - 1]) + 1) // 2
+    p_blob, p_off, p_lens = api.PinnedBuffer(o1 - o0 + 64, np.uint8), api.PinnedBuffer(n_reads, np.uint64), \
+        api.PinnedBuffer(n_reads, np.uint32)
+    p_blob.array[:o1 - o0] = blob[o0:o1]
+    p_lens.array[:] = lens[:n_reads]
+    bin_base = [int(off[b * per]) - o0 for b in range(bins)]
+    for b in range(bins):   # a bin's offsets count from its own first read
+        p_off.array[b * per:(b + 1) * per] = off[b * per:(b + 1) * per] - off[b * per]
+
+    def upload(b, stream=None):
+        a, e = b * per, (b + 1) * per
+        return ctx.upload_reads(p_blob.array[bin_base[b]:], p_off.array[a:e], p_lens.array[a:e], api.READS_NIBBLE,
+                                orientations=3, stream=stream)
+
+    def verify(b, reads):
+        a, e = b * per, (b + 1) * per
+        ctx.verify_sa_candidates(reads, api.sa_batch(per, k, (fl, fr), 0, api.SA_VERIFIER_DISTANCE),
+                                 p_counts.array[2 * a:2 * e], p_sa.array[a * c:e * c], errors=p_err.array[a * c:e * c])
+
+    # (1) reads resident
+    resident = [upload(b) for b in range(bins)]
+    verify(0, resident[0])                      # staging buffers and streams exist after this
+    t0 = time.perf_counter()
+    for b in range(bins):
+        verify(b, resident[b])
+    dt = time.perf_counter() - t0
+    out["host_to_host_compact_candidates_per_s"] = bins * per * c / dt
+    # parity: the task form of bin 0's candidates through the synchronous host-pointer call, clamped at k + 1
+    tt = np.zeros(per * c, api.DIST_TASK)
+    tt["read_idx"] = np.repeat(np.arange(per, dtype=np.uint32), c)
+    tt["ref_pos"] = ref_pos[:per].reshape(-1).astype(np.uint32)
+    tt["max_distance_in_ref"] = np.repeat(m[:per] + 2 * k, c)
+    tt["max_ed"] = k
+    tt["flags"] = np.repeat(rc[:per].astype(np.uint8), c)
+    want = ctx.dynamic_programming(resident[0], tt, -1)["edit_distance"]
+    out["compact_matches_task_form"] = bool((np.minimum(want, k + 1) == p_err.array[:per * c]).all())
+    out["compact_accepted_fraction"] = float((p_err.array[:per * c] <= k).mean())
+    for r in resident:
+        r.free()
+    # (2) the next bin's reads uploaded beside this bin's kernels, into one of two batches that take turns
+    # (wamd_reads_refill: after its first two bins a mapper allocates nothing)
+    up_stream = torch.cuda.Stream(device=device)
+    batch = [upload(0, up_stream.cuda_stream), upload(1, up_stream.cuda_stream)]
+
+    def refill(b):
+        a, e = b * per, (b + 1) * per
+        batch[b & 1].refill(p_blob.array[bin_base[b]:], p_off.array[a:e], p_lens.array[a:e], stream=up_stream.cuda_stream)
+
+    def pipeline():
+        refill(0)
+        for b in range(bins):
+            th = None
+            if b + 1 < bins:
+                th = threading.Thread(target=refill, args=(b + 1,))
+                th.start()
+            verify(b, batch[b & 1])
+            if th:
+                th.join()
+
+    pipeline()      # (the first pass pays for the second thread's first calls into the runtime)
+    t0 = time.perf_counter()
+    pipeline()
+    dt = time.perf_counter() - t0
+    out["host_to_host_compact_with_reads_upload_candidates_per_s"] = bins * per * c / dt
+    t0 = time.perf_counter()
+    refill(0)
+    out["reads_refill_ms_per_bin"] = (time.perf_counter() - t0) * 1e3
+    for r in batch:
+        r.free()
+    out["bytes_over_pcie_per_candidate"] = 4 + 1 + 4 / c
+    out["reads_bytes_over_pcie_per_candidate"] = float((o1 - o0 + 12 * n_reads) / (n_reads * c))
+    for b in (p_counts, p_sa, p_err, p_blob, p_off, p_lens):
+        b.free()
+    return out
+
+
 def run_extras(ctx, device, genome_symbols, stream, n_small):
     """Secondary shapes of SURVEY 8d and the rows next to the verifier on the same resident genome: one entry per
     kernel family, timed with HIP events on the context's stream (3 launches after one warm-up), each with the
@@ -1020,6 +1128,7 @@ def main():
                 out["parity_error"] = "GPU and CPU results differ on the baseline sample"
         if not args.no_boundary and world == 1:
             out["boundary"] = boundary_costs(ctx, device, blob, off, lens, tasks, n)
+            out["boundary"]["compact"] = boundary_compact(ctx, device, blob, off, lens, tasks, n, ref_size)
         if not args.no_extras and world == 1:
             del d_tasks, d_results, d_results_alt, res_bufs, last_buf, d_records, d_scratch, d_rec_pos, d_dir, d_count
             reads.free()

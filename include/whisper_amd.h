@@ -320,6 +320,16 @@ WAMD_API int wamd_ctx_take_flags(wamd_ctx* ctx, void* stream, uint32_t* flags);
 WAMD_API int wamd_reads_upload(wamd_ctx* ctx, const uint8_t* data, const uint64_t* offsets,
                                const uint32_t* lens, uint32_t n, int encoding,
                                int orientations, wamd_reads** out);
+/* The same on a stream of the caller's (NULL = the context's): the upload of the next bin's reads from a second host
+ * thread, beside the kernels of the current one.  Returns when the batch is ready (waits for that stream only). */
+WAMD_API int wamd_reads_upload_stream(wamd_ctx* ctx, const uint8_t* data, const uint64_t* offsets,
+                                      const uint32_t* lens, uint32_t n, int encoding,
+                                      int orientations, void* stream, wamd_reads** out);
+/* Re-fill an existing batch with the next bin's reads (its encoding and orientations): buffers that are large
+ * enough are kept, so a mapper that alternates between two batches allocates nothing after its first bins.  No
+ * kernel may still be reading the batch.  On failure the batch is left empty. */
+WAMD_API int wamd_reads_refill(wamd_reads* reads, const uint8_t* data, const uint64_t* offsets,
+                               const uint32_t* lens, uint32_t n, void* stream);
 WAMD_API int wamd_reads_free(wamd_reads* reads);
 WAMD_API uint32_t wamd_reads_count(const wamd_reads* reads);
 
@@ -376,6 +386,51 @@ WAMD_API int wamd_filter_verify_distance_dev(wamd_ctx* ctx, const wamd_reads* re
 WAMD_API int wamd_filter_levdiag_dev(wamd_ctx* ctx, const wamd_reads* reads, const wamd_cf_task* d_cf_tasks,
                                      const wamd_levdiag_task* d_tasks, uint32_t n, uint32_t* d_results,
                                      void* d_workspace, uint64_t workspace_bytes, void* stream);
+
+/* ---- the suffix-array loops' candidates in their compact form ---------------------------------------- *
+ * search_in_unknown_range_dir_and_rc / search_in_known_range_dir_and_rc (mapping_core_sa.cpp:193-348, 355-513) hold
+ * everything fixed inside a stage but the read and the suffix-array entry.  A batch is therefore: the stage's
+ * constants (wamd_sa_batch), per read of reads[read_first .. read_first + n_reads) how many suffix-array entries
+ * it has on the direct and on the other strand (counts[2 i], counts[2 i + 1]), and the 4-byte entries themselves,
+ * read after read, a read's direct-strand entries before its other-strand ones - the order the loops visit them.
+ * The device writes the tasks wamd_filter_verify_distance_dev / wamd_filter_levdiag_dev take (as :228-239 and
+ * :283-291 form them; ref_size is the context's) and runs those kernels.  errors[j] = cur_match as the loop goes on
+ * with it: the verifier's errors if <= max_mismatches, else max_mismatches + 1 (also for a candidate the CF
+ * pre-filter turns away); end_positions (may be NULL; distance verifier only): dynamicProgramming's end column,
+ * 0 for a rejected candidate.  4 + 1 bytes per candidate and 4 per read cross the link.
+ * min_read_len == 0: no CF pre-filter (the loops' is_short_read for every read).  The other strand's LevDiag takes
+ * the REVERSED read (reverse_read, :291): upload those behind the reads and say where in reverse_read_offset.
+ * The distance verifier runs in its accepted-only form whatever the context's mode: nothing of a rejected candidate
+ * is reported. */
+#define WAMD_SA_VERIFIER_DISTANCE 0   /* max_mismatches >= lev_alg_thr: LevMyers::dynamicProgramming */
+#define WAMD_SA_VERIFIER_LEVDIAG 1    /* below it: CEditDist::LevDiag                                */
+typedef struct wamd_sa_batch {
+    uint32_t read_first;
+    uint32_t n_reads;
+    uint32_t reverse_read_offset;   /* LevDiag: index of read i's reversed copy = i + this          */
+    uint16_t max_mismatches;
+    uint16_t fixed_left;            /* start_pos / end_pos of the stage's anchor in the direct read */
+    uint16_t fixed_right;
+    uint16_t min_read_len;
+    uint8_t verifier;               /* WAMD_SA_VERIFIER_*                                           */
+    uint8_t reserved[3];
+} wamd_sa_batch;
+
+WAMD_API uint64_t wamd_sa_candidates_workspace_bytes(uint32_t n_candidates, uint32_t n_reads);
+/* counts, sa_positions, errors 4-byte aligned; d_workspace 256-byte aligned, the caller's; nothing is allocated
+ * and nothing synchronises.  A batch whose counts do not add up to n_candidates raises flag bit 5. */
+WAMD_API int wamd_verify_sa_candidates_dev(wamd_ctx* ctx, const wamd_reads* reads, const wamd_sa_batch* batch,
+                                           const uint16_t* d_counts, const uint32_t* d_sa_positions,
+                                           uint32_t n_candidates, uint8_t* d_errors, uint32_t* d_end_positions,
+                                           void* d_workspace, uint64_t workspace_bytes, void* stream);
+/* The same from host buffers, as the mapper holds them: cut into chunks of whole reads that alternate between two
+ * streams, so that the upload of one chunk, the kernels of the previous one and the download of the one before
+ * overlap.  Buffers from wamd_host_alloc (page-locked) make the copies asynchronous; pageable ones work, slower. */
+WAMD_API int wamd_verify_sa_candidates(wamd_ctx* ctx, const wamd_reads* reads, const wamd_sa_batch* batch,
+                                       const uint16_t* counts, const uint32_t* sa_positions, uint32_t n_candidates,
+                                       uint8_t* errors, uint32_t* end_positions);
+WAMD_API int wamd_host_alloc(void** out, uint64_t bytes);   /* page-locked host memory for the calls above */
+WAMD_API int wamd_host_free(void* p);
 
 /* ---- verification with alignment (post-processing) --------------------- *
  * dynamicProgramming + getExtCigar (+ refine_ext_cigar when refine != 0) as in

@@ -767,3 +767,43 @@ def test_windows_at_the_genome_ends(oracle):
             reads.free()
     finally:
         c.destroy()
+
+
+def test_reads_refill_and_stream_upload(ctx, oracle):
+    """wamd_reads_refill: the next bin's reads in the buffers of an existing batch (larger and smaller than what it
+    held), and wamd_reads_upload_stream: the same batch built on a caller's stream - both must verify as a fresh
+    upload does."""
+    import torch
+    w1 = common.distance_workload(150, 12, 3000, seed=901)
+    w2 = common.distance_workload(100, 10, 5000, seed=902)     # more reads, shorter
+    w3 = common.distance_workload(250, 17, 700, seed=903)      # fewer reads, longer: other vector widths
+    reads = ctx.upload_reads(*w1[2], api.READS_NIBBLE)
+    for codes, packed, (blob, off, lens), tasks in (w2, w3, w1):
+        fresh = ctx.upload_reads(blob, off, lens, api.READS_NIBBLE)
+        want = ctx.dynamic_programming(fresh, tasks)
+        fresh.free()
+        reads.refill(blob, off, lens)
+        np.testing.assert_array_equal(ctx.dynamic_programming(reads, tasks), want)
+        rc, orc = oracle.distance(packed, blob, off, lens, 0, tasks, -1)
+        np.testing.assert_array_equal(want, orc)
+    reads.free()
+    st = torch.cuda.Stream()
+    codes, packed, (blob, off, lens), tasks = w3
+    r2 = ctx.upload_reads(blob, off, lens, api.READS_NIBBLE, stream=st.cuda_stream)
+    rc, orc = oracle.distance(packed, blob, off, lens, 0, tasks, -1)
+    np.testing.assert_array_equal(ctx.dynamic_programming(r2, tasks), orc)
+    # the traceback's 64-bit vectors are rebuilt for the refilled reads
+    codes, packed, (blob, off, lens), tasks = common.distance_workload(150, 13, 1500, seed=904, encoding=1, W=177)
+    r3 = ctx.upload_reads(*w1[2], api.READS_NIBBLE)
+    r3.free()
+    r3 = ctx.upload_reads(blob, off, lens, 1)
+    want = ctx.align(r3, tasks, 0, 1, cigar_stride=512)
+    codes_b, packed_b, (blob_b, off_b, lens_b), tasks_b = common.distance_workload(150, 13, 1500, seed=905, encoding=1, W=177)
+    r3.refill(blob_b, off_b, lens_b)
+    ctx.align(r3, tasks_b, 0, 1, cigar_stride=512)
+    r3.refill(blob, off, lens)
+    got = ctx.align(r3, tasks, 0, 1, cigar_stride=512)
+    np.testing.assert_array_equal(got[0], want[0])
+    assert bytes(got[1]) == bytes(want[1])
+    r2.free()
+    r3.free()

@@ -83,3 +83,94 @@ def test_device_loop_equals_the_reference_loop(name, mode):
         assert bytes(got) == bytes(z["group_bytes"])
     finally:
         ctx.destroy()
+
+
+def _compact(z):
+    """The fixture's candidates as the compact form holds them: counts per read and strand, the SA entries."""
+    nr = len(z["read_ids"])
+    rf = z["read_first"].astype(np.int64)
+    direct = z["cf"]["dir_gen_flag"].astype(np.int64)
+    counts = np.zeros((nr, 2), np.uint16)
+    for r in range(nr):
+        d = int(direct[rf[r]:rf[r + 1]].sum())
+        counts[r] = (d, rf[r + 1] - rf[r] - d)
+    return counts, z["cf"]["position"].astype(np.uint32)
+
+
+@pytest.mark.parametrize("filtered", [True, False])
+@pytest.mark.parametrize("name", gu.cases("saloop"))
+def test_compact_form_equals_the_task_form(name, filtered):
+    """wamd_verify_sa_candidates(_dev): counts + 4-byte suffix-array entries expanded to tasks on the device must give
+    what the task form gives for the tasks the fixture holds (which the test above pins to the reference's loop):
+    errors clamped at k + 1, end columns of the accepted candidates; the host-pointer pipeline the same again."""
+    z = gu.load(name)
+    k, seg, mrl = int(z["k"]), (int(z["seg"][0]), int(z["seg"][1])), int(z["min_read_len"])
+    n, nr = len(z["commit"]), len(z["read_ids"])
+    lev = k < 7
+    counts, sa = _compact(z)
+    cf = z["cf"].copy()
+    if not filtered:
+        cf["pattern_len"] = 0          # the task form's "short read": no filter
+    ctx = api.Context(z["packed"], ref_size=int(z["ref_size"]), cur_offset=seg[0])
+    try:
+        ctx.set_distance_mode(api.DISTANCE_EXACT)
+        reads = ctx.upload_reads(z["blob"], z["off"], z["lens"], api.READS_NIBBLE, orientations=3)
+        wsb = ctx.filter_verify_workspace_bytes(n)
+        d_ws = torch.zeros(wsb + 256, dtype=torch.uint8, device="cuda:0")
+        d_ws = d_ws[(-d_ws.data_ptr()) % 256:]
+        d_cf, d_lev, d_dist = dev(cf), dev(z["lev"]), dev(z["dist"])
+        d_ed = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+        d_res = torch.zeros(n * 2, dtype=torch.int32, device="cuda:0")
+        b = api.sa_batch(nr, k, seg, mrl if filtered else 0, api.SA_VERIFIER_LEVDIAG if lev else api.SA_VERIFIER_DISTANCE,
+                         reverse_read_offset=nr)
+        wsb2 = ctx.sa_candidates_workspace_bytes(n, nr)
+        d_ws2 = torch.zeros(wsb2 + 256, dtype=torch.uint8, device="cuda:0")
+        d_ws2 = d_ws2[(-d_ws2.data_ptr()) % 256:]
+        d_counts, d_sa = dev(counts), dev(sa)
+        d_err = torch.full((n + 3,), 0xEE, dtype=torch.uint8, device="cuda:0")
+        d_end = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+        torch.cuda.synchronize()
+        ts = torch.cuda.Stream()
+        st = ts.cuda_stream
+        with torch.cuda.stream(ts):
+            if lev:
+                ctx.filter_levdiag_dev(reads, d_cf, d_lev, n, d_ed, d_ws, wsb, stream=st)
+            else:
+                ctx.filter_verify_distance_dev(reads, d_cf, d_dist, n, d_res, d_ws, wsb, last_symbol=-1, stream=st)
+            ctx.verify_sa_candidates_dev(reads, b, d_counts, d_sa, n, d_err, None if lev else d_end, d_ws2, wsb2, stream=st)
+        torch.cuda.synchronize()
+        assert ctx.take_flags(st) == 0
+        if lev:
+            want_e, want_p = d_ed.cpu().numpy().view(np.uint32), None
+        else:
+            r = d_res.cpu().numpy().view(np.uint32).reshape(n, 2)
+            want_e, want_p = r[:, 0], np.where(r[:, 0] <= k, r[:, 1], 0)
+        want_e = np.minimum(want_e, k + 1).astype(np.uint8)
+        got = d_err.cpu().numpy()
+        np.testing.assert_array_equal(got[:n], want_e)
+        assert (got[n:] == 0xEE).all() and (want_e <= k).sum() > n // 10
+        if want_p is not None:
+            np.testing.assert_array_equal(d_end.cpu().numpy().view(np.uint32), want_p)
+        # host buffers (page-locked and pageable) through the chunked pipeline
+        pc, ps, pe = api.PinnedBuffer(2 * nr, np.uint16), api.PinnedBuffer(n, np.uint32), api.PinnedBuffer(n, np.uint8)
+        pc.array[:] = counts.reshape(-1)
+        ps.array[:] = sa
+        pe.array[:] = 0xEE
+        ctx.verify_sa_candidates(reads, b, pc.array, ps.array, errors=pe.array)
+        np.testing.assert_array_equal(pe.array, want_e)
+        for buf in (pc, ps, pe):
+            buf.free()
+        out = ctx.verify_sa_candidates(reads, b, counts, sa, want_positions=not lev)
+        if lev:
+            np.testing.assert_array_equal(out, want_e)
+        else:
+            np.testing.assert_array_equal(out[0], want_e)
+            np.testing.assert_array_equal(out[1], want_p)
+        # counts that do not add up are an error, on either path
+        bad = counts.copy()
+        bad[0, 0] += 1
+        with pytest.raises(api.WamdError):
+            ctx.verify_sa_candidates(reads, b, bad, sa)
+        reads.free()
+    finally:
+        ctx.destroy()

@@ -92,6 +92,39 @@ COMMIT_TASK = np.dtype([("lev_pos", "<u4"), ("lev_errors", "<u4"), ("max_mismatc
 assert COMMIT_TASK.itemsize == 16
 
 
+class SaBatch(C.Structure):
+    """wamd_sa_batch: what a stage of the suffix-array loops holds fixed (mapping_core_sa.cpp:193-348)."""
+    _fields_ = [("read_first", C.c_uint32), ("n_reads", C.c_uint32), ("reverse_read_offset", C.c_uint32),
+                ("max_mismatches", C.c_uint16), ("fixed_left", C.c_uint16), ("fixed_right", C.c_uint16),
+                ("min_read_len", C.c_uint16), ("verifier", C.c_uint8), ("reserved", C.c_uint8 * 3)]
+
+
+SA_VERIFIER_DISTANCE, SA_VERIFIER_LEVDIAG = 0, 1
+
+
+def sa_batch(n_reads, k, seg, min_read_len, verifier, read_first=0, reverse_read_offset=0):
+    b = SaBatch()
+    b.read_first, b.n_reads, b.reverse_read_offset = read_first, n_reads, reverse_read_offset
+    b.max_mismatches, b.fixed_left, b.fixed_right, b.min_read_len, b.verifier = k, seg[0], seg[1], min_read_len, verifier
+    return b
+
+
+class PinnedBuffer:
+    """Page-locked host memory from wamd_host_alloc, seen as a numpy array."""
+
+    def __init__(self, n, dtype):
+        self.p = C.c_void_p()
+        dt = np.dtype(dtype)
+        _check(lib().wamd_host_alloc(C.byref(self.p), C.c_uint64(max(1, n) * dt.itemsize)))
+        self.array = np.ctypeslib.as_array(C.cast(self.p, C.POINTER(C.c_uint8)), shape=(max(1, n) * dt.itemsize,)).view(dt)[:n]
+
+    def free(self):
+        if self.p:
+            self.array = None
+            lib().wamd_host_free(self.p)
+            self.p = None
+
+
 class GroupParams(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("id_bytes", "mapping_counter_size", "max_no_mappings", "reserved")]
 
@@ -112,6 +145,8 @@ STATUS = {0: "WAMD_OK", 1: "WAMD_ERR_INVALID_ARG", 2: "WAMD_ERR_HIP", 3: "WAMD_E
 
 EXPORTS = [
     "wamd_version", "wamd_last_error", "wamd_device_count", "wamd_ctx_create",
+    "wamd_sa_candidates_workspace_bytes", "wamd_verify_sa_candidates_dev", "wamd_verify_sa_candidates", "wamd_host_alloc",
+    "wamd_host_free", "wamd_reads_upload_stream", "wamd_reads_refill",
     "wamd_ctx_create_dev", "wamd_ctx_destroy", "wamd_ctx_set_scoring",
     "wamd_ctx_set_max_text_len", "wamd_ctx_set_distance_mode", "wamd_ctx_set_reference_params", "wamd_ctx_stream",
     "wamd_ctx_synchronize", "wamd_ctx_take_flags", "wamd_reads_upload", "wamd_reads_free",
@@ -178,6 +213,7 @@ def lib():
         L.wamd_finish_workspace_bytes.restype = C.c_uint64
         L.wamd_result_groups_workspace_bytes.restype = C.c_uint64
         L.wamd_filter_verify_workspace_bytes.restype = C.c_uint64
+        L.wamd_sa_candidates_workspace_bytes.restype = C.c_uint64
         _lib = L
     return _lib
 
@@ -197,7 +233,7 @@ def _ptr(a):
 
 
 class Reads:
-    def __init__(self, ctx, data, offsets, lens, encoding, orientations=3):
+    def __init__(self, ctx, data, offsets, lens, encoding, orientations=3, stream=None):
         self.ctx = ctx
         data = np.ascontiguousarray(data, np.uint8)
         offsets = np.ascontiguousarray(offsets, np.uint64)
@@ -206,9 +242,24 @@ class Reads:
         self.encoding = encoding
         self.max_len = int(lens.max()) if self.n else 0
         self.h = C.c_void_p()
-        _check(lib().wamd_reads_upload(ctx.h, _ptr(data), _ptr(offsets), _ptr(lens),
-                                       C.c_uint32(self.n), C.c_int(encoding),
-                                       C.c_int(orientations), C.byref(self.h)))
+        if stream is None:
+            _check(lib().wamd_reads_upload(ctx.h, _ptr(data), _ptr(offsets), _ptr(lens),
+                                           C.c_uint32(self.n), C.c_int(encoding),
+                                           C.c_int(orientations), C.byref(self.h)))
+        else:   # beside another bin's kernels: waits for `stream` only
+            _check(lib().wamd_reads_upload_stream(ctx.h, _ptr(data), _ptr(offsets), _ptr(lens),
+                                                  C.c_uint32(self.n), C.c_int(encoding),
+                                                  C.c_int(orientations), C.c_void_p(stream), C.byref(self.h)))
+
+    def refill(self, data, offsets, lens, stream=None):
+        """The next bin's reads into this batch's buffers (wamd_reads_refill)."""
+        data = np.ascontiguousarray(data, np.uint8)
+        offsets = np.ascontiguousarray(offsets, np.uint64)
+        lens = np.ascontiguousarray(lens, np.uint32)
+        self.n = len(lens)
+        self.max_len = int(lens.max()) if self.n else 0
+        _check(lib().wamd_reads_refill(self.h, _ptr(data), _ptr(offsets), _ptr(lens), C.c_uint32(self.n),
+                                       C.c_void_p(stream or 0)))
 
     def free(self):
         if self.h:
@@ -279,8 +330,8 @@ class Context:
         _check(lib().wamd_ctx_take_flags(self.h, C.c_void_p(stream or 0), C.byref(f)))
         return f.value
 
-    def upload_reads(self, data, offsets, lens, encoding, orientations=3):
-        return Reads(self, data, offsets, lens, encoding, orientations)
+    def upload_reads(self, data, offsets, lens, encoding, orientations=3, stream=None):
+        return Reads(self, data, offsets, lens, encoding, orientations, stream)
 
     # ---- host-pointer entry points ------------------------------------------------------
     def dynamic_programming(self, reads, tasks, last_symbol=LAST_SYMBOL_FROM_READ):
@@ -322,6 +373,31 @@ class Context:
         _check(lib().wamd_filter_levdiag_dev(self.h, reads.h, _ptr(d_cf_tasks), _ptr(d_tasks), C.c_uint32(n),
                                              _ptr(d_results), _ptr(d_ws), C.c_uint64(ws_bytes),
                                              C.c_void_p(stream or 0)))
+
+    def sa_candidates_workspace_bytes(self, n_candidates, n_reads):
+        return int(lib().wamd_sa_candidates_workspace_bytes(C.c_uint32(n_candidates), C.c_uint32(n_reads)))
+
+    def verify_sa_candidates_dev(self, reads, batch, d_counts, d_positions, n, d_errors, d_end_positions, d_ws, ws_bytes,
+                                 stream=None):
+        """The suffix-array loops' candidates in their compact form (mapping_core_sa.cpp:193-348): counts per read and
+        strand, 4-byte suffix-array entries; one byte of errors per candidate."""
+        _check(lib().wamd_verify_sa_candidates_dev(self.h, reads.h, C.byref(batch), _ptr(d_counts), _ptr(d_positions),
+                                                   C.c_uint32(n), _ptr(d_errors),
+                                                   _ptr(d_end_positions) if d_end_positions is not None else None,
+                                                   _ptr(d_ws), C.c_uint64(ws_bytes), C.c_void_p(stream or 0)))
+
+    def verify_sa_candidates(self, reads, batch, counts, positions, errors=None, end_positions=None, want_positions=False):
+        """Host buffers in, host buffers out: the chunked two-stream pipeline of wamd_verify_sa_candidates."""
+        counts = np.ascontiguousarray(counts, np.uint16)
+        positions = np.ascontiguousarray(positions, np.uint32)
+        n = len(positions)
+        if errors is None:
+            errors = np.zeros(n, np.uint8)
+        if end_positions is None and want_positions:
+            end_positions = np.zeros(n, np.uint32)
+        _check(lib().wamd_verify_sa_candidates(self.h, reads.h, C.byref(batch), _ptr(counts), _ptr(positions), C.c_uint32(n),
+                                               _ptr(errors), _ptr(end_positions) if end_positions is not None else None))
+        return (errors, end_positions) if end_positions is not None else errors
 
     def align(self, reads, tasks, last_symbol=0, refine=1, cigar_stride=1024):
         tasks = np.ascontiguousarray(tasks, DIST_TASK)

@@ -299,7 +299,8 @@ uint64_t filter_verify_workspace_bytes(uint32_t n)
 }
 
 int launch_filter_distance(wamd_ctx* ctx, const wamd_reads* r, const wamd_cf_task* d_cf, const wamd_dist_task* d_tasks,
-                           uint32_t n, int last_symbol, wamd_dist_result* d_results, void* d_ws, hipStream_t s)
+                           uint32_t n, int last_symbol, wamd_dist_result* d_results, void* d_ws, hipStream_t s,
+                           int distance_mode)
 {
     WAMD_HIP(hipSetDevice(ctx->device));
     if (n == 0)
@@ -316,7 +317,7 @@ int launch_filter_distance(wamd_ctx* ctx, const wamd_reads* r, const wamd_cf_tas
                        r->view(), d_cf, d_tasks, n, ctx->ref_size, ctx->cur_offset, d_results, p_tasks, p_idx, count,
                        ctx->d_flags);
     WAMD_HIP(hipGetLastError());
-    const int rc = launch_distance(ctx, r, p_tasks, n, last_symbol, p_res, ctx->distance_mode, s, count);
+    const int rc = launch_distance(ctx, r, p_tasks, n, last_symbol, p_res, distance_mode < 0 ? ctx->distance_mode : distance_mode, s, count);
     if (rc)
         return rc;
     hipLaunchKernelGGL((filter_unpack_kernel<wamd_dist_result>), dim3(blocks), dim3(256), 0, s, p_res, p_idx, count, d_results);

@@ -279,11 +279,93 @@ __global__ __launch_bounds__(256) void pattern_vectors32_kernel(ReadsView rv, ui
     *dst = make_uint4(row[0], row[1], row[2], row[3]);
 }
 
+// ---- where every read's codes start: an exclusive scan of the reads' code bytes, on the device --------------------
+// (a host loop that fills 8 bytes per read and sends them was a third of an upload's time)
+__device__ __forceinline__ uint32_t code_bytes_of(uint32_t len) { return ((len + 1) / 2 + 3) / 4 * 4; }
+
+__global__ __launch_bounds__(256) void code_off_sums_kernel(uint32_t n, const uint32_t* __restrict__ lens,
+                                                            uint64_t* __restrict__ sums)
+{
+    __shared__ uint32_t w[4];
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    uint32_t x = i < n ? code_bytes_of(lens[i]) : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        x += __shfl_xor((int)x, o);
+    if ((threadIdx.x & 63) == 0)
+        w[threadIdx.x >> 6] = x;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        sums[blockIdx.x] = (uint64_t)w[0] + w[1] + w[2] + w[3];
+}
+
+__global__ __launch_bounds__(1024) void code_off_scan_kernel(uint32_t nb, uint64_t* __restrict__ sums)
+{
+    __shared__ uint64_t part[1024];
+    const uint32_t t = threadIdx.x;
+    const uint32_t per = (nb + 1023) / 1024;
+    const uint32_t lo = t * per, hi = min(nb, lo + per);
+    uint64_t s = 0;
+    for (uint32_t i = lo; i < hi; ++i)
+        s += sums[i];
+    part[t] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        const uint64_t v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint64_t run = t ? part[t - 1] : 0;
+    for (uint32_t i = lo; i < hi; ++i) {
+        const uint64_t c = sums[i];
+        sums[i] = run;
+        run += c;
+    }
+}
+
+__global__ __launch_bounds__(256) void code_off_spread_kernel(uint32_t n, const uint32_t* __restrict__ lens,
+                                                              const uint64_t* __restrict__ sums,
+                                                              uint64_t* __restrict__ code_off)
+{
+    __shared__ uint32_t w[4];
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t mine = i < n ? code_bytes_of(lens[i]) : 0;
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
+        if (lane >= (uint32_t)d)
+            incl += o;
+    }
+    if (lane == 63)
+        w[wave] = incl;
+    __syncthreads();
+    uint64_t base = sums[blockIdx.x];
+    for (uint32_t q = 0; q < wave; ++q)
+        base += w[q];
+    if (i < n)
+        code_off[i] = base + incl - mine;
+    if (i + 1 == n)
+        code_off[n] = base + incl;
+}
+
 int launch_reads_prepare(wamd_ctx* ctx, wamd_reads* r, const uint8_t* d_raw,
                          const uint64_t* d_raw_off, hipStream_t s)
 {
     (void)ctx;
     const uint32_t dwords_per_read = ((r->max_len + 1) / 2 + 3) / 4;
+    {   // d_meta (4 bytes per read and orientation) lends its front to the block sums; it is cleared afterwards
+        const uint32_t nb = (r->n + 255) / 256;
+        uint64_t* sums = reinterpret_cast<uint64_t*>(r->d_meta);
+        hipLaunchKernelGGL(code_off_sums_kernel, dim3(nb), dim3(256), 0, s, r->n, r->d_lens, sums);
+        hipLaunchKernelGGL(code_off_scan_kernel, dim3(1), dim3(1024), 0, s, nb, sums);
+        hipLaunchKernelGGL(code_off_spread_kernel, dim3(nb), dim3(256), 0, s, r->n, r->d_lens, sums, r->d_code_off);
+        WAMD_HIP(hipGetLastError());
+        const uint32_t n_orient = r->orientations == 3 ? 2 : 1;
+        WAMD_HIP(hipMemsetAsync(r->d_meta, 0, (size_t)r->n * n_orient * sizeof(uint32_t), s));
+    }
     {
         const uint64_t threads = (uint64_t)r->n * ((dwords_per_read + 3) / 4);
         const uint32_t blocks = (uint32_t)((threads + 255) / 256);

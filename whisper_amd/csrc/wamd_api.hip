@@ -274,6 +274,9 @@ int wamd_ctx_destroy(wamd_ctx* c)
         (void)hipFree(c->d_stage);
     if (c->h_stage)
         (void)hipHostFree(c->h_stage);
+    for (hipStream_t ps : c->pipe)
+        if (ps)
+            (void)hipStreamDestroy(ps);
     if (c->stream)
         (void)hipStreamDestroy(c->stream);
     delete c;
@@ -344,9 +347,57 @@ int wamd_ctx_take_flags(wamd_ctx* ctx, void* stream, uint32_t* flags)
 
 // ---- reads -----------------------------------------------------------------------
 
+static int reads_upload_on(wamd_ctx* ctx, const uint8_t* data, const uint64_t* offsets, const uint32_t* lens, uint32_t n,
+                           int encoding, int orientations, hipStream_t s, wamd_reads* reuse, wamd_reads** out);
+
 int wamd_reads_upload(wamd_ctx* ctx, const uint8_t* data, const uint64_t* offsets,
                       const uint32_t* lens, uint32_t n, int encoding, int orientations,
                       wamd_reads** out)
+{
+    if (out)
+        *out = nullptr;
+    return reads_upload_on(ctx, data, offsets, lens, n, encoding, orientations, ctx ? ctx->stream : nullptr, nullptr, out);
+}
+
+int wamd_reads_upload_stream(wamd_ctx* ctx, const uint8_t* data, const uint64_t* offsets, const uint32_t* lens, uint32_t n,
+                             int encoding, int orientations, void* stream, wamd_reads** out)
+{
+    if (out)
+        *out = nullptr;
+    return reads_upload_on(ctx, data, offsets, lens, n, encoding, orientations,
+                           ctx && !stream ? ctx->stream : (hipStream_t)stream, nullptr, out);
+}
+
+int wamd_reads_refill(wamd_reads* reads, const uint8_t* data, const uint64_t* offsets, const uint32_t* lens, uint32_t n,
+                      void* stream)
+{
+    if (!reads) {
+        set_error("wamd_reads_refill: null batch");
+        return WAMD_ERR_INVALID_ARG;
+    }
+    wamd_reads* same = nullptr;
+    return reads_upload_on(reads->ctx, data, offsets, lens, n, reads->encoding, reads->orientations,
+                           stream ? (hipStream_t)stream : reads->ctx->stream, reads, &same);
+}
+
+// device buffer of at least `want` bytes; an existing one that is large enough stays (a refill allocates nothing)
+static hipError_t reads_buffer(void** p, uint64_t* cap, uint64_t want, bool generous)
+{
+    if (*p && *cap >= want)
+        return hipSuccess;
+    if (*p)
+        (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    const uint64_t take = generous ? want + want / 8 : want;
+    const hipError_t e = hipMalloc(p, take);
+    if (e == hipSuccess)
+        *cap = take;
+    return e;
+}
+
+static int reads_upload_on(wamd_ctx* ctx, const uint8_t* data, const uint64_t* offsets, const uint32_t* lens, uint32_t n,
+                           int encoding, int orientations, hipStream_t s, wamd_reads* reuse, wamd_reads** out)
 {
     if (!ctx || !out || (n && (!data || !offsets || !lens)) ||
         (encoding != WAMD_READS_NIBBLE && encoding != WAMD_READS_ASCII) || orientations < 1 ||
@@ -354,28 +405,34 @@ int wamd_reads_upload(wamd_ctx* ctx, const uint8_t* data, const uint64_t* offset
         set_error("wamd_reads_upload: bad argument");
         return WAMD_ERR_INVALID_ARG;
     }
-    *out = nullptr;
     WAMD_HIP(hipSetDevice(ctx->device));
 
     uint32_t max_len = 0;
     uint64_t raw_end = 0;
-    std::vector<uint64_t> code_off((size_t)n + 1);
-    uint64_t acc = 0;
-    for (uint32_t i = 0; i < n; ++i) {
-        if (lens[i] == 0 || lens[i] > WAMD_MAX_READ_LEN) {
-            set_error("read %u has length %u (allowed 1..%u)", i, lens[i], WAMD_MAX_READ_LEN);
-            return WAMD_ERR_TOO_LONG;
-        }
-        max_len = lens[i] > max_len ? lens[i] : max_len;
-        uint64_t raw_bytes = encoding == WAMD_READS_NIBBLE ? (lens[i] + 1) / 2 : lens[i];
-        raw_end = offsets[i] + raw_bytes > raw_end ? offsets[i] + raw_bytes : raw_end;
-        code_off[i] = acc;
-        acc += ((uint64_t)(lens[i] + 1) / 2 + 3) / 4 * 4;
+    uint64_t acc = 0;     // bytes of all reads' codes (where each read's start: a scan on the device)
+    uint32_t min_len = n ? 0xffffffffu : 1u;
+    const uint32_t nib = encoding == WAMD_READS_NIBBLE ? 1u : 0u;
+    for (uint32_t i = 0; i < n; ++i) {     // (no early exit: the loop vectorises)
+        const uint32_t len = lens[i];
+        max_len = len > max_len ? len : max_len;
+        min_len = len < min_len ? len : min_len;
+        const uint64_t end = offsets[i] + (nib ? (len + 1) / 2 : len);
+        raw_end = end > raw_end ? end : raw_end;
+        acc += ((uint64_t)(len + 1) / 2 + 3) / 4 * 4;
     }
-    code_off[n] = acc;
+    if (min_len == 0 || max_len > WAMD_MAX_READ_LEN) {
+        uint32_t i = 0;
+        while (i < n && lens[i] != 0 && lens[i] <= WAMD_MAX_READ_LEN)
+            ++i;
+        set_error("read %u has length %u (allowed 1..%u)", i, i < n ? lens[i] : 0u, WAMD_MAX_READ_LEN);
+        return WAMD_ERR_TOO_LONG;
+    }
 
-    wamd_reads* r = new wamd_reads();
-    memset(r, 0, sizeof(*r));
+    wamd_reads* r = reuse;
+    if (!r) {
+        r = new wamd_reads();
+        memset(r, 0, sizeof(*r));
+    }
     r->ctx = ctx;
     r->n = n;
     r->encoding = encoding;
@@ -385,45 +442,42 @@ int wamd_reads_upload(wamd_ctx* ctx, const uint8_t* data, const uint64_t* offset
     r->words32 = max_len ? (max_len - 1) / 32 + 1 : 1;
     r->pm32_stride = r->words32 <= 4 ? (r->words32 <= 2 ? r->words32 : 4u) : (r->words32 + 7u) / 8u * 8u;
     r->codes_bytes = acc;
+    r->pm_state = 0;     // the 64-bit pattern vectors belong to the reads that were here before
     const uint32_t n_orient = orientations == 3 ? 2 : 1;
     int rc = WAMD_OK;
-    uint8_t* d_raw = nullptr;
-    uint64_t* d_raw_off = nullptr;
     do {
         hipError_t e;
-        hipStream_t s = ctx->stream;
+        const bool gen = reuse != nullptr;
         const uint64_t pm_bytes = (uint64_t)n * n_orient * 4 * r->words * sizeof(uint64_t);
         const uint64_t pm32_bytes = (uint64_t)n * n_orient * 4 * r->pm32_stride * sizeof(uint32_t);
-        if ((e = hipMalloc(&r->d_codes, acc + 64)) != hipSuccess ||
-            (e = hipMalloc(&r->d_code_off, ((size_t)n + 1) * sizeof(uint64_t))) != hipSuccess ||
-            (e = hipMalloc(&r->d_lens, ((size_t)n + 1) * sizeof(uint32_t))) != hipSuccess ||
-            (e = hipMalloc(&r->d_pm, pm_bytes + 64)) != hipSuccess ||
-            (e = hipMalloc(&r->d_pm32, pm32_bytes + 64)) != hipSuccess ||
-            (e = hipMalloc(&r->d_meta, ((size_t)n * n_orient + 1) * sizeof(uint32_t))) != hipSuccess ||
-            (e = hipMalloc(&d_raw, raw_end + 64)) != hipSuccess ||
-            (e = hipMalloc(&d_raw_off, ((size_t)n + 1) * sizeof(uint64_t))) != hipSuccess) {
+        // (the raw reads stay with the batch until it is freed: releasing device memory waits for the whole device,
+        //  and an upload that runs beside another bin's kernels must not)
+        if ((e = reads_buffer((void**)&r->d_codes, &r->cap[0], acc + 64, gen)) != hipSuccess ||
+            (e = reads_buffer((void**)&r->d_code_off, &r->cap[1], ((uint64_t)n + 1) * sizeof(uint64_t), gen)) != hipSuccess ||
+            (e = reads_buffer((void**)&r->d_lens, &r->cap[2], ((uint64_t)n + 1) * sizeof(uint32_t), gen)) != hipSuccess ||
+            (e = reads_buffer((void**)&r->d_pm, &r->cap[3], pm_bytes + 64, gen)) != hipSuccess ||
+            (e = reads_buffer((void**)&r->d_pm32, &r->cap[4], pm32_bytes + 64, gen)) != hipSuccess ||
+            (e = reads_buffer((void**)&r->d_meta, &r->cap[5], ((uint64_t)n * n_orient + 1) * sizeof(uint32_t), gen)) != hipSuccess ||
+            (e = reads_buffer((void**)&r->d_raw, &r->cap[6], raw_end + 64, gen)) != hipSuccess ||
+            (e = reads_buffer((void**)&r->d_raw_off, &r->cap[7], ((uint64_t)n + 1) * sizeof(uint64_t), gen)) != hipSuccess) {
             rc = hip_fail(e, "hipMalloc(reads)", __FILE__, __LINE__);
             break;
         }
-        if ((e = hipEventCreateWithFlags(&r->pm_event, hipEventDisableTiming)) != hipSuccess) {
+        if (!r->pm_event && (e = hipEventCreateWithFlags(&r->pm_event, hipEventDisableTiming)) != hipSuccess) {
             rc = hip_fail(e, "hipEventCreate(reads)", __FILE__, __LINE__);
             break;
         }
         if (n == 0)
             break;
-        if ((e = hipMemcpyAsync(d_raw, data, raw_end, hipMemcpyHostToDevice, s)) != hipSuccess ||
-            (e = hipMemcpyAsync(d_raw_off, offsets, (size_t)n * sizeof(uint64_t),
-                                hipMemcpyHostToDevice, s)) != hipSuccess ||
-            (e = hipMemcpyAsync(r->d_code_off, code_off.data(), ((size_t)n + 1) * sizeof(uint64_t),
+        if ((e = hipMemcpyAsync(r->d_raw, data, raw_end, hipMemcpyHostToDevice, s)) != hipSuccess ||
+            (e = hipMemcpyAsync(r->d_raw_off, offsets, (size_t)n * sizeof(uint64_t),
                                 hipMemcpyHostToDevice, s)) != hipSuccess ||
             (e = hipMemcpyAsync(r->d_lens, lens, (size_t)n * sizeof(uint32_t),
-                                hipMemcpyHostToDevice, s)) != hipSuccess ||
-            (e = hipMemsetAsync(r->d_meta, 0, (size_t)n * n_orient * sizeof(uint32_t), s)) !=
-                hipSuccess) {
+                                hipMemcpyHostToDevice, s)) != hipSuccess) {
             rc = hip_fail(e, "reads upload", __FILE__, __LINE__);
             break;
         }
-        rc = launch_reads_prepare(ctx, r, d_raw, d_raw_off, s);
+        rc = launch_reads_prepare(ctx, r, r->d_raw, r->d_raw_off, s);
         if (rc != WAMD_OK)
             break;
         if ((e = hipStreamSynchronize(s)) != hipSuccess) {
@@ -431,12 +485,11 @@ int wamd_reads_upload(wamd_ctx* ctx, const uint8_t* data, const uint64_t* offset
             break;
         }
     } while (0);
-    if (d_raw)
-        (void)hipFree(d_raw);
-    if (d_raw_off)
-        (void)hipFree(d_raw_off);
     if (rc != WAMD_OK) {
-        wamd_reads_free(r);
+        if (!reuse)
+            wamd_reads_free(r);
+        else
+            r->n = 0;     // the batch stays the caller's, empty
         return rc;
     }
     *out = r;
@@ -454,6 +507,8 @@ int wamd_reads_free(wamd_reads* r)
     if (r->d_pm) (void)hipFree(r->d_pm);
     if (r->d_pm32) (void)hipFree(r->d_pm32);
     if (r->d_meta) (void)hipFree(r->d_meta);
+    if (r->d_raw) (void)hipFree(r->d_raw);
+    if (r->d_raw_off) (void)hipFree(r->d_raw_off);
     if (r->pm_event) (void)hipEventDestroy(r->pm_event);
     delete r;
     return WAMD_OK;
@@ -638,6 +693,138 @@ int wamd_filter_levdiag_dev(wamd_ctx* ctx, const wamd_reads* reads, const wamd_c
         return rc;
     return launch_filter_levdiag(ctx, reads, d_cf_tasks, d_tasks, n, d_results, d_workspace,
                                  stream ? (hipStream_t)stream : ctx->stream);
+}
+
+uint64_t wamd_sa_candidates_workspace_bytes(uint32_t n_candidates, uint32_t n_reads)
+{
+    return sa_candidates_workspace_bytes(n_candidates, n_reads);
+}
+
+static int check_sa_batch(wamd_ctx* ctx, const wamd_reads* reads, const wamd_sa_batch* b, const void* counts,
+                          const void* positions, const void* errors, const char* who)
+{
+    int rc = check_batch(ctx, reads, counts, positions, who);
+    if (rc)
+        return rc;
+    if (!b || !errors || (((uintptr_t)counts | (uintptr_t)positions | (uintptr_t)errors) & 3u)) {
+        set_error("%s: null batch or output, or counts / positions / errors not 4-byte aligned", who);
+        return WAMD_ERR_INVALID_ARG;
+    }
+    if (b->verifier > WAMD_SA_VERIFIER_LEVDIAG || b->fixed_left >= b->fixed_right ||
+        (b->min_read_len && b->fixed_right > b->min_read_len) || b->max_mismatches > 254 ||
+        (uint64_t)b->read_first + b->n_reads > reads->n) {
+        set_error("%s: bad verifier, anchor [%u, %u) outside min_read_len %u, max_mismatches %u above 254, or reads "
+                  "[%u, +%u) beyond the %u uploaded", who, b->fixed_left, b->fixed_right, b->min_read_len,
+                  b->max_mismatches, b->read_first, b->n_reads, reads->n);
+        return WAMD_ERR_INVALID_ARG;
+    }
+    return WAMD_OK;
+}
+
+int wamd_verify_sa_candidates_dev(wamd_ctx* ctx, const wamd_reads* reads, const wamd_sa_batch* batch,
+                                  const uint16_t* d_counts, const uint32_t* d_sa_positions, uint32_t n_candidates,
+                                  uint8_t* d_errors, uint32_t* d_end_positions, void* d_workspace,
+                                  uint64_t workspace_bytes, void* stream)
+{
+    if (n_candidates == 0)
+        return WAMD_OK;
+    int rc = check_sa_batch(ctx, reads, batch, d_counts, d_sa_positions, d_errors, "wamd_verify_sa_candidates_dev");
+    if (rc)
+        return rc;
+    if (!d_workspace || ((uintptr_t)d_workspace & 255u) ||
+        workspace_bytes < sa_candidates_workspace_bytes(n_candidates, batch->n_reads)) {
+        set_error("wamd_verify_sa_candidates_dev: workspace missing, not 256-byte aligned or below "
+                  "wamd_sa_candidates_workspace_bytes(%u, %u)", n_candidates, batch->n_reads);
+        return WAMD_ERR_INVALID_ARG;
+    }
+    return launch_sa_candidates(ctx, reads, batch, d_counts, d_sa_positions, n_candidates, d_errors, d_end_positions,
+                                d_workspace, stream ? (hipStream_t)stream : ctx->stream);
+}
+
+int wamd_verify_sa_candidates(wamd_ctx* ctx, const wamd_reads* reads, const wamd_sa_batch* batch, const uint16_t* counts,
+                              const uint32_t* sa_positions, uint32_t n_candidates, uint8_t* errors, uint32_t* end_positions)
+{
+    if (n_candidates == 0)
+        return WAMD_OK;
+    int rc = check_sa_batch(ctx, reads, batch, counts, sa_positions, errors, "wamd_verify_sa_candidates");
+    if (rc)
+        return rc;
+    WAMD_HIP(hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> hold(ctx->host_mutex);
+    for (hipStream_t& ps : ctx->pipe)
+        if (!ps)
+            WAMD_HIP(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
+    // chunks of whole reads: about 1 M candidates, at most 1 M reads
+    constexpr uint32_t CHUNK_C = 1u << 20, CHUNK_R = 1u << 20, CMAX = CHUNK_C + 2u * 65535u;
+    auto up = [](uint64_t x) { return (x + 255) / 256 * 256; };
+    const uint32_t cmax = n_candidates < CMAX ? n_candidates : CMAX;
+    const uint32_t rmax = batch->n_reads < CHUNK_R ? batch->n_reads : CHUNK_R;
+    const uint64_t o_counts = 0, o_pos = o_counts + up((uint64_t)rmax * 4), o_err = o_pos + up((uint64_t)cmax * 4),
+                   o_end = o_err + up(cmax), o_ws = o_end + (end_positions ? up((uint64_t)cmax * 4) : 0),
+                   slot_bytes = o_ws + up(sa_candidates_workspace_bytes(cmax, rmax));
+    rc = ensure_stage(ctx, 2 * slot_bytes, 0);
+    if (rc)
+        return rc;
+    uint32_t r0 = 0, c0 = 0, chunk = 0;
+    uint64_t seen = 0;
+    while (r0 < batch->n_reads) {
+        uint32_t r1 = r0, c = 0;
+        while (r1 < batch->n_reads && r1 - r0 < CHUNK_R && c < CHUNK_C) {
+            c += (uint32_t)counts[2 * (uint64_t)r1] + counts[2 * (uint64_t)r1 + 1];
+            ++r1;
+        }
+        seen += c;
+        if (seen > n_candidates)
+            break;
+        if (c) {
+            char* slot = (char*)ctx->d_stage + (uint64_t)(chunk & 1u) * slot_bytes;
+            hipStream_t st = ctx->pipe[chunk & 1u];
+            wamd_sa_batch b = *batch;
+            b.read_first = batch->read_first + r0;
+            b.n_reads = r1 - r0;
+            WAMD_HIP(hipMemcpyAsync(slot + o_counts, counts + 2 * (uint64_t)r0, (uint64_t)(r1 - r0) * 4, hipMemcpyHostToDevice, st));
+            WAMD_HIP(hipMemcpyAsync(slot + o_pos, sa_positions + c0, (uint64_t)c * 4, hipMemcpyHostToDevice, st));
+            rc = launch_sa_candidates(ctx, reads, &b, (const uint16_t*)(slot + o_counts), (const uint32_t*)(slot + o_pos), c,
+                                      (uint8_t*)(slot + o_err), end_positions ? (uint32_t*)(slot + o_end) : nullptr,
+                                      slot + o_ws, st);
+            if (rc)
+                break;
+            WAMD_HIP(hipMemcpyAsync(errors + c0, slot + o_err, c, hipMemcpyDeviceToHost, st));
+            if (end_positions)
+                WAMD_HIP(hipMemcpyAsync(end_positions + c0, slot + o_end, (uint64_t)c * 4, hipMemcpyDeviceToHost, st));
+            ++chunk;
+        }
+        r0 = r1;
+        c0 += c;
+    }
+    for (hipStream_t ps : ctx->pipe)
+        WAMD_HIP(hipStreamSynchronize(ps));
+    if (rc)
+        return rc;
+    if (seen != n_candidates) {
+        set_error("wamd_verify_sa_candidates: the counts add up to %llu candidates, the call says %u",
+                  (unsigned long long)seen, n_candidates);
+        return WAMD_ERR_INVALID_ARG;
+    }
+    uint32_t flags = 0;
+    rc = fetch_flags(ctx, ctx->stream, &flags);
+    return rc ? rc : flags_to_status(flags);
+}
+
+int wamd_host_alloc(void** out, uint64_t bytes)
+{
+    if (!out)
+        return WAMD_ERR_INVALID_ARG;
+    *out = nullptr;
+    WAMD_HIP(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return WAMD_OK;
+}
+
+int wamd_host_free(void* p)
+{
+    if (p)
+        WAMD_HIP(hipHostFree(p));
+    return WAMD_OK;
 }
 
 uint64_t wamd_align_workspace_bytes(const wamd_reads* reads, uint32_t n)

@@ -93,6 +93,7 @@ struct wamd_ctx {
     uint64_t d_stage_bytes;
     void* h_stage;
     uint64_t h_stage_bytes;
+    hipStream_t pipe[2];        // wamd_verify_sa_candidates: chunks alternate between these (created at first use)
     // Host-pointer entry points share d_stage, h_flags and `stream`: each of them holds this lock
     // from its first use of the staging buffer to its last read of the results, so worker threads
     // that flush on one shared context are serialised, never interleaved.
@@ -114,6 +115,9 @@ struct wamd_reads {
     uint32_t words32;
     uint32_t pm32_stride;
     uint32_t* d_meta;
+    uint8_t* d_raw;             // the reads as uploaded (read by the prepare kernels only; kept until the batch is freed)
+    uint64_t* d_raw_off;
+    uint64_t cap[8];            // bytes behind d_codes, d_code_off, d_lens, d_pm, d_pm32, d_meta, d_raw, d_raw_off
     uint64_t codes_bytes;
     // the 64-bit pattern vectors are only read by the traceback's wide classes: built by the first
     // wamd_align call on the batch (ensure_pm), on its stream; other streams wait for pm_event
@@ -178,7 +182,12 @@ int launch_cf_filter(wamd_ctx* ctx, const wamd_reads* r, const wamd_cf_task* d_t
 
 uint64_t filter_verify_workspace_bytes(uint32_t n);
 int launch_filter_distance(wamd_ctx* ctx, const wamd_reads* r, const wamd_cf_task* d_cf, const wamd_dist_task* d_tasks,
-                           uint32_t n, int last_symbol, wamd_dist_result* d_results, void* d_ws, hipStream_t s);
+                           uint32_t n, int last_symbol, wamd_dist_result* d_results, void* d_ws, hipStream_t s,
+                           int distance_mode = -1);   // -1: the context's
+uint64_t sa_candidates_workspace_bytes(uint32_t n, uint32_t n_reads);
+int launch_sa_candidates(wamd_ctx* ctx, const wamd_reads* r, const wamd_sa_batch* b, const uint16_t* d_counts,
+                         const uint32_t* d_sa_positions, uint32_t n, uint8_t* d_errors, uint32_t* d_end_positions,
+                         void* d_ws, hipStream_t s);
 int launch_filter_levdiag(wamd_ctx* ctx, const wamd_reads* r, const wamd_cf_task* d_cf, const wamd_levdiag_task* d_tasks,
                           uint32_t n, uint32_t* d_results, void* d_ws, hipStream_t s);
 
