@@ -401,7 +401,9 @@ WAMD_API int wamd_filter_levdiag_dev(wamd_ctx* ctx, const wamd_reads* reads, con
  * min_read_len == 0: no CF pre-filter (the loops' is_short_read for every read).  The other strand's LevDiag takes
  * the REVERSED read (reverse_read, :291): upload those behind the reads and say where in reverse_read_offset.
  * The distance verifier runs in its accepted-only form whatever the context's mode: nothing of a rejected candidate
- * is reported. */
+ * is reported.  read_max_mismatches (may be NULL): one byte per read replacing batch->max_mismatches for that read's
+ * candidates - mapping_mode second verifies with min(stage, best_error + 1) (mapping_core.cpp:955-956); the verifier
+ * stays the batch's, so a caller sorts its reads by "k >= lev_alg_thr" into two batches. */
 #define WAMD_SA_VERIFIER_DISTANCE 0   /* max_mismatches >= lev_alg_thr: LevMyers::dynamicProgramming */
 #define WAMD_SA_VERIFIER_LEVDIAG 1    /* below it: CEditDist::LevDiag                                */
 typedef struct wamd_sa_batch {
@@ -420,14 +422,16 @@ WAMD_API uint64_t wamd_sa_candidates_workspace_bytes(uint32_t n_candidates, uint
 /* counts, sa_positions, errors 4-byte aligned; d_workspace 256-byte aligned, the caller's; nothing is allocated
  * and nothing synchronises.  A batch whose counts do not add up to n_candidates raises flag bit 5. */
 WAMD_API int wamd_verify_sa_candidates_dev(wamd_ctx* ctx, const wamd_reads* reads, const wamd_sa_batch* batch,
-                                           const uint16_t* d_counts, const uint32_t* d_sa_positions,
+                                           const uint16_t* d_counts, const uint8_t* d_read_max_mismatches,
+                                           const uint32_t* d_sa_positions,
                                            uint32_t n_candidates, uint8_t* d_errors, uint32_t* d_end_positions,
                                            void* d_workspace, uint64_t workspace_bytes, void* stream);
 /* The same from host buffers, as the mapper holds them: cut into chunks of whole reads that alternate between two
  * streams, so that the upload of one chunk, the kernels of the previous one and the download of the one before
  * overlap.  Buffers from wamd_host_alloc (page-locked) make the copies asynchronous; pageable ones work, slower. */
 WAMD_API int wamd_verify_sa_candidates(wamd_ctx* ctx, const wamd_reads* reads, const wamd_sa_batch* batch,
-                                       const uint16_t* counts, const uint32_t* sa_positions, uint32_t n_candidates,
+                                       const uint16_t* counts, const uint8_t* read_max_mismatches,
+                                       const uint32_t* sa_positions, uint32_t n_candidates,
                                        uint8_t* errors, uint32_t* end_positions);
 WAMD_API int wamd_host_alloc(void** out, uint64_t bytes);   /* page-locked host memory for the calls above */
 WAMD_API int wamd_host_free(void* p);

@@ -804,6 +804,8 @@ def test_reads_refill_and_stream_upload(ctx, oracle):
     r3.refill(blob, off, lens)
     got = ctx.align(r3, tasks, 0, 1, cigar_stride=512)
     np.testing.assert_array_equal(got[0], want[0])
-    assert bytes(got[1]) == bytes(want[1])
+    for i in np.nonzero(want[0]["ok"])[0]:
+        e = want[0]["cigar_len"][i] + 1
+        assert bytes(got[1][i, :e]) == bytes(want[1][i, :e]), i
     r2.free()
     r3.free()

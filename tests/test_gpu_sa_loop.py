@@ -166,6 +166,27 @@ def test_compact_form_equals_the_task_form(name, filtered):
         else:
             np.testing.assert_array_equal(out[0], want_e)
             np.testing.assert_array_equal(out[1], want_p)
+        # mapping_mode second: every read verifies with its own k = min(stage, best_error + 1) (mapping_core.cpp:955-956)
+        rng = np.random.default_rng(3)
+        read_k = rng.integers(max(1, k - 4) if lev else max(7, k - 5), k + 1, nr).astype(np.uint8)
+        per_cand = np.repeat(read_k, counts.sum(axis=1).astype(np.int64))
+        lev_t, dist_t = z["lev"].copy(), z["dist"].copy()
+        lev_t["max_mismatches"] = per_cand
+        dist_t["max_ed"] = per_cand
+        d_lev2, d_dist2 = dev(lev_t), dev(dist_t)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(ts):
+            if lev:
+                ctx.filter_levdiag_dev(reads, d_cf, d_lev2, n, d_ed, d_ws, wsb, stream=st)
+            else:
+                ctx.filter_verify_distance_dev(reads, d_cf, d_dist2, n, d_res, d_ws, wsb, last_symbol=-1, stream=st)
+        torch.cuda.synchronize()
+        assert ctx.take_flags(st) == 0
+        e2 = d_ed.cpu().numpy().view(np.uint32) if lev else d_res.cpu().numpy().view(np.uint32).reshape(n, 2)[:, 0]
+        want2 = np.where(e2 <= per_cand, e2, per_cand.astype(np.uint32) + 1).astype(np.uint8)
+        got2 = ctx.verify_sa_candidates(reads, b, counts, sa, read_k=read_k)
+        np.testing.assert_array_equal(got2, want2)
+        assert (want2 != want_e).any()
         # counts that do not add up are an error, on either path
         bad = counts.copy()
         bad[0, 0] += 1

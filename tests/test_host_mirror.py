@@ -181,3 +181,59 @@ def test_integration_patch_compiles():
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0, r.stdout
     assert r.stdout.count("compiles") == 3
+
+
+def _bin_expected(oracle, z, per_cand_k):
+    """What the loop body leaves in cur_match for every candidate of a saloop fixture (mapping_core_sa.cpp:223-255,
+    279-307), from the oracle's CF pre-filter and verifier on the fixture's tasks."""
+    ref_size, cur_offset = int(z["ref_size"]), int(z["seg"][0])
+    blob, off, lens = z["blob"], z["off"], z["lens"]
+    _, cf = oracle.cf_filter(z["packed"], ref_size, cur_offset, blob, off, lens, z["cf"])
+    passed = (z["cf"]["pattern_len"] == 0) | (cf <= 4 * per_cand_k.astype(np.uint32))
+    lev_t, dist_t = z["lev"].copy(), z["dist"].copy()
+    lev_t["max_mismatches"] = per_cand_k
+    dist_t["max_ed"] = per_cand_k
+    _, e_lev = oracle.levdiag(z["packed"], ref_size, cur_offset, blob, off, lens, lev_t)
+    _, d = oracle.distance(z["packed"], blob, off, lens, 0, dist_t, -1)
+    return passed, e_lev, d["edit_distance"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,lev_thr", [("saloop_m150_k5_seg2", 7), ("saloop_m150_k12_seg3_sens", 7),
+                                          ("saloop_m100_k2_seg1", 2)])
+def test_bin_replay_matches_oracle(tmp_path, oracle, name, lev_thr):
+    """replay_batch --bin: a bin of a stage through GpuSaBin - addRead per read, candidate per suffix-array entry, ONE
+    flush - on the reads and entries of a fixture that pins the reference's own loops; every read verifies with its
+    own max_mismatches, so the bin holds reads of both verifiers (below and from lev_alg_thr on)."""
+    import golden_util as gu
+    z = gu.load(name)
+    k, fl, fr, mrl = int(z["k"]), int(z["seg"][0]), int(z["seg"][1]), int(z["min_read_len"])
+    nr, n = len(z["read_ids"]), len(z["cf"])
+    rf = z["read_first"].astype(np.int64)
+    direct = z["cf"]["dir_gen_flag"].astype(np.int64)
+    counts = np.zeros((nr, 2), np.uint16)
+    for r in range(nr):
+        d = int(direct[rf[r]:rf[r + 1]].sum())
+        counts[r] = (d, rf[r + 1] - rf[r] - d)
+    rng = np.random.default_rng(8)
+    read_k = rng.integers(max(1, k - 3), k + 3, nr).astype(np.uint8)       # around the fixture's k, across lev_alg_thr where it is 7
+    per_cand = np.repeat(read_k, counts.sum(axis=1).astype(np.int64))
+    passed, e_lev, e_dist = _bin_expected(oracle, z, per_cand)
+    e = np.where(per_cand >= lev_thr, e_dist, e_lev)
+    want = np.where(passed & (e <= per_cand), e, per_cand.astype(np.uint32) + 1).astype(np.uint8)
+    assert (want <= per_cand).sum() > n // 10
+    lens = z["lens"][:nr]
+    stride = (int(lens.max()) + 1) // 2
+    reads = np.zeros((nr, stride), np.uint8)
+    for r in range(nr):
+        b = (int(lens[r]) + 1) // 2
+        reads[r, :b] = z["blob"][int(z["off"][r]):int(z["off"][r]) + b]
+    fin, fout = tmp_path / "bin.in", tmp_path / "bin.out"
+    with open(fin, "wb") as f:
+        f.write(struct.pack("<8I", int(z["ref_size"]), fl, nr, fl, fr, mrl, lev_thr, stride))
+        for a in (z["packed"], reads, lens.astype(np.uint32), read_k, counts, z["cf"]["position"].astype(np.uint32)):
+            f.write(_vec(a))
+    out = subprocess.run([BIN, "--bin", str(fin), str(fout), "2"], check=True, timeout=120, stdout=subprocess.PIPE, text=True)
+    assert "flush_candidates_per_s" in out.stdout
+    got = np.fromfile(fout, np.uint8)
+    np.testing.assert_array_equal(got, want)

@@ -378,15 +378,16 @@ class Context:
         return int(lib().wamd_sa_candidates_workspace_bytes(C.c_uint32(n_candidates), C.c_uint32(n_reads)))
 
     def verify_sa_candidates_dev(self, reads, batch, d_counts, d_positions, n, d_errors, d_end_positions, d_ws, ws_bytes,
-                                 stream=None):
+                                 stream=None, d_read_k=None):
         """The suffix-array loops' candidates in their compact form (mapping_core_sa.cpp:193-348): counts per read and
         strand, 4-byte suffix-array entries; one byte of errors per candidate."""
-        _check(lib().wamd_verify_sa_candidates_dev(self.h, reads.h, C.byref(batch), _ptr(d_counts), _ptr(d_positions),
+        _check(lib().wamd_verify_sa_candidates_dev(self.h, reads.h, C.byref(batch), _ptr(d_counts), _ptr(d_read_k), _ptr(d_positions),
                                                    C.c_uint32(n), _ptr(d_errors),
                                                    _ptr(d_end_positions) if d_end_positions is not None else None,
                                                    _ptr(d_ws), C.c_uint64(ws_bytes), C.c_void_p(stream or 0)))
 
-    def verify_sa_candidates(self, reads, batch, counts, positions, errors=None, end_positions=None, want_positions=False):
+    def verify_sa_candidates(self, reads, batch, counts, positions, errors=None, end_positions=None, want_positions=False,
+                             read_k=None):
         """Host buffers in, host buffers out: the chunked two-stream pipeline of wamd_verify_sa_candidates."""
         counts = np.ascontiguousarray(counts, np.uint16)
         positions = np.ascontiguousarray(positions, np.uint32)
@@ -395,7 +396,9 @@ class Context:
             errors = np.zeros(n, np.uint8)
         if end_positions is None and want_positions:
             end_positions = np.zeros(n, np.uint32)
-        _check(lib().wamd_verify_sa_candidates(self.h, reads.h, C.byref(batch), _ptr(counts), _ptr(positions), C.c_uint32(n),
+        if read_k is not None:
+            read_k = np.ascontiguousarray(read_k, np.uint8)
+        _check(lib().wamd_verify_sa_candidates(self.h, reads.h, C.byref(batch), _ptr(counts), _ptr(read_k), _ptr(positions), C.c_uint32(n),
                                                _ptr(errors), _ptr(end_positions) if end_positions is not None else None))
         return (errors, end_positions) if end_positions is not None else errors
 

@@ -102,6 +102,7 @@ struct SaParams {
 
 template <bool LEVDIAG>
 __global__ __launch_bounds__(256) void sa_expand_kernel(ReadsView rv, SaParams p, const uint16_t* __restrict__ counts,
+                                                        const uint8_t* __restrict__ read_k,
                                                         const uint32_t* __restrict__ sa_pos,
                                                         const uint32_t* __restrict__ sums, uint32_t* __restrict__ first,
                                                         wamd_cf_task* __restrict__ cf, void* __restrict__ tasks,
@@ -146,7 +147,9 @@ __global__ __launch_bounds__(256) void sa_expand_kernel(ReadsView rv, SaParams p
         else if ((m = rv.lens[read]) == 0)
             raise_flag(flags, FLAG_ARG);
     }
-    const uint32_t k = p.b.max_mismatches, fl = p.b.fixed_left, fr = p.b.fixed_right, mrl = p.b.min_read_len;
+    const uint32_t fl = p.b.fixed_left, fr = p.b.fixed_right, mrl = p.b.min_read_len;
+    // max_mismatches of this thread's read: the stage's, or the read's own (mapping_mode second: min(stage, best_error + 1))
+    const uint32_t my_k = (read_k && i < p.b.n_reads) ? read_k[i] : p.b.max_mismatches;
     for (uint32_t c0 = 0; c0 < total; c0 += 64) {
         const uint32_t j = c0 + lane;   // candidate of this lane inside the wave
         // its read: the first lane whose inclusive prefix exceeds j
@@ -161,6 +164,7 @@ __global__ __launch_bounds__(256) void sa_expand_kernel(ReadsView rv, SaParams p
         const uint32_t r_dir = (uint32_t)__shfl((int)n_dir, (int)src);
         const uint32_t r_m = (uint32_t)__shfl((int)m, (int)src);
         const uint32_t r_read = (uint32_t)__shfl((int)read, (int)src);
+        const uint32_t k = (uint32_t)__shfl((int)my_k, (int)src);
         if (j >= total || r_m == 0)
             continue;
         const uint32_t g = base + j;
@@ -199,8 +203,9 @@ __global__ __launch_bounds__(256) void sa_expand_kernel(ReadsView rv, SaParams p
 }
 
 template <bool LEVDIAG>
-__global__ __launch_bounds__(256) void sa_finish_kernel(uint32_t n, uint32_t k, const void* __restrict__ results,
-                                                        uint8_t* __restrict__ errors, uint32_t* __restrict__ end_pos)
+__global__ __launch_bounds__(256) void sa_finish_kernel(uint32_t n, const void* __restrict__ tasks,
+                                                        const void* __restrict__ results, uint8_t* __restrict__ errors,
+                                                        uint32_t* __restrict__ end_pos)
 {
     // four candidates a thread: their bytes leave as one dword
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -213,13 +218,15 @@ __global__ __launch_bounds__(256) void sa_finish_kernel(uint32_t n, uint32_t k, 
         const uint32_t g = g0 + u;
         if (g >= n)
             break;
-        uint32_t e, pos = 0;
+        uint32_t e, pos = 0, k;     // k: the candidate's own (its read's) max_mismatches, as its task holds it
         if constexpr (LEVDIAG) {
             e = reinterpret_cast<const uint32_t*>(results)[g];
+            k = reinterpret_cast<const wamd_levdiag_task*>(tasks)[g].max_mismatches;
         } else {
             const wamd_dist_result r = reinterpret_cast<const wamd_dist_result*>(results)[g];
             e = r.edit_distance;
             pos = r.pos;
+            k = reinterpret_cast<const wamd_dist_task*>(tasks)[g].max_ed;
         }
         const bool ok = e <= k;     // (RESULT_ERROR is above every k)
         packed |= (ok ? e : k + 1) << (8 * u);
@@ -235,7 +242,7 @@ __global__ __launch_bounds__(256) void sa_finish_kernel(uint32_t n, uint32_t k, 
 }
 
 int launch_sa_candidates(wamd_ctx* ctx, const wamd_reads* r, const wamd_sa_batch* b, const uint16_t* d_counts,
-                         const uint32_t* d_sa_positions, uint32_t n, uint8_t* d_errors, uint32_t* d_end_positions,
+                         const uint8_t* d_read_k, const uint32_t* d_sa_positions, uint32_t n, uint8_t* d_errors, uint32_t* d_end_positions,
                          void* d_ws, hipStream_t s)
 {
     WAMD_HIP(hipSetDevice(ctx->device));
@@ -257,10 +264,10 @@ int launch_sa_candidates(wamd_ctx* ctx, const wamd_reads* r, const wamd_sa_batch
     hipLaunchKernelGGL(sa_block_sums, dim3(nb), dim3(256), 0, s, b->n_reads, d_counts, sums);
     hipLaunchKernelGGL(sa_scan_sums, dim3(1), dim3(1024), 0, s, nb, sums, n, ctx->d_flags);
     if (lev)
-        hipLaunchKernelGGL(sa_expand_kernel<true>, dim3(nb), dim3(256), 0, s, r->view(), p, d_counts, d_sa_positions, sums,
+        hipLaunchKernelGGL(sa_expand_kernel<true>, dim3(nb), dim3(256), 0, s, r->view(), p, d_counts, d_read_k, d_sa_positions, sums,
                            first, cf, tasks, ctx->d_flags);
     else
-        hipLaunchKernelGGL(sa_expand_kernel<false>, dim3(nb), dim3(256), 0, s, r->view(), p, d_counts, d_sa_positions, sums,
+        hipLaunchKernelGGL(sa_expand_kernel<false>, dim3(nb), dim3(256), 0, s, r->view(), p, d_counts, d_read_k, d_sa_positions, sums,
                            first, cf, tasks, ctx->d_flags);
     WAMD_HIP(hipGetLastError());
     int rc;
@@ -279,10 +286,10 @@ int launch_sa_candidates(wamd_ctx* ctx, const wamd_reads* r, const wamd_sa_batch
         return rc;
     const uint32_t fb = ((n + 3) / 4 + 255) / 256;
     if (lev)
-        hipLaunchKernelGGL(sa_finish_kernel<true>, dim3(fb), dim3(256), 0, s, n, (uint32_t)b->max_mismatches, results, d_errors,
+        hipLaunchKernelGGL(sa_finish_kernel<true>, dim3(fb), dim3(256), 0, s, n, tasks, results, d_errors,
                            (uint32_t*)nullptr);
     else
-        hipLaunchKernelGGL(sa_finish_kernel<false>, dim3(fb), dim3(256), 0, s, n, (uint32_t)b->max_mismatches, results, d_errors,
+        hipLaunchKernelGGL(sa_finish_kernel<false>, dim3(fb), dim3(256), 0, s, n, tasks, results, d_errors,
                            d_end_positions);
     WAMD_HIP(hipGetLastError());
     return WAMD_OK;

@@ -722,7 +722,8 @@ static int check_sa_batch(wamd_ctx* ctx, const wamd_reads* reads, const wamd_sa_
 }
 
 int wamd_verify_sa_candidates_dev(wamd_ctx* ctx, const wamd_reads* reads, const wamd_sa_batch* batch,
-                                  const uint16_t* d_counts, const uint32_t* d_sa_positions, uint32_t n_candidates,
+                                  const uint16_t* d_counts, const uint8_t* d_read_max_mismatches,
+                                  const uint32_t* d_sa_positions, uint32_t n_candidates,
                                   uint8_t* d_errors, uint32_t* d_end_positions, void* d_workspace,
                                   uint64_t workspace_bytes, void* stream)
 {
@@ -737,12 +738,14 @@ int wamd_verify_sa_candidates_dev(wamd_ctx* ctx, const wamd_reads* reads, const 
                   "wamd_sa_candidates_workspace_bytes(%u, %u)", n_candidates, batch->n_reads);
         return WAMD_ERR_INVALID_ARG;
     }
-    return launch_sa_candidates(ctx, reads, batch, d_counts, d_sa_positions, n_candidates, d_errors, d_end_positions,
+    return launch_sa_candidates(ctx, reads, batch, d_counts, d_read_max_mismatches, d_sa_positions, n_candidates, d_errors,
+                                d_end_positions,
                                 d_workspace, stream ? (hipStream_t)stream : ctx->stream);
 }
 
 int wamd_verify_sa_candidates(wamd_ctx* ctx, const wamd_reads* reads, const wamd_sa_batch* batch, const uint16_t* counts,
-                              const uint32_t* sa_positions, uint32_t n_candidates, uint8_t* errors, uint32_t* end_positions)
+                              const uint8_t* read_max_mismatches, const uint32_t* sa_positions, uint32_t n_candidates,
+                              uint8_t* errors, uint32_t* end_positions)
 {
     if (n_candidates == 0)
         return WAMD_OK;
@@ -759,7 +762,8 @@ int wamd_verify_sa_candidates(wamd_ctx* ctx, const wamd_reads* reads, const wamd
     auto up = [](uint64_t x) { return (x + 255) / 256 * 256; };
     const uint32_t cmax = n_candidates < CMAX ? n_candidates : CMAX;
     const uint32_t rmax = batch->n_reads < CHUNK_R ? batch->n_reads : CHUNK_R;
-    const uint64_t o_counts = 0, o_pos = o_counts + up((uint64_t)rmax * 4), o_err = o_pos + up((uint64_t)cmax * 4),
+    const uint64_t o_counts = 0, o_k = o_counts + up((uint64_t)rmax * 4), o_pos = o_k + up(rmax),
+                   o_err = o_pos + up((uint64_t)cmax * 4),
                    o_end = o_err + up(cmax), o_ws = o_end + (end_positions ? up((uint64_t)cmax * 4) : 0),
                    slot_bytes = o_ws + up(sa_candidates_workspace_bytes(cmax, rmax));
     rc = ensure_stage(ctx, 2 * slot_bytes, 0);
@@ -784,7 +788,10 @@ int wamd_verify_sa_candidates(wamd_ctx* ctx, const wamd_reads* reads, const wamd
             b.n_reads = r1 - r0;
             WAMD_HIP(hipMemcpyAsync(slot + o_counts, counts + 2 * (uint64_t)r0, (uint64_t)(r1 - r0) * 4, hipMemcpyHostToDevice, st));
             WAMD_HIP(hipMemcpyAsync(slot + o_pos, sa_positions + c0, (uint64_t)c * 4, hipMemcpyHostToDevice, st));
-            rc = launch_sa_candidates(ctx, reads, &b, (const uint16_t*)(slot + o_counts), (const uint32_t*)(slot + o_pos), c,
+            if (read_max_mismatches)
+                WAMD_HIP(hipMemcpyAsync(slot + o_k, read_max_mismatches + r0, r1 - r0, hipMemcpyHostToDevice, st));
+            rc = launch_sa_candidates(ctx, reads, &b, (const uint16_t*)(slot + o_counts),
+                                      read_max_mismatches ? (const uint8_t*)(slot + o_k) : nullptr, (const uint32_t*)(slot + o_pos), c,
                                       (uint8_t*)(slot + o_err), end_positions ? (uint32_t*)(slot + o_end) : nullptr,
                                       slot + o_ws, st);
             if (rc)

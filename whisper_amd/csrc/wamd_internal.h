@@ -186,7 +186,7 @@ int launch_filter_distance(wamd_ctx* ctx, const wamd_reads* r, const wamd_cf_tas
                            int distance_mode = -1);   // -1: the context's
 uint64_t sa_candidates_workspace_bytes(uint32_t n, uint32_t n_reads);
 int launch_sa_candidates(wamd_ctx* ctx, const wamd_reads* r, const wamd_sa_batch* b, const uint16_t* d_counts,
-                         const uint32_t* d_sa_positions, uint32_t n, uint8_t* d_errors, uint32_t* d_end_positions,
+                         const uint8_t* d_read_k, const uint32_t* d_sa_positions, uint32_t n, uint8_t* d_errors, uint32_t* d_end_positions,
                          void* d_ws, hipStream_t s);
 int launch_filter_levdiag(wamd_ctx* ctx, const wamd_reads* r, const wamd_cf_task* d_cf, const wamd_levdiag_task* d_tasks,
                           uint32_t n, uint32_t* d_results, void* d_ws, hipStream_t s);

@@ -14,6 +14,7 @@
 #pragma once
 
 #include <cstdint>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -428,6 +429,189 @@ private:
     std::vector<uchar_t> cigars_;
     uint32_t cur_read_ = 0;
     uint32_t cur_flags_ = 0;
+};
+
+// ---- one bin of one stage in the compact form ------------------------------------------------------------------
+// The suffix-array loops (mapper/mapping_core_sa.cpp:193-348, 355-513) verify candidate after candidate; what the
+// bin loop around them (mapper/mapping_core.cpp:860-1010) does with a read's answers - Push, best_error, pass_read -
+// depends on that read's answers alone, and nothing the loops enumerate depends on an answer.  So a bin is enqueued
+// as the loops walk it, verified with ONE flush behind the bin's read loop, and consumed read by read in the same
+// order.  Per candidate the loops hand over the 4-byte suffix-array entry; the CF pre-filter of :228-230 / :283-285
+// runs on the device in front of the verifier (wamd_verify_sa_candidates), so the host computes no histograms.
+// Reads whose max_mismatches is below lev_alg_thr go to CEditDist::LevDiag, the others to dynamicProgramming
+// (:236-239): two batches inside, each with its reads in page-locked memory.
+template <class T>
+class PinnedVec {
+public:
+    PinnedVec() = default;
+    PinnedVec(const PinnedVec&) = delete;
+    PinnedVec& operator=(const PinnedVec&) = delete;
+    ~PinnedVec() { wamd_host_free(p_); }
+    void push_back(const T& v)
+    {
+        if (n_ == cap_)
+            grow(cap_ ? 2 * cap_ : 4096);
+        p_[n_++] = v;
+    }
+    T* append(size_t k)      // k more elements, uninitialised
+    {
+        if (n_ + k > cap_)
+            grow(n_ + k > 2 * cap_ ? n_ + k : 2 * cap_);
+        T* at = p_ + n_;
+        n_ += k;
+        return at;
+    }
+    void resize(size_t k)
+    {
+        if (k > cap_)
+            grow(k);
+        n_ = k;
+    }
+    void clear() { n_ = 0; }
+    size_t size() const { return n_; }
+    T* data() { return p_; }
+    const T* data() const { return p_; }
+    T& operator[](size_t i) { return p_[i]; }
+    const T& operator[](size_t i) const { return p_[i]; }
+
+private:
+    void grow(size_t want)
+    {
+        void* q = nullptr;
+        check(wamd_host_alloc(&q, want * sizeof(T)), "wamd_host_alloc");
+        if (n_)
+            memcpy(q, p_, n_ * sizeof(T));
+        wamd_host_free(p_);
+        p_ = (T*)q;
+        cap_ = want;
+    }
+    T* p_ = nullptr;
+    size_t n_ = 0, cap_ = 0;
+};
+
+class GpuSaBin {
+public:
+    GpuSaBin(GpuReference& ref, uint32_t lev_alg_thr) : ref_(ref), lev_alg_thr_(lev_alg_thr) {}
+    ~GpuSaBin()
+    {
+        for (Sub& s : sub_)
+            wamd_reads_free(s.reads);
+    }
+    // what the stage holds fixed: the anchor [start_pos, end_pos) and min_read_len (mapping_core.cpp:150-160)
+    void beginBin(uint32_t start_pos, uint32_t end_pos, uint32_t min_read_len)
+    {
+        start_pos_ = start_pos;
+        end_pos_ = end_pos;
+        min_read_len_ = min_read_len;
+        for (Sub& s : sub_)
+            s.clear();
+        where_.clear();
+    }
+    // A read the loops are about to search: its symbols as the bin holds them, the reversed read the loop built
+    // from them (reverse_read, mapping_core.cpp:563) and the max_mismatches it is searched with.  Returns its handle.
+    uint32_t addRead(const uchar_t* data, const uchar_t* rc_data, uint32_t size, uint32_t max_mismatches)
+    {
+        const uint32_t which = max_mismatches >= lev_alg_thr_ ? 0u : 1u;
+        Sub& s = sub_[which];
+        const size_t bytes = (size + 1) / 2;
+        s.off.push_back(s.blob.size());
+        memcpy(s.blob.append(bytes), data, bytes);
+        if (which == 1)      // LevDiag on the other strand verifies the reversed read itself (:291)
+            memcpy(s.rc_blob.append(bytes), rc_data, bytes);
+        s.lens.push_back(size);
+        s.k.push_back((uint8_t)max_mismatches);
+        s.counts.push_back(0);
+        s.counts.push_back(0);
+        s.first.push_back((uint32_t)s.sa.size());
+        where_.push_back(which << 31 | (uint32_t)(s.lens.size() - 1));
+        return (uint32_t)where_.size() - 1;
+    }
+    // one suffix-array entry of the last added read, in the loops' order: its direct-strand entries first
+    void candidate(uint32_t sa_entry, bool dir_gen_flag)
+    {
+        Sub& s = sub_[where_.back() >> 31];
+        uint16_t& c = s.counts[s.counts.size() - (dir_gen_flag ? 2 : 1)];
+        if (c == 0xffff || (dir_gen_flag && s.counts[s.counts.size() - 1]))
+            throw std::runtime_error("GpuSaBin: more than 65535 entries of a read on one strand, or a direct-strand entry "
+                                     "after the other strand's");
+        ++c;
+        s.sa.push_back(sa_entry);
+    }
+    size_t pendingCandidates() const { return sub_[0].sa.size() + sub_[1].sa.size(); }
+
+    void flush()
+    {
+        for (uint32_t which = 0; which < 2; ++which) {
+            Sub& s = sub_[which];
+            const uint32_t n = (uint32_t)s.lens.size();
+            s.errors.resize(s.sa.size());
+            if (!n || !s.sa.size())
+                continue;
+            if (which == 1) {      // the reversed reads behind the reads: read i's copy is read n + i
+                const size_t fwd = s.blob.size();
+                memcpy(s.blob.append(s.rc_blob.size()), s.rc_blob.data(), s.rc_blob.size());
+                for (uint32_t i = 0; i < n; ++i) {
+                    s.off.push_back(fwd + s.off[i]);
+                    s.lens.push_back(s.lens[i]);
+                }
+            }
+            const uint32_t n_up = (uint32_t)s.lens.size();
+            if (!s.reads)
+                check(wamd_reads_upload(ref_.ctx(), s.blob.data(), s.off.data(), s.lens.data(), n_up, WAMD_READS_NIBBLE, 3,
+                                        &s.reads), "wamd_reads_upload");
+            else
+                check(wamd_reads_refill(s.reads, s.blob.data(), s.off.data(), s.lens.data(), n_up, nullptr), "wamd_reads_refill");
+            wamd_sa_batch b{};
+            b.read_first = 0;
+            b.n_reads = n;
+            b.reverse_read_offset = n;
+            b.max_mismatches = 0;      // every read brings its own
+            b.fixed_left = (uint16_t)start_pos_;
+            b.fixed_right = (uint16_t)end_pos_;
+            b.min_read_len = (uint16_t)min_read_len_;
+            b.verifier = which == 1 ? WAMD_SA_VERIFIER_LEVDIAG : WAMD_SA_VERIFIER_DISTANCE;
+            check(wamd_verify_sa_candidates(ref_.ctx(), s.reads, &b, s.counts.data(), s.k.data(), s.sa.data(),
+                                            (uint32_t)s.sa.size(), s.errors.data(), nullptr), "wamd_verify_sa_candidates");
+        }
+    }
+    // after flush(): the answers of read `h`, strand by strand, in the order they were enqueued
+    uint32_t count(uint32_t h, bool dir_gen_flag) const
+    {
+        const Sub& s = sub_[where_[h] >> 31];
+        return s.counts[2 * (size_t)(where_[h] & 0x7fffffffu) + (dir_gen_flag ? 0 : 1)];
+    }
+    // cur_match as the loops go on with it: the errors if <= max_mismatches, else max_mismatches + 1
+    uint32_t curMatch(uint32_t h, bool dir_gen_flag, uint32_t j) const { return sub_[where_[h] >> 31].errors[index(h, dir_gen_flag, j)]; }
+    uint32_t saEntry(uint32_t h, bool dir_gen_flag, uint32_t j) const { return sub_[where_[h] >> 31].sa[index(h, dir_gen_flag, j)]; }
+
+private:
+    struct Sub {
+        PinnedVec<uchar_t> blob, rc_blob;
+        PinnedVec<uint64_t> off;
+        PinnedVec<uint32_t> lens;
+        PinnedVec<uint16_t> counts;
+        PinnedVec<uint8_t> k;
+        PinnedVec<uint32_t> sa;
+        PinnedVec<uint8_t> errors;
+        std::vector<uint32_t> first;
+        wamd_reads* reads = nullptr;
+        void clear()
+        {
+            blob.clear(); rc_blob.clear(); off.clear(); lens.clear(); counts.clear(); k.clear(); sa.clear(); errors.clear();
+            first.clear();
+        }
+    };
+    size_t index(uint32_t h, bool dir_gen_flag, uint32_t j) const
+    {
+        const Sub& s = sub_[where_[h] >> 31];
+        const size_t r = where_[h] & 0x7fffffffu;
+        return (size_t)s.first[r] + (dir_gen_flag ? 0 : s.counts[2 * r]) + j;
+    }
+    GpuReference& ref_;
+    uint32_t lev_alg_thr_;
+    uint32_t start_pos_ = 0, end_pos_ = 0, min_read_len_ = 0;
+    Sub sub_[2];
+    std::vector<uint32_t> where_;     // per handle: batch (bit 31) and the read's index in it
 };
 
 } // namespace whisper_amd

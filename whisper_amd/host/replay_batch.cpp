@@ -3,6 +3,9 @@
 // Input / output are flat binary files written and checked by tests/test_host_mirror.py.
 //   replay_batch <in.bin> <out.bin> [--accepted-only]
 //   replay_batch --rescue <in.bin> <out.bin>
+//   replay_batch --bin <in.bin> <out.bin> [repeats]   one bin of one stage through GpuSaBin: per read addRead(), per
+//                                           suffix-array entry candidate(), ONE flush; prints host-to-host candidates/s
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -75,8 +78,99 @@ static int replay_rescue(const char* in, const char* out)
     return 0;
 }
 
+// reverse_read (mapping_core.cpp:1063-1108): the reverse complement of a nibble-packed read, first symbol in the high nibble
+static void reverse_read(const uchar_t* data, uint32_t size, uchar_t* rc)
+{
+    static uchar_t lut[256];
+    static bool have = false;
+    if (!have) {
+        auto comp = [](uint32_t c) -> uint32_t { return c < 4 ? 3 - c : c; };
+        for (uint32_t b = 0; b < 256; ++b)
+            lut[b] = (uchar_t)(comp(b & 15u) << 4 | comp(b >> 4));
+        have = true;
+    }
+    const uint32_t nb = (size + 1) / 2;
+    if ((size & 1u) == 0) {      // whole bytes: the last byte, nibbles swapped and complemented, comes first
+        for (uint32_t i = 0; i < nb; ++i)
+            rc[i] = lut[data[nb - 1 - i]];
+        return;
+    }
+    auto sym = [&](uint32_t i) -> uint32_t { return (i & 1u) ? (data[i >> 1] & 15u) : (data[i >> 1] >> 4); };
+    memset(rc, 0, nb);
+    for (uint32_t i = 0; i < size; ++i) {
+        const uint32_t c = sym(size - 1 - i);
+        const uint32_t r = c < 4 ? 3 - c : c;
+        rc[i >> 1] |= (uchar_t)((i & 1u) ? r : r << 4);
+    }
+}
+
+// replay_batch --bin: the per-bin form of INTEGRATION.md section 3 on a synthetic bin.  The input holds what the
+// bin loop and the suffix-array loops would have at hand: the reads, per read its max_mismatches and how many
+// suffix-array entries it has on either strand, the entries.  Enqueue as the loops would, flush once, write the
+// answers in enqueue order.
+static int replay_bin(const char* in, const char* out, int repeats)
+{
+    std::ifstream f(in, std::ios::binary);
+    uint32_t hdr[8];   // ref_size, cur_offset, n_reads, start_pos, end_pos, min_read_len, lev_alg_thr, bytes per read
+    f.read((char*)hdr, sizeof(hdr));
+    auto genome = read_vec<uchar_t>(f);
+    auto reads = read_vec<uchar_t>(f);       // n_reads x hdr[7], nibble-packed
+    auto lens = read_vec<uint32_t>(f);
+    auto read_k = read_vec<uint8_t>(f);
+    auto counts = read_vec<uint16_t>(f);     // direct, other strand per read
+    auto sa = read_vec<uint32_t>(f);
+    const uint32_t n = hdr[2], stride = hdr[7];
+
+    GpuReference ref(0, genome.data(), genome.size(), hdr[0], hdr[1]);
+    GpuSaBin bin(ref, hdr[6]);
+    std::vector<uchar_t> rc(stride + 1);
+    std::vector<uint8_t> answers(sa.size());
+    double best = 0;
+    for (int rep = 0; rep < repeats; ++rep) {
+        const auto t0 = std::chrono::steady_clock::now();
+        bin.beginBin(hdr[3], hdr[4], hdr[5]);
+        size_t c = 0;
+        for (uint32_t r = 0; r < n; ++r) {
+            const uchar_t* data = reads.data() + (size_t)r * stride;
+            reverse_read(data, lens[r], rc.data());
+            bin.addRead(data, rc.data(), lens[r], read_k[r]);
+            for (uint32_t j = 0; j < counts[2 * r]; ++j)
+                bin.candidate(sa[c++], true);
+            for (uint32_t j = 0; j < counts[2 * r + 1]; ++j)
+                bin.candidate(sa[c++], false);
+        }
+        const auto t1 = std::chrono::steady_clock::now();
+        bin.flush();
+        const auto t2 = std::chrono::steady_clock::now();
+        c = 0;
+        for (uint32_t r = 0; r < n; ++r)
+            for (int strand = 1; strand >= 0; --strand)
+                for (uint32_t j = 0; j < bin.count(r, strand != 0); ++j)
+                    answers[c++] = (uint8_t)bin.curMatch(r, strand != 0, j);
+        const auto t3 = std::chrono::steady_clock::now();
+        const double enq = std::chrono::duration<double>(t1 - t0).count(), fl = std::chrono::duration<double>(t2 - t1).count(),
+                     cons = std::chrono::duration<double>(t3 - t2).count();
+        std::cout << "bin of " << n << " reads, " << sa.size() << " candidates: enqueue " << enq * 1e3 << " ms, flush "
+                  << fl * 1e3 << " ms, consume " << cons * 1e3 << " ms; flush alone " << sa.size() / fl << " candidates/s, "
+                  << "host to host " << sa.size() / (enq + fl + cons) << " candidates/s\n";
+        best = std::max(best, sa.size() / fl);
+    }
+    std::ofstream o(out, std::ios::binary);
+    o.write((const char*)answers.data(), (std::streamsize)answers.size());
+    std::cout << "flush_candidates_per_s " << best << "\n";
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
+    if ((argc == 4 || argc == 5) && std::string(argv[1]) == "--bin") {
+        try {
+            return replay_bin(argv[2], argv[3], argc == 5 ? atoi(argv[4]) : 1);
+        } catch (const std::exception& e) {
+            std::cerr << "error: " << e.what() << "\n";
+            return 1;
+        }
+    }
     if (argc == 4 && std::string(argv[1]) == "--rescue") {
         try {
             return replay_rescue(argv[2], argv[3]);
