@@ -14,10 +14,15 @@ and nothing is written under /root/reference.
 
     python scripts/check_integration_patch.py [--keep]     exit 0 = both objects compile
 
-The patch is the per-range form: every candidate of one suffix-array range is enqueued, the
-range is flushed, the results are consumed in the order the loop enqueued them - the function
-still returns best_match to its caller, so nothing outside it changes.  Flushing once per bin
-instead moves the consume block behind the bin loop of mapping_core.cpp:560-1050.
+Two forms of the patch are compiled, each in its own scratch tree:
+  per-range  every candidate of one suffix-array range is enqueued, the range is flushed, the results are
+             consumed in the order the loop enqueued them - the function still returns best_match to its
+             caller, so nothing outside it changes (the smallest edit; one device round trip per range).
+  per-bin    the form to run: search_in_* only enqueue the 4-byte suffix-array entries (GpuSaBin, the compact
+             form of wamd_verify_sa_candidates: the CF pre-filter runs on the device), process_reads keeps one
+             record per read of the bin, the bin is flushed ONCE behind its read loop, and what the loop did
+             with a read's answers (Push, best_error, pass_read - mapping_core.cpp:973-1036) runs read by read
+             afterwards, in the same order.  Suffix-array ranges a malicious group takes stay on the host path.
 """
 import os
 import shutil
@@ -248,6 +253,285 @@ SAM_MATCHING_CPP = [
 '''),
 ]
 
+# ---------------------------------------------------------------------------------------------------------
+# The per-bin form
+HEADER_CORE_BIN = [
+    (28, 28, "LevMyers.h", """#include "LevMyers.h"
+#include "gpu_verifier.hpp"
+"""),
+    (109, 109, "indel_matching_rc", """	CIndelMatching* indel_matching_rc;
+	// MI355X verification path, per-bin form (INTEGRATION.md section 3)
+	whisper_amd::GpuReference* gpu_ref;
+	whisper_amd::GpuSaBin* gpu_bin;
+	whisper_amd::GpuIndelMatching* gpu_indel_dir;
+	whisper_amd::GpuIndelMatching* gpu_indel_rc;
+	struct wamd_strand_t {
+		bool enqueued = false, known_range = false;
+		uint32_t mismatch = 0;                           // the host path's answer (malicious groups, no range) ...
+		std::vector<candidate_mapping_t> positions;      // ... and what it pushed
+		std::vector<size_t> indel_tickets;               // sensitive mode: one per enqueued entry
+	};
+	struct wamd_read_t {
+		read_id_t id;
+		uchar_t* data;
+		uint32_t size, best_error, bin_id, max_mismatches, handle;
+		bool searched = false, duplicate = false;
+		wamd_strand_t strand[2];                         // [0] direct, [1] other strand
+	};
+	std::vector<wamd_read_t> wamd_bin_reads;
+	wamd_strand_t* wamd_cur_strand;
+	uint32_t wamd_consume(wamd_read_t& wr, bool dir_gen_flag);
+	void wamd_finish_read(wamd_read_t& wr, uint32_t& dir_mismatch, uint32_t& rc_mismatch, int64_t& no_of_reads);
+"""),
+]
+
+FIND_ARGS_DIR = "data, data_sft, size, matching_part_is_new, sa_dir_part, sa_dir_size, &sa_dir_last_index, &sa_dir_start_index, 1, &dir_inside_malicious_group, &dir_aux_struct_valid, max_mismatches"
+FIND_ARGS_RC = "rc_data, rc_data_sft, size, matching_part_is_new, sa_rc_part, sa_rc_size, &sa_rc_last_index, &sa_rc_start_index, 0, &rc_inside_malicious_group, &rc_aux_struct_valid, max_mismatches"
+
+CORE_CPP_BIN = [
+    (191, 191, "indel_matching_rc->SetReference", """	indel_matching_rc->SetReference(reference->GetData(), 0, 0);
+	{
+		wamd_indel_params ip{};
+		ip.scoring.match = params->match_score;
+		ip.scoring.mismatch = params->mismatch_score;
+		ip.scoring.gap_ins_open = params->gap_ins_open;
+		ip.scoring.gap_ins_extend = params->gap_ins_extend;
+		ip.scoring.gap_del_open = params->gap_del_open;
+		ip.scoring.gap_del_extend = params->gap_del_extend;
+		ip.scoring.clipping = params->clipping_score;
+		ip.min_clipped_factor = params->min_clipped_factor;
+		ip.max_indel_bound = params->max_approx_indel_len;
+		gpu_ref = new whisper_amd::GpuReference(0, reference->GetData(), ((uint64_t) sa_dir->GetRefSize() + 1) / 2,
+			sa_dir->GetRefSize(), start_pos);
+		gpu_ref->setMaxTextLen(max_ref_len);
+		gpu_bin = new whisper_amd::GpuSaBin(*gpu_ref, lev_alg_thr);
+		gpu_indel_dir = new whisper_amd::GpuIndelMatching(*gpu_ref, ip);
+		gpu_indel_rc = new whisper_amd::GpuIndelMatching(*gpu_ref, ip);
+	}
+"""),
+    # process_reads_init_stage (the first stage's bins, 388-777): read by read - the same calls, one flush per read
+    (635, 636, "findMismatches_dir_and_rc", """					{
+						wamd_read_t wr;
+						wr.searched = true;
+						wr.size = size;
+						wr.max_mismatches = stage_major;
+						gpu_bin->beginBin(start_pos, end_pos, min_read_len);
+						wr.handle = gpu_bin->addRead(data, rc_data, size, stage_major);
+						if (sensitive_mode && enable_mapping_indels)	// (the reference's matcher objects still hold the last read of process_reads here)
+						{
+							gpu_indel_dir->Preprocess(data, size, genome_t::direct);
+							gpu_indel_rc->Preprocess(data, size, genome_t::rev_comp);
+						}
+						wamd_cur_strand = &wr.strand[0];
+						wr.strand[0].mismatch = findMismatches_dir_and_rc(%s);
+						if (!wr.strand[0].enqueued)
+							wr.strand[0].positions = dir_match_positions;
+						wamd_cur_strand = &wr.strand[1];
+						wr.strand[1].mismatch = findMismatches_dir_and_rc(%s);
+						if (!wr.strand[1].enqueued)
+							wr.strand[1].positions = rc_match_positions;
+						gpu_bin->flush();
+						if (sensitive_mode && enable_mapping_indels)
+						{
+							gpu_indel_dir->flush();
+							gpu_indel_rc->flush();
+						}
+						dir_match_positions.clear();
+						rc_match_positions.clear();
+						dir_mismatch = wamd_consume(wr, true);
+						rc_mismatch = wamd_consume(wr, false);
+					}
+""" % (FIND_ARGS_DIR.replace("max_mismatches", "stage_major"), FIND_ARGS_RC.replace("max_mismatches", "stage_major"))),
+    # the bin begins
+    (853, 853, "reads_deliverer->Pop", """	gpu_bin->beginBin(start_pos, end_pos, min_read_len);
+	wamd_bin_reads.clear();
+	while (reads_deliverer->Pop(id, data, data_sft, size, best_error))//id number was assigned internally
+"""),
+    (871, 872, "indel_matching_dir->Preprocess", """				gpu_indel_dir->Preprocess(data, size, genome_t::direct);
+				gpu_indel_rc->Preprocess(data, size, genome_t::rev_comp);
+"""),
+    # a new read: its record, and both strands searched - the loops enqueue into it
+    (967, 968, "findMismatches_dir_and_rc", """				wamd_bin_reads.emplace_back();
+				{
+					wamd_read_t& wr = wamd_bin_reads.back();
+					wr.searched = true;
+					wr.handle = gpu_bin->addRead(data, rc_data, size, max_mismatches);
+					wamd_cur_strand = &wr.strand[0];
+					wr.strand[0].mismatch = findMismatches_dir_and_rc(%s);
+					if (!wr.strand[0].enqueued)
+						wr.strand[0].positions = dir_match_positions;
+					wamd_cur_strand = &wr.strand[1];
+					wr.strand[1].mismatch = findMismatches_dir_and_rc(%s);
+					if (!wr.strand[1].enqueued)
+						wr.strand[1].positions = rc_match_positions;
+				}
+""" % (FIND_ARGS_DIR, FIND_ARGS_RC)),
+    # what the loop did with the answers (973-1014) waits for the flush; a repeated read shares the answers of the read before it
+    (973, 1014, "dir_mismatch <= max_mismatches", """			if (!newly_read_data)
+			{
+				wamd_bin_reads.emplace_back();
+				wamd_bin_reads.back().searched = true;
+				wamd_bin_reads.back().duplicate = true;
+			}
+"""),
+    (1017, 1036, "pass_read", """		if (!(size >= end_pos))
+			wamd_bin_reads.emplace_back();
+		{
+			wamd_read_t& wr = wamd_bin_reads.back();
+			wr.id = id;
+			wr.data = data;
+			wr.size = size;
+			wr.best_error = best_error;
+			wr.bin_id = bin_id;
+			wr.max_mismatches = max_mismatches;
+		}
+"""),
+    # behind the bin's read loop: one flush, then every read in its turn
+    (1038, 1037, "", """
+	gpu_bin->flush();
+	if (sensitive_mode && enable_mapping_indels)
+	{
+		gpu_indel_dir->flush();
+		gpu_indel_rc->flush();
+	}
+	dir_mismatch = error_unknown;
+	rc_mismatch = error_unknown;
+	for (auto& wr : wamd_bin_reads)
+		wamd_finish_read(wr, dir_mismatch, rc_mismatch, no_of_reads);
+	wamd_bin_reads.clear();
+"""),
+]
+
+
+def enqueue_bin(indent):
+    t = indent
+    return (
+        t + "gpu_bin->candidate(sa_part[i], dir_gen_flag);\n" +
+        t + "if (sensitive_mode && enable_mapping_indels)\n" +
+        t + "	wamd_cur_strand->indel_tickets.push_back(dir_gen_flag\n" +
+        t + "		? gpu_indel_dir->Match(sa_part[i] - start_pos, max_approx_indel_len, start_pos, end_pos - start_pos, max_mismatches)\n" +
+        t + "		: gpu_indel_rc->Match(ref_size - sa_part[i] - pattern_len + start_pos, max_approx_indel_len, pattern_len - end_pos, end_pos - start_pos, max_mismatches));\n")
+
+
+CONSUME_BIN = """
+// *** MI355X path, per-bin form: the answers of one read's strand, in enumeration order (INTEGRATION.md section 3)
+uint32_t CMappingCore::wamd_consume(wamd_read_t& wr, bool dir_gen_flag)
+{
+	wamd_strand_t& s = wr.strand[dir_gen_flag ? 0 : 1];
+	std::vector<candidate_mapping_t>& out = dir_gen_flag ? dir_match_positions : rc_match_positions;
+	if (!s.enqueued)		// a malicious group, or no range with this anchor: the host path has answered already
+	{
+		out = s.positions;
+		return s.mismatch;
+	}
+	const uint32_t max_mismatches = wr.max_mismatches;
+	const uint32_t pattern_len = wr.size;
+	uint32_t best_match = max_mismatches + 1;
+	whisper_amd::GpuIndelMatching* gpu_indel = dir_gen_flag ? gpu_indel_dir : gpu_indel_rc;
+	const uint32_t n = gpu_bin->count(wr.handle, dir_gen_flag);
+
+	for (uint32_t j = 0; j < n; ++j)
+	{
+		candidate_mapping_t candidate_mapping;
+		const uint32_t sa = gpu_bin->saEntry(wr.handle, dir_gen_flag, j);
+		const uint32_t cur_match = gpu_bin->curMatch(wr.handle, dir_gen_flag, j);
+
+		if (cur_match <= max_mismatches)
+		{
+			if (dir_gen_flag)
+				candidate_mapping = candidate_mapping_t::construct<mapping_type_t::lev>(
+					s.known_range ? sa - start_pos : sa - CUR_OFFSET, genome_t::direct, cur_match);
+			else
+				candidate_mapping = candidate_mapping_t::construct<mapping_type_t::lev>(
+					ref_size - (sa - CUR_OFFSET) - 1, genome_t::rev_comp, cur_match);
+		}
+		if (!s.indel_tickets.empty())
+		{
+			candidate_mapping_t candidate_mapping_indel;
+			if (gpu_indel->result(s.indel_tickets[j], candidate_mapping_indel))
+			{
+				candidate_mapping_indel.direction = dir_gen_flag ? genome_t::direct : genome_t::rev_comp;
+				if (!dir_gen_flag)
+					candidate_mapping_indel.pos += (pattern_len - 1);
+				candidate_mapping = candidate_mapping_t::better(candidate_mapping, candidate_mapping_indel);
+			}
+		}
+		if (candidate_mapping.type != mapping_type_t::none && candidate_mapping.penalty < best_match)
+			best_match = candidate_mapping.penalty;
+		if (candidate_mapping.type != mapping_type_t::none && candidate_mapping.penalty <= max_mismatches)
+			out.push_back(candidate_mapping);
+	}
+	return best_match;
+}
+
+// what process_reads does with a read once both strands have answered (mapping_core.cpp:973-1036), behind the flush
+void CMappingCore::wamd_finish_read(wamd_read_t& wr, uint32_t& dir_mismatch, uint32_t& rc_mismatch, int64_t& no_of_reads)
+{
+	uint32_t best_error = wr.best_error;
+	const uint32_t max_mismatches = wr.max_mismatches;
+
+	if (wr.searched)
+	{
+		if (!wr.duplicate)
+		{
+			dir_match_positions.clear();
+			rc_match_positions.clear();
+			collected_mappings.Clear(max_no_mappings);
+			dir_mismatch = wamd_consume(wr, true);
+			rc_mismatch = wamd_consume(wr, false);
+		}
+		if ((dir_mismatch <= max_mismatches) || (rc_mismatch <= max_mismatches))
+		{
+			if (dir_mismatch <= max_mismatches)
+				for (uint32_t i = 0; i < dir_match_positions.size(); i++)
+					collected_mappings.Push(dir_match_positions[i]);
+			if (rc_mismatch <= max_mismatches)
+				for (uint32_t i = 0; i < rc_match_positions.size(); i++)
+					collected_mappings.Push(rc_match_positions[i]);
+			while (!collected_mappings.Empty())
+			{
+				auto x = collected_mappings.PopUnsorted();
+				results_collector->Push(wr.id, x);
+			}
+			uint32_t tmp_best_error = MIN(dir_mismatch, rc_mismatch);
+			best_error = MIN(best_error, tmp_best_error);
+		}
+	}
+
+	bool pass_read = false;
+	if (stage_minor < stage_major)
+		pass_read = true;
+	else if (mapping_mode == mapping_mode_t::first)
+	{
+		if (best_error > stage_major)
+			pass_read = true;
+	}
+	else if (mapping_mode == mapping_mode_t::second)
+	{
+		if (best_error >= stage_major)
+			pass_read = true;
+	}
+	if (pass_read)
+	{
+		reads_collector->Push(wr.bin_id, wr.id, wr.data, wr.size, best_error);
+		no_of_reads++;
+	}
+}
+"""
+
+SA_CPP_BIN = [
+    (212, 213, "lev_alg_thr", """	wamd_cur_strand->enqueued = true;
+	wamd_cur_strand->known_range = false;
+"""),
+    (217, 344, "candidate_mapping_t", enqueue_bin("\t\t")),
+    (376, 377, "lev_alg_thr", """	wamd_cur_strand->enqueued = true;
+	wamd_cur_strand->known_range = true;
+"""),
+    (383, 504, "candidate_mapping_t", enqueue_bin("\t\t\t")),
+    (514, 513, "", CONSUME_BIN),
+]
+
+
 
 def apply(src_lines, edits):
     out = list(src_lines)
@@ -262,12 +546,8 @@ def apply(src_lines, edits):
     return out
 
 
-def main():
-    keep = "--keep" in sys.argv
-    if not os.path.isdir(REF):
-        print("reference sources absent (%s): nothing to check" % REF)
-        return 0
-    scratch = tempfile.mkdtemp(prefix="wamd_patch_")
+def check(name, patched, keep):
+    scratch = tempfile.mkdtemp(prefix="wamd_patch_%s_" % name)
     assert not os.path.abspath(scratch).startswith(REPO + os.sep)
     try:
         for d in os.listdir(REF):
@@ -275,13 +555,6 @@ def main():
             if d != "mapper":
                 os.symlink(s, os.path.join(scratch, d))
         os.mkdir(os.path.join(scratch, "mapper"))
-        patched = {
-            "mapping_core.h": HEADER_CORE,
-            "mapping_core.cpp": CORE_CPP,
-            "mapping_core_sa.cpp": SA_CPP,
-            "sam.h": HEADER_SAM,
-            "sam_matching.cpp": SAM_MATCHING_CPP,
-        }
         for f in os.listdir(os.path.join(REF, "mapper")):
             s = os.path.join(REF, "mapper", f)
             t = os.path.join(scratch, "mapper", f)
@@ -299,7 +572,7 @@ def main():
         for f in ("mapping_core_sa.cpp", "mapping_core.cpp", "sam_matching.cpp"):
             cmd = [os.environ.get("CXX", "g++")] + flags + [os.path.join(scratch, "mapper", f)]
             r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-            print("%-22s %s" % (f, "compiles" if r.returncode == 0 else "FAILS"))
+            print("%-10s %-22s %s" % (name, f, "compiles" if r.returncode == 0 else "FAILS"))
             if r.returncode:
                 print(r.stdout[-4000:])
                 rc = 1
@@ -309,6 +582,28 @@ def main():
     finally:
         if not keep:
             shutil.rmtree(scratch, ignore_errors=True)
+
+
+def main():
+    keep = "--keep" in sys.argv
+    if not os.path.isdir(REF):
+        print("reference sources absent (%s): nothing to check" % REF)
+        return 0
+    per_range = {
+        "mapping_core.h": HEADER_CORE,
+        "mapping_core.cpp": CORE_CPP,
+        "mapping_core_sa.cpp": SA_CPP,
+        "sam.h": HEADER_SAM,
+        "sam_matching.cpp": SAM_MATCHING_CPP,
+    }
+    per_bin = {
+        "mapping_core.h": HEADER_CORE_BIN,
+        "mapping_core.cpp": CORE_CPP_BIN,
+        "mapping_core_sa.cpp": SA_CPP_BIN,
+        "sam.h": HEADER_SAM,
+        "sam_matching.cpp": SAM_MATCHING_CPP,
+    }
+    return check("per-range", per_range, keep) | check("per-bin", per_bin, keep)
 
 
 if __name__ == "__main__":
