@@ -346,7 +346,7 @@ def boundary_compact(ctx, device, blob, off, lens, tasks, n, ref_size):
     return out
 
 
-def run_extras(ctx, device, genome_symbols, stream, n_small):
+def run_extras(ctx, device, genome_symbols, stream, n_small, gather_cabi=False):
     """Secondary shapes of SURVEY 8d and the rows next to the verifier on the same resident genome: one entry per
     kernel family, timed with HIP events on the context's stream (3 launches after one warm-up), each with the
     roofline that bounds it.  Algorithmic bytes per unit are SURVEY 8(d)'s accounting: 2-bit read + 2-bit window +
@@ -670,6 +670,21 @@ def run_extras(ctx, device, genome_symbols, stream, n_small):
 
     ms_v = timed(verify_all, tag="R1_verify", units=nt)
     ms_g = timed(groups, tag="K_result_groups", units=nt)
+    if gather_cabi:
+        # --gather cabi: the bin's result-group bytes - what rank 0 of a sharded stage needs - through the library's own
+        # RCCL gather as records of one byte each (one rank here: ncclCommInitRank, the all-gather of counts, the packed
+        # copy at the root; N > 1 replaces the copy by ncclSend / ncclRecv)
+        comm1 = api.Comm(ctx, 0, 1, api.comm_unique_id())
+        d_gg = torch.zeros(gcap, dtype=torch.uint8, device=device)
+        holder = {}
+        ms_gg = timed(lambda: holder.__setitem__("c", comm1.gather_records_dev(d_gout, d_gnb, gcap, d_gg, record_bytes=1)))
+        nbytes = int(holder["c"][0])
+        out["K_result_groups_gather"] = {"shape": "wamd_gather_records_dev of the bin's result-group bytes (record_bytes = 1), one rank",
+                                         "bytes": nbytes, "kernel_ms": ms_gg,
+                                         "same_bytes": bool(torch.equal(d_gg[:nbytes], d_gout[:nbytes])),
+                                         "roofline": roof_hbm(nbytes, 2, ms_gg, "device-to-device copy at the root")}
+        comm1.destroy()
+        del d_gg
     ms = timed(chain, tag="R1_mapped_reads", units=na)
     # the same chain with the verifier in accepted-only mode (banded kernels): the commit step only asks
     # cur_match <= max_mismatches (mapping_core_sa.cpp:241), so the group bytes are the same
@@ -1134,7 +1149,7 @@ def main():
             reads.free()
             reads = None
             torch.cuda.empty_cache()
-            out["extras"] = run_extras(ctx, device, args.genome_symbols, stream, args.extras_tasks)
+            out["extras"] = run_extras(ctx, device, args.genome_symbols, stream, args.extras_tasks, gather_cabi=args.gather == "cabi")
             out["extras"]["S1_accepted_only"] = banded
             r1 = out["extras"].get("R1_mapped_reads")
             if r1 and "cpu_baseline" in out:

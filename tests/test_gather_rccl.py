@@ -70,3 +70,52 @@ def test_one_rank_gathers_to_itself(oracle):
         L.wamd_comm_destroy(C.c_void_p(comms[0]))
     finally:
         ctx.destroy()
+
+
+def test_result_group_bytes_gather(oracle):
+    """What rank 0 of a sharded stage actually needs: the variable-length result-group bytes of every rank's bin
+    (wamd_emit_result_groups_dev leaves them and their byte count on the device) through the same gather, as records of
+    one byte each."""
+    import torch
+    codes, packed = common.genome()
+    ctx = api.Context(packed, ref_size=codes.numel(), cur_offset=0)
+    try:
+        t, indel, read_first, read_ids = common.commit_workload(oracle, 3000, 17)
+        dev = torch.device("cuda", 0)
+
+        def up(a):
+            return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev)
+
+        n, nr = len(t), len(read_ids)
+        d_t, d_i, d_rf, d_ids = up(t), up(indel), up(read_first.astype(np.uint32)), up(read_ids.astype(np.uint64))
+        d_c = torch.zeros(n * api.MAPPING.itemsize, dtype=torch.uint8, device=dev)
+        cap = nr * 16 + n * 11 + 64
+        d_bytes = torch.full((cap,), 0xEE, dtype=torch.uint8, device=dev)
+        d_nb = torch.zeros(1, dtype=torch.int32, device=dev)
+        d_ws = torch.zeros(ctx.result_groups_workspace_bytes(n, nr), dtype=torch.uint8, device=dev)
+        d_out = torch.full((cap,), 0x55, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        ctx.commit_candidates_dev(n, d_t, d_i, d_c)
+        ctx.emit_result_groups_dev(n, d_t, d_c, nr, d_rf, d_ids, api.GroupParams(5, 4, 8, 0), d_bytes, cap, d_nb, None, d_ws)
+        ctx.synchronize()
+        assert ctx.take_flags() == 0
+        nb = int(d_nb.item())
+        want = oracle_group_bytes(oracle, t, indel, read_first, read_ids)
+        assert nb == len(want) and bytes(d_bytes[:nb].cpu().numpy()) == bytes(want)
+        comm = api.Comm(ctx, 0, 1, api.comm_unique_id())
+        counts = comm.gather_records_dev(d_bytes, d_nb, cap, d_out, record_bytes=1)
+        ctx.synchronize()
+        assert counts.tolist() == [nb]
+        assert torch.equal(d_out[:nb], d_bytes[:nb]) and bool((d_out[nb:] == 0x55).all())
+        comm.destroy()
+    finally:
+        ctx.destroy()
+
+
+def oracle_group_bytes(oracle, t, indel, read_first, read_ids):
+    from oracle import bindings as ob
+    rc, committed = oracle.commit(t, indel)
+    assert rc == 0
+    rc, out = oracle.result_groups(t, committed, read_first, read_ids, ob.GroupParams(5, 4, 8, 0))
+    assert rc == 0
+    return out
