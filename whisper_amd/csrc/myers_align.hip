@@ -240,15 +240,19 @@ template <int NW, int WW, int BLOCK, int PHASE>
 #endif
 // (second launch bound = waves per SIMD the register budget must allow: the walk kernel sat at 133
 // VGPRs, one wave per SIMD short of what its LDS permits)
-__global__ __launch_bounds__(BLOCK, (PHASE == 1 && NW <= 4 ? WAMD_WALK_WAVES : 1)) void align_traceback_kernel(GenomeView g, ReadsView rv, AlignParams ap)
+__global__ __launch_bounds__(BLOCK, (PHASE == 1 && NW <= 4 ? (WW == -1 ? 2 : (WW == -2 ? 1 : WAMD_WALK_WAVES)) : 1)) void align_traceback_kernel(GenomeView g, ReadsView rv, AlignParams ap)
 {
-    // WW = 0: 32-row windows kept as dwords; otherwise WW 64-bit words per window (at most NW)
-    constexpr bool HALF = WW == 0;
+    // WW = 0 / -1 / -2: banded (nothing of the matrix is stored; a band of 64 / 128 / 256 rows, the walk's windows the
+    // 32 / 64 / 128 rows in its middle); otherwise WW 64-bit words per stored window (at most NW)
+    constexpr bool HALF = WW <= 0;
+    constexpr int BW = WW == -1 ? 2 : (WW == -2 ? 4 : 1);   // 64-bit words of the band
+    constexpr int MARGIN = 16 * BW;                         // band rows below the walk's window
     constexpr int WWE = HALF ? 1 : (WW >= NW ? NW : WW);   // words actually kept per vector and column
     constexpr bool DECIDED = WWE == 1;   // the forward pass stores the walk's four decision bits per cell
     constexpr int NVEC = DECIDED ? 4 : 3;
-    using WT = typename std::conditional<HALF, uint32_t, uint64_t>::type;
-    constexpr uint32_t WMASK = HALF ? 31u : 63u;
+    using WT = typename std::conditional<HALF && BW == 1, uint32_t,
+                                         typename std::conditional<HALF && BW == 4, unsigned __int128, uint64_t>::type>::type;
+    constexpr uint32_t WMASK = (HALF && BW == 1) ? 31u : ((HALF && BW == 4) ? 127u : 63u);
     constexpr bool WINDOWED = HALF || WW < NW;   // windows slide with the column; else whole columns from row 0
     // One wave per block: its LDS holds the pattern-match vectors during the forward pass and,
     // once that is over, the read and the genome window the two walks fetch symbols from
@@ -259,7 +263,7 @@ __global__ __launch_bounds__(BLOCK, (PHASE == 1 && NW <= 4 ? WAMD_WALK_WAVES : 1
     constexpr int CH = 8;                                      // columns per refill of the walk's LDS chunk
     constexpr int CHB = WWE == 2 ? (CH + 1) * 3 * WWE * 2 : 0;  // chunk dwords per lane
     // banded pass: dwords per shifted pattern row = bits 0 .. (columns + 63), one more for the funnel
-    constexpr int SD = (64 * NW + 16 + 64 + 31) / 32 + 1;
+    constexpr int SD = (64 * NW + 16 * BW + 64 * BW + 31) / 32 + 1;
     constexpr int LDS_A = HALF ? 4 * SD : 12 * NW;              // forward pass
     constexpr int LDS_B = RD + GD + CHB;                        // staged symbols (+ the old walk's chunk)
     // the replay kernel (PHASE 2) sizes its staging by the batch's longest read, in dynamic LDS:
@@ -313,7 +317,10 @@ __global__ __launch_bounds__(BLOCK, (PHASE == 1 && NW <= 4 ? WAMD_WALK_WAVES : 1
 
         // ---- banded class: common pieces of the forward pass and of the walk's recomputation ----
         const uint32_t F = (ap.max_cols + 7u) & ~7u;   // iterations of every lane
-        uint64_t VPb = 0, VNb = 0;
+        uint64_t VPb[BW], VNb[BW];
+#pragma unroll
+        for (int w = 0; w < BW; ++w)
+            VPb[w] = VNb[w] = 0;
         auto low_ones = [](int32_t nbits) -> uint64_t {   // ones in bits 0 .. nbits-1
             return nbits <= 0 ? 0ull : (nbits >= 64 ? ~0ull : ((1ull << nbits) - 1ull));
         };
@@ -336,52 +343,104 @@ __global__ __launch_bounds__(BLOCK, (PHASE == 1 && NW <= 4 ? WAMD_WALK_WAVES : 1
         // one banded column: updates VPb / VNb, returns the four decision windows of the column
         // CHECKED: some lane of the wave may see a symbol >= 4 in this group of eight columns (asked once per group,
         // so that the common group is eight columns of straight-line code)
-        auto band_col = [&](auto checked, uint32_t f, uint32_t c, uint32_t (&win)[4]) {
+        auto band_col = [&](auto checked, uint32_t f, uint32_t c, WT (&win)[4]) {
             const uint32_t* S = reinterpret_cast<const uint32_t*>(lds_all) + tid;
             const uint32_t delay = F - n_cols;
             const bool act = valid && f >= delay;
             const uint32_t kd = f >> 5, sh = f & 31u;
             const uint32_t* sp = S + ((c & 3u) * SD + kd) * BLOCK;
-            const uint32_t a0 = sp[0], a1 = sp[BLOCK], a2 = sp[2 * BLOCK];
-            uint64_t eq = ((uint64_t)__builtin_amdgcn_alignbit(a2, a1, sh) << 32) | __builtin_amdgcn_alignbit(a1, a0, sh);
-            uint64_t we = eq;
+            uint32_t a[2 * BW + 1];
+#pragma unroll
+            for (int q = 0; q <= 2 * BW; ++q)
+                a[q] = sp[q * BLOCK];
+            uint64_t eq[BW], we[BW];
+#pragma unroll
+            for (int w = 0; w < BW; ++w) {
+                eq[w] = ((uint64_t)__builtin_amdgcn_alignbit(a[2 * w + 2], a[2 * w + 1], sh) << 32) |
+                        __builtin_amdgcn_alignbit(a[2 * w + 1], a[2 * w], sh);
+                we[w] = eq[w];
+            }
             if constexpr (decltype(checked)::value) {   // N runs and other non-ACGT symbols
                 if (c >= 4u) {
                     // read row of bit 0
-                    const int32_t r0 = (int32_t)f + (int32_t)s_col + (int32_t)m - 2 - (int32_t)ed - (int32_t)end_pos - 16 -
+                    const int32_t r0 = (int32_t)f + (int32_t)s_col + (int32_t)m - 2 - (int32_t)ed - (int32_t)end_pos - MARGIN -
                                        (int32_t)delay;
-                    eq = low_ones(-r0);
-                    we = 0;
+#pragma unroll
+                    for (int w = 0; w < BW; ++w) {
+                        eq[w] = low_ones(-r0 - 64 * w);
+                        we[w] = 0;
+                    }
                     // the walk compares min(c, N_ref) with the read's walk code (> 3 -> N_read for ASCII reads)
                     const uint32_t cw = c > 5u ? 5u : c;
                     if (act && (((presence >> c) | (presence >> cw)) & 1u)) {
                         const uint8_t* codes = rv.codes + rv.code_off[read_idx];
-                        for (int32_t t = 0; t < 64; ++t) {
+                        for (int32_t t = 0; t < 64 * BW; ++t) {
                             const int32_t r = r0 + t;
                             if (r >= 0 && r < (int32_t)m) {
                                 const uint32_t rcode = rev ? rc_code(packed_symbol(codes, m - 1 - (uint32_t)r))
                                                            : packed_symbol(codes, (uint32_t)r);
-                                eq |= (uint64_t)(rcode == c) << t;
-                                we |= (uint64_t)(((ap.ascii && rcode > 3u) ? 4u : rcode) == cw) << t;
+                                const uint64_t e1 = (uint64_t)(rcode == c) << (t & 63);
+                                const uint64_t e2 = (uint64_t)(((ap.ascii && rcode > 3u) ? 4u : rcode) == cw) << (t & 63);
+#pragma unroll
+                                for (int w = 0; w < BW; ++w)
+                                    if ((t >> 6) == w) {
+                                        eq[w] |= e1;
+                                        we[w] |= e2;
+                                    }
                             }
                         }
                     }
                 }
             }
-            const uint64_t D0 = (((eq & VPb) + VPb) ^ VPb) | eq | VNb;
-            const uint64_t HP = VNb | ~(D0 | VPb);
-            const uint64_t HN = D0 & VPb;
-            const uint64_t D0s = D0 >> 1;
-            const uint64_t vp_new = HN | ~(D0s | HP);   // vertical deltas of this column, in the NEXT column's frame
-            const uint64_t vn_new = D0s & HP;
-            VPb = act ? vp_new : VPb;
-            VNb = act ? vn_new : VNb;
+            // D0 = (((eq & VP) + VP) ^ VP) | eq | VN over the whole band (the carry crosses its words)
+            uint64_t D0[BW], HP[BW], HN[BW];
+            uint64_t carry = 0;
+#pragma unroll
+            for (int w = 0; w < BW; ++w) {
+                const uint64_t x = eq[w] & VPb[w];
+                const uint64_t s1 = x + VPb[w];
+                const uint64_t s2 = s1 + carry;
+                carry = (uint64_t)(s1 < x) | (uint64_t)(s2 < s1);
+                D0[w] = (s2 ^ VPb[w]) | eq[w] | VNb[w];
+                HP[w] = VNb[w] | ~(D0[w] | VPb[w]);
+                HN[w] = D0[w] & VPb[w];
+            }
+            uint64_t vp_new[BW], vn_new[BW];
+#pragma unroll
+            for (int w = 0; w < BW; ++w) {
+                const uint64_t D0s = (D0[w] >> 1) | (w + 1 < BW ? D0[w + 1 < BW ? w + 1 : w] << 63 : 0ull);
+                vp_new[w] = HN[w] | ~(D0s | HP[w]);   // vertical deltas of this column, in the NEXT column's frame
+                vn_new[w] = D0s & HP[w];
+            }
+#pragma unroll
+            for (int w = 0; w < BW; ++w) {
+                VPb[w] = act ? vp_new[w] : VPb[w];
+                VNb[w] = act ? vn_new[w] : VNb[w];
+            }
             // what getExtCigar tests at a cell (LevMyers64.cpp:419-442), as bits:
             // d_val + mismatch == c  <=>  D0 == match;  h_val + 1 == c  <=>  HP;  v_val + 1 == c  <=>  VP
-            win[0] = (uint32_t)((D0 & we) >> 16);
-            win[1] = (uint32_t)(~(D0 | we) >> 16);
-            win[2] = (uint32_t)(HP >> 16);
-            win[3] = (uint32_t)(vp_new >> 15);
+            // the window: the 32 BW rows above the margin (vp_new is one row further down: the next column's frame)
+            auto window = [](const uint64_t (&x)[BW], int below) -> WT {
+                if constexpr (BW == 1) {
+                    return (WT)(x[0] >> (below ? 15 : 16));
+                } else if constexpr (BW == 2) {
+                    return below ? (WT)((x[0] >> 31) | (x[1] << 33)) : (WT)((x[0] >> 32) | (x[1] << 32));
+                } else {
+                    const uint64_t lo = below ? (x[0] >> 63) | (x[1] << 1) : x[1];
+                    const uint64_t hi = below ? (x[1] >> 63) | (x[2] << 1) : x[2];
+                    return ((WT)hi << 64) | (WT)lo;
+                }
+            };
+            uint64_t dm[BW], dx[BW];
+#pragma unroll
+            for (int w = 0; w < BW; ++w) {
+                dm[w] = D0[w] & we[w];
+                dx[w] = ~(D0[w] | we[w]);
+            }
+            win[0] = window(dm, 0);
+            win[1] = window(dx, 0);
+            win[2] = window(HP, 0);
+            win[3] = window(vp_new, 1);
         };
         const uint8_t* my_codes = rv.codes + rv.code_off[read_idx];
         if constexpr (PHASE == 2) {
@@ -408,7 +467,7 @@ __global__ __launch_bounds__(BLOCK, (PHASE == 1 && NW <= 4 ? WAMD_WALK_WAVES : 1
             uint32_t* S = reinterpret_cast<uint32_t*>(lds_all) + tid;                 // [c][d][lane]
             const uint32_t delay = F - n_cols;                                        // iterations before column s_col
             // read row under bit 0 of iteration f is f + Zf
-            const int32_t Zf = (int32_t)s_col + (int32_t)m - 2 - (int32_t)ed - (int32_t)end_pos - 16 - (int32_t)delay;
+            const int32_t Zf = (int32_t)s_col + (int32_t)m - 2 - (int32_t)ed - (int32_t)end_pos - MARGIN - (int32_t)delay;
             {
                 const uint32_t slot = valid ? (uint32_t)(rev ? rv.slot_rc : rv.slot_direct) : 0;
                 const uint32_t* src = rv.pm32 + ((uint64_t)read_idx * rv.n_orient + slot) * 4 * rv.pm32_stride;
@@ -442,8 +501,11 @@ __global__ __launch_bounds__(BLOCK, (PHASE == 1 && NW <= 4 ? WAMD_WALK_WAVES : 1
                     }
                 }
             }
-            VPb = ~low_ones(-(Zf + (int32_t)delay));   // column s_col - 1: D = row, phantom rows flat
-            VNb = 0;
+#pragma unroll
+            for (int w = 0; w < BW; ++w) {
+                VPb[w] = ~low_ones(-(Zf + (int32_t)delay) - 64 * w);   // column s_col - 1: D = row, phantom rows flat
+                VNb[w] = 0;
+            }
             uint32_t t_lo = text_dword(tx_i0);
             for (uint32_t fb4 = 0; fb4 < F; fb4 += 32) {   // four text dwords per 16-byte load
                 uint32_t raw[4];
@@ -452,22 +514,25 @@ __global__ __launch_bounds__(BLOCK, (PHASE == 1 && NW <= 4 ? WAMD_WALK_WAVES : 1
                 for (int q = 0; q < 4; ++q) {
                     const uint32_t fb = fb4 + 8u * q;
                     if (fb < F) {
-                        uint64_t* ck = mat + ((uint64_t)(fb / 8) * 2) * BLOCK + tid;
-                        ck[0] = VPb;
-                        ck[BLOCK] = VNb;
+                        uint64_t* ck = mat + ((uint64_t)(fb / 8) * 2 * BW) * BLOCK + tid;
+#pragma unroll
+                        for (int w = 0; w < BW; ++w) {
+                            ck[(2 * w) * BLOCK] = VPb[w];
+                            ck[(2 * w + 1) * BLOCK] = VNb[w];
+                        }
                         const uint32_t t_hi = nibble_swap(raw[q]);
                         const uint32_t syms = __builtin_amdgcn_alignbit(t_hi, t_lo, tx_sh);
                         t_lo = t_hi;
                         if (__any(valid && (syms & 0xccccccccu))) {
 #pragma unroll
                             for (int u = 0; u < 8; ++u) {
-                                uint32_t win[4];
+                                WT win[4];
                                 band_col(std::true_type{}, fb + u, (syms >> (4 * u)) & 15u, win);
                             }
                         } else {
 #pragma unroll
                             for (int u = 0; u < 8; ++u) {
-                                uint32_t win[4];
+                                WT win[4];
                                 band_col(std::false_type{}, fb + u, (syms >> (4 * u)) & 15u, win);
                             }
                         }
@@ -810,21 +875,27 @@ __global__ __launch_bounds__(BLOCK, (PHASE == 1 && NW <= 4 ? WAMD_WALK_WAVES : 1
                 // eight columns at a time: reload the state kept before iteration F - 8(q+1), run the
                 // band forward into registers, then walk those columns right to left
                 const uint32_t n_chunks = F / 8;
-                auto ck_load = [&](uint32_t q, uint64_t& vp, uint64_t& vn) {
+                auto ck_load = [&](uint32_t q, uint64_t (&vp)[BW], uint64_t (&vn)[BW]) {
                     const uint32_t idx = q < n_chunks ? n_chunks - 1 - q : 0u;
-                    const uint64_t* ck = mat + ((uint64_t)idx * 2) * BLOCK + tid;
-                    vp = ck[0];
-                    vn = ck[BLOCK];
+                    const uint64_t* ck = mat + ((uint64_t)idx * 2 * BW) * BLOCK + tid;
+#pragma unroll
+                    for (int w = 0; w < BW; ++w) {
+                        vp[w] = ck[(2 * w) * BLOCK];
+                        vn[w] = ck[(2 * w + 1) * BLOCK];
+                    }
                 };
-                uint64_t nvp, nvn;
+                uint64_t nvp[BW], nvn[BW];
                 ck_load(0, nvp, nvn);
                 // text dwords right to left: the low dword of a group is the high one of the next
                 uint32_t t_lo = text_dword(tx_i0 + (int32_t)n_chunks - 1);
                 uint32_t nsyms = __builtin_amdgcn_alignbit(text_dword(tx_i0 + (int32_t)n_chunks), t_lo, tx_sh);
                 for (uint32_t q = 0; q < n_chunks && __any(read_pos && pos); ++q) {
                     const uint32_t fb = F - 8 * (q + 1);
-                    VPb = nvp;
-                    VNb = nvn;
+#pragma unroll
+                    for (int w = 0; w < BW; ++w) {
+                        VPb[w] = nvp[w];
+                        VNb[w] = nvn[w];
+                    }
                     const uint32_t syms = nsyms;
                     ck_load(q + 1, nvp, nvn);
                     {
@@ -832,7 +903,7 @@ __global__ __launch_bounds__(BLOCK, (PHASE == 1 && NW <= 4 ? WAMD_WALK_WAVES : 1
                         t_lo = text_dword(tx_i0 + (int32_t)(fb >> 3) - 1);
                         nsyms = __builtin_amdgcn_alignbit(t_hi, t_lo, tx_sh);
                     }
-                    uint32_t D[8][4];
+                    WT D[8][4];
                     if (__any(valid && (syms & 0xccccccccu))) {
 #pragma unroll
                         for (int u = 0; u < 8; ++u)
@@ -1361,7 +1432,7 @@ struct AlignLayout {
     uint64_t per_block[4];           // per class: bytes of one block's slot
 };
 
-static AlignLayout align_layout(const wamd_reads* r, uint32_t n, bool wide_class)
+static AlignLayout align_layout(const wamd_reads* r, uint32_t n, uint32_t max_ed)
 {
     AlignLayout L{};
     const uint32_t nw = r->words ? r->words : 1;
@@ -1374,13 +1445,13 @@ static AlignLayout align_layout(const wamd_reads* r, uint32_t n, bool wide_class
     L.cols[1] = m + 30 + 2;
     L.cols[2] = m + 62 + 2;
     L.cols[3] = 2 * m + 2;
-    const uint64_t col_bytes[4] = {0, 4 * 8, nw < 2 ? 4 * 8u : 3 * 2 * 8u, nw < 2 ? 4 * 8u : 3 * nw * 8u};
+    const uint64_t col_bytes[4] = {0, 0, nw < 2 ? 4 * 8u : 3 * 2 * 8u, nw < 2 ? 4 * 8u : 3 * nw * 8u};
     uint64_t* per_block = L.per_block;
     L.slot_bytes_max = 0;
     for (int c = 0; c < 4; ++c) {
         per_block[c] = ((uint64_t)L.cols[c] * col_bytes[c] + (uint64_t)L.path_dwords * 4) * L.block;
-        if (c == 0)
-            per_block[c] = (uint64_t)((L.cols[0] + 7) / 8) * 16 * L.block;   // its paths live in their own region
+        if (c < 3)   // banded: the state before every eighth column (16 / 32 / 64 bytes); the paths live in their own region
+            per_block[c] = (uint64_t)((L.cols[c] + 7) / 8) * 16 * (1u << c) * L.block;
         per_block[c] = up256(per_block[c]);
         L.slot_bytes_max = per_block[c] > L.slot_bytes_max ? per_block[c] : L.slot_bytes_max;
     }
@@ -1389,14 +1460,11 @@ static AlignLayout align_layout(const wamd_reads* r, uint32_t n, bool wide_class
     L.blocks = need_blocks < cap_blocks ? need_blocks : cap_blocks;
     if (L.blocks == 0)
         L.blocks = 1;
-    // the region serves the classes one after the other: all blocks of the banded class, and blocks of the
-    // 64-row class (ed 15 .. 30) - 2048 of them (eight waves per CU) where the caller expects such distances
-    // (wamd_align_workspace_bytes_for with max_ed >= 15: the mate rescue, the 250 bp high-error configuration),
-    // else 256 (one wave per CU: stragglers).  The launcher uses whatever the caller gives beyond the minimum.
+    // the region serves the classes one after the other: all blocks of the first banded class (ed <= 14; the others,
+    // ed <= 30 and ed <= 62, take two and four times as much a block and run that many fewer at a time; whole columns -
+    // ed beyond 62 - one block at least).  The launcher uses whatever the caller gives beyond the minimum.
     uint64_t region = (uint64_t)L.blocks * per_block[0];
-    const uint32_t wide_blocks = wide_class ? 2048u : 256u;
-    const uint64_t wide = (uint64_t)(need_blocks < wide_blocks ? (need_blocks ? need_blocks : 1u) : wide_blocks) * per_block[1];
-    region = region < wide ? wide : region;
+    (void)max_ed;
     if (region < L.slot_bytes_max)
         region = L.slot_bytes_max;
     L.dist_off = 0;
@@ -1411,14 +1479,14 @@ static AlignLayout align_layout(const wamd_reads* r, uint32_t n, bool wide_class
 
 uint64_t align_workspace_bytes(const wamd_reads* r, uint32_t n, uint32_t max_ed)
 {
-    return align_layout(r, n, max_ed >= 15).total;
+    return align_layout(r, n, max_ed).total;
 }
 
 template <int NW, int WW, int BLOCK>
 static int launch_tb(const GenomeView& g, const ReadsView& rv, AlignParams ap, uint32_t blocks, uint32_t groups,
                      hipStream_t s)
 {
-    if constexpr (WW == 0) {
+    if constexpr (WW <= 0) {
         hipLaunchKernelGGL((align_traceback_kernel<NW, WW, BLOCK, 1>), dim3(blocks), dim3(BLOCK), 0, s, g, rv, ap);
         const uint32_t lds = 256u * ap.rp_sw;   // a wave's rows
         if (lds <= 40u * 1024u)   // (four waves per CU at least; longer reads take the form without LDS)
@@ -1439,9 +1507,9 @@ static int launch_tb_class(int cls, const GenomeView& g, const ReadsView& rv, co
     if (cls == 0)
         return launch_tb<NW, 0, BLOCK>(g, rv, ap, blocks, groups, s);
     if (cls == 1)
-        return launch_tb<NW, 1, BLOCK>(g, rv, ap, blocks, groups, s);
+        return launch_tb<NW, -1, BLOCK>(g, rv, ap, blocks, groups, s);
     if (cls == 2)
-        return launch_tb<NW, 2, BLOCK>(g, rv, ap, blocks, groups, s);
+        return launch_tb<NW, -2, BLOCK>(g, rv, ap, blocks, groups, s);
     return launch_tb<NW, NW, BLOCK>(g, rv, ap, blocks, groups, s);
 }
 
@@ -1456,7 +1524,7 @@ int launch_align(wamd_ctx* ctx, const wamd_reads* r, const wamd_dist_task* d_tas
         set_error("wamd_align: cigar_stride must be a multiple of 4, buffers aligned (cigars 4, workspace 256)");
         return WAMD_ERR_INVALID_ARG;
     }
-    const AlignLayout L = align_layout(r, n, false);
+    const AlignLayout L = align_layout(r, n, 0);
     if (ws_bytes < L.total)
         return WAMD_ERR_INVALID_ARG;
     char* ws = (char*)d_ws;
@@ -1502,10 +1570,11 @@ int launch_align(wamd_ctx* ctx, const wamd_reads* r, const wamd_dist_task* d_tas
         // replay of the banded class (ed <= 14): the read, and the m + ed + 2 genome symbols the
         // alignment can span, from whatever nibble of a dword they start at
         ap.rd_cap = 0;   // the read comes straight from memory
-        ap.gd_cap = (r->max_len + 30) / 8 + 2;
+        const uint32_t ed_max = cls == 0 ? 14u : (cls == 1 ? 30u : 62u);   // of the banded classes
+        ap.gd_cap = (r->max_len + ed_max + 16) / 8 + 2;
         // staged replay (ed <= 14): a string of at most m + 29 bytes and its terminator, rounded up to dwords - an odd
         // number of them
-        ap.rp_sw = ((r->max_len + 32u) >> 2) | 1u;
+        ap.rp_sw = ((r->max_len + 2u * ed_max + 4u) >> 2) | 1u;
         const uint64_t per_block = L.per_block[cls];
         ap.slot_words = per_block / 8;
         uint64_t blocks64 = region / per_block;
