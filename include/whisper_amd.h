@@ -751,6 +751,62 @@ WAMD_API int wamd_finish_pairs_dev(wamd_ctx* ctx, const wamd_reads* reads, const
                                    uint8_t* d_cigars, uint32_t cigar_stride, uint8_t* d_mdz, uint32_t mdz_stride,
                                    void* d_workspace, uint64_t workspace_bytes, void* stream);
 
+/* ---- mate rescue by LevMyers: find_pairs<LevMyers>'s chain per hit (sam_matching.cpp:379-457) -------------------- *
+ * For a hit of one read the mate is aligned in the window the insert-size model allows beside it:
+ *     start_pos = paired_dir == direct ? hit_pos + len(mate) - distance_threshold : hit_pos + 1 - max_mate_edit_distance
+ *     dynamicProgramming(start_pos, distance_threshold + 2 * max_mate_edit_distance, max_mate_edit_distance)   :392-400
+ *     getExtCigar (+ refine_ext_cigar), paired_raw_pos = start_pos + relative_begin_pos                         :414-422
+ *     Translate(paired_raw_pos) must give the hit's chromosome; num_events <= max_mate_edit_distance / 2 for the
+ *     mate's alignment and for the hit                                                                          :424-426
+ *     the mate's mapping_desc_t (lev: err_edit_distance = the edit distance, ref_length = end - begin,
+ *     score = the affine score), clipIllegalPositions, clipBoundaryPositions                                    :433-450
+ * all of it on the device, one call per batch of hits: results[i].ok says whether the pair candidate exists, and then
+ * holds the mate's mapping as the pair evaluator sees it; its ext-CIGAR is in ext_cigars + i * ext_stride.  The hit's
+ * own two clipping passes (:444, :448) are wamd_clip_illegal / wamd_clip_boundary on the caller's records.
+ * What Translate needs of the hit's chromosome travels in the task (ref_desc.cpp:81-118): raw positions p with
+ * seq_lo < p + 1 <= seq_hi belong to it, ref_seq_pos = p + seq_delta.  Reads: ASCII, both orientations. */
+typedef struct wamd_rescue_task {
+    uint32_t mate_read_idx;
+    uint32_t hit_pos;                 /* this_hit.mapping.pos                                             */
+    uint32_t distance_threshold;      /* (ref_pos_t) (mean + MyersDev), :347                              */
+    uint32_t seq_lo;                  /* pos_in_ref_seq + SEPARATE_N_LEN / 2 of the hit's chromosome      */
+    uint32_t seq_hi;                  /* the same of the next one; the last: pos_in_ref_seq + size + 2 * SEPARATE_N_LEN */
+    int32_t seq_delta;                /* no_initial_Ns - no_starting_Ns + 1 - pos_in_ref_seq              */
+    int32_t ref_size;                 /* size + no_final_Ns + no_initial_Ns (soft_clipping.cpp:594-595)   */
+    uint16_t max_mate_edit_distance;  /* (uint32_t) (len(mate) * max_mate_edit_distance_frac) * 2, :388   */
+    uint16_t hit_num_events;
+    uint8_t paired_dir_direct;        /* get_direction_using_orientation(...) == genome_t::direct         */
+    uint8_t reserved[3];
+} wamd_rescue_task;
+
+typedef struct wamd_rescue_result {
+    double score;                     /* affine, after the clipping passes                                */
+    uint32_t ok;                      /* the pair candidate exists                                        */
+    uint32_t aligned;                 /* dynamicProgramming returned true (:402)                          */
+    uint32_t pos;                     /* paired_raw_pos                                                   */
+    int32_t ref_seq_pos;
+    uint16_t ref_length;
+    uint16_t err_edit_distance;       /* = num_events of the mate's mapping_desc_t (lev)                  */
+    uint16_t left_clipping;
+    uint16_t right_clipping;
+    uint32_t ext_cigar_len;
+    uint32_t cigar_events;            /* num_events of getExtCigar / refine_ext_cigar (:424)              */
+} wamd_rescue_result;
+
+typedef struct wamd_rescue_params {
+    uint32_t enable_short_indel_refinement;
+    uint32_t enable_boundary_clipping;
+} wamd_rescue_params;
+
+WAMD_API uint64_t wamd_rescue_workspace_bytes(const wamd_reads* reads, uint32_t n, uint32_t max_mate_edit_distance);
+WAMD_API int wamd_rescue_mates(wamd_ctx* ctx, const wamd_reads* reads, const wamd_rescue_task* tasks, uint32_t n,
+                               const wamd_rescue_params* params, wamd_rescue_result* results, uint8_t* ext_cigars,
+                               uint32_t ext_stride);
+/* ext_stride: a multiple of 4, >= 2 * (read length + max_mate_edit_distance) + 8; d_workspace 256-byte aligned */
+WAMD_API int wamd_rescue_mates_dev(wamd_ctx* ctx, const wamd_reads* reads, const wamd_rescue_task* d_tasks, uint32_t n,
+                                   const wamd_rescue_params* params, wamd_rescue_result* d_results, uint8_t* d_ext_cigars,
+                                   uint32_t ext_stride, void* d_workspace, uint64_t workspace_bytes, void* stream);
+
 /* ---- from verified candidates to the bytes of a result group ---------------------------- *
  * One suffix-array candidate after its verifiers have answered, as the loop of
  * search_in_unknown_range_dir_and_rc holds it at mapping_core_sa.cpp:241-344 (the known-range and

@@ -549,3 +549,51 @@ def _r_search_reads(self, genome, ref_size, reads, offsets, lens, sa_dir, sa_rc,
 
 
 Reference.search_reads = _r_search_reads
+
+
+# ---- mate rescue by LevMyers: find_pairs<LevMyers>'s chain per hit (sam_matching.cpp:379-457)
+RESCUE_TASK = np.dtype([("mate_read_idx", "<u4"), ("hit_pos", "<u4"), ("distance_threshold", "<u4"), ("seq_lo", "<u4"),
+                        ("seq_hi", "<u4"), ("seq_delta", "<i4"), ("ref_size", "<i4"), ("max_mate_edit_distance", "<u2"),
+                        ("hit_num_events", "<u2"), ("paired_dir_direct", "u1"), ("reserved", "u1", (3,))])
+RESCUE_RESULT = np.dtype([("score", "<f8"), ("ok", "<u4"), ("aligned", "<u4"), ("pos", "<u4"), ("ref_seq_pos", "<i4"),
+                          ("ref_length", "<u2"), ("err_edit_distance", "<u2"), ("left_clipping", "<u2"),
+                          ("right_clipping", "<u2"), ("ext_cigar_len", "<u4"), ("cigar_events", "<u4")])
+assert RESCUE_TASK.itemsize == 36 and RESCUE_RESULT.itemsize == 40
+
+
+class RescueParams(C.Structure):
+    _fields_ = [("enable_short_indel_refinement", C.c_uint32), ("enable_boundary_clipping", C.c_uint32)]
+
+
+def _o_rescue_mates(self, genome, reads, offsets, lens, tasks, params=None, scoring=None, ext_stride=512):
+    prm = params or RescueParams(1, 1)
+    sc = scoring or default_scoring()
+    t = np.ascontiguousarray(tasks, RESCUE_TASK)
+    res = np.zeros(len(t), RESCUE_RESULT)
+    ext = np.zeros((len(t), ext_stride), np.uint8)
+    rc = self.lib.wo_rescue_mates_batch(_p(genome), _p(reads), _p(offsets), _p(lens), _p(t), C.c_uint32(len(t)), C.byref(prm),
+                                        C.byref(sc), _p(res), _p(ext), C.c_uint32(ext_stride))
+    return rc, res, ext
+
+
+def _r_rescue_mates(self, genome, ref_size, desc, reads, offsets, lens, mate_read_idx, hit_pos, hit_seq_id, hit_num_events,
+                    paired_dir_direct, max_mate_ed, params=None, scoring=None, model=(500.0, 125.0), ext_stride=512):
+    """The reference's own statements on its own objects: returns (rc, tasks as the C-ABI takes them, results, ext-CIGARs)."""
+    prm = params or RescueParams(1, 1)
+    sc = scoring or default_scoring()
+    n = len(mate_read_idx)
+    desc = np.ascontiguousarray(desc, np.uint64)
+    tasks = np.zeros(n, RESCUE_TASK)
+    res = np.zeros(n, RESCUE_RESULT)
+    ext = np.zeros((n, ext_stride), np.uint8)
+    rc = self.lib.ref_rescue_mates_batch(_p(genome), C.c_uint32(ref_size), _p(desc), C.c_uint32(len(desc)), _p(reads),
+                                         _p(offsets), _p(lens), C.c_uint32(n), _p(_c(mate_read_idx, np.uint32)),
+                                         _p(_c(hit_pos, np.uint32)), _p(_c(hit_seq_id, np.int32)),
+                                         _p(_c(hit_num_events, np.uint16)), _p(_c(paired_dir_direct, np.uint8)),
+                                         _p(_c(max_mate_ed, np.uint16)), C.byref(prm), C.byref(sc), C.c_double(model[0]),
+                                         C.c_double(model[1]), _p(tasks), _p(res), _p(ext), C.c_uint32(ext_stride))
+    return rc, tasks, res, ext
+
+
+Oracle.rescue_mates = _o_rescue_mates
+Reference.rescue_mates = _r_rescue_mates

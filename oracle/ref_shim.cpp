@@ -1179,3 +1179,129 @@ REF_API int ref_result_groups_batch(uint32_t n_tasks, const wamd_commit_task* ta
     (void)n_tasks;
     return 0;
 }
+
+/* find_pairs<LevMyers>'s chain per hit (sam_matching.cpp:379-457), its statements in its order on the reference's own
+ * objects; the loops over the hits of a pair and the pair evaluator behind it stay out.  hit_seq_id names the hit's
+ * chromosome in the table; tasks_out receives the task as the C-ABI takes it (Translate's view of that chromosome). */
+REF_API int ref_rescue_mates_batch(const uint8_t* genome, uint32_t ref_size, const uint64_t* seq_desc5, uint32_t n_seq,
+                                   const uint8_t* reads, const uint64_t* offsets, const uint32_t* lens, uint32_t n,
+                                   const uint32_t* mate_read_idx, const uint32_t* hit_pos, const int32_t* hit_seq_id,
+                                   const uint16_t* hit_num_events, const uint8_t* paired_dir_direct,
+                                   const uint16_t* max_mate_ed, const wamd_rescue_params* prm, const wamd_scoring* sc,
+                                   double model_mean, double model_dev, wamd_rescue_task* tasks_out,
+                                   wamd_rescue_result* results, uint8_t* ext_cigars, uint32_t ext_stride)
+{
+    const uint32_t max_query_len = 1024, max_text_len = 16384;
+    Verifiers v(max_query_len, max_text_len, 0, const_cast<uint8_t*>(genome), ref_size, 0);
+    SamGenBox box;
+    CSamGenerator* gen = box.get();
+    fill_params(box.params, sc, 1.0);
+    box.params.enable_short_indel_refinement = prm->enable_short_indel_refinement != 0;
+    scoring_t scoring = make_scoring(sc);
+    InsertSizeModel model(model_mean, model_dev, 100, 10000, 4.0, 7.0, 7.0, scoring);
+    CSoftClipping clip(max_query_len, max_text_len, 3, 50, 0);
+    clip.setReference(const_cast<uint8_t*>(genome), 0, 0);
+    CMemoryPool<uchar_t> pool(64 * (int64_t)ext_stride, ext_stride, "shim");
+    CRefSeqDesc desc;
+    for (uint32_t i = 0; i < n_seq; ++i) {
+        const uint64_t* d = seq_desc5 + 5 * (size_t)i;
+        desc.seq_desc.push_back(seq_desc_t("chr" + std::to_string(i + 1), (int32_t)i, d[0], d[1], d[2], d[3], d[4]));
+    }
+    std::vector<uint8_t> read_codes(max_query_len + 8), ref_codes(max_text_len + 8);
+    uint8_t name[] = "shim";
+    const ref_pos_t distanceThreshold = (ref_pos_t)(model.mean() + model.getMyersDev());   /* :347 */
+
+    for (uint32_t i = 0; i < n; ++i) {
+        wamd_rescue_result& o = results[i];
+        uint8_t* ec = ext_cigars + (size_t)i * ext_stride;
+        memset(&o, 0, sizeof(o));
+        ec[0] = 0;
+        uint8_t* seq = const_cast<uint8_t*>(reads + offsets[mate_read_idx[i]]);
+        const uint32_t len = lens[mate_read_idx[i]];
+        const genome_t paired_dir = paired_dir_direct[i] ? genome_t::direct : genome_t::rev_comp;
+        const uint32_t max_mate_edit_distance = max_mate_ed[i];
+        {   /* the task as the C-ABI takes it */
+            wamd_rescue_task& t = tasks_out[i];
+            memset(&t, 0, sizeof(t));
+            const seq_desc_t& sd = desc[hit_seq_id[i]];
+            t.mate_read_idx = mate_read_idx[i];
+            t.hit_pos = hit_pos[i];
+            t.distance_threshold = distanceThreshold;
+            t.seq_lo = (uint32_t)(sd.pos_in_ref_seq + SEPARATE_N_LEN / 2);
+            t.seq_hi = (uint32_t)hit_seq_id[i] + 1 < n_seq
+                           ? (uint32_t)(desc[hit_seq_id[i] + 1].pos_in_ref_seq + SEPARATE_N_LEN / 2)
+                           : (uint32_t)(sd.pos_in_ref_seq + sd.size + 2 * SEPARATE_N_LEN);
+            t.seq_delta = (int32_t)((int64_t)sd.no_initial_Ns - (int64_t)sd.no_starting_Ns + 1 - (int64_t)sd.pos_in_ref_seq);
+            t.ref_size = (int32_t)(sd.size + sd.no_final_Ns + sd.no_initial_Ns);
+            t.max_mate_edit_distance = (uint16_t)max_mate_edit_distance;
+            t.hit_num_events = hit_num_events[i];
+            t.paired_dir_direct = paired_dir_direct[i];
+        }
+        LevMyers* lm = (len < 256) ? ((len < 128) ? v.m128.get() : v.m256.get()) : v.m64.get();   /* :331-337 */
+        ref_pos_t start_pos = (paired_dir == genome_t::direct) ? (hit_pos[i] + len - distanceThreshold)
+                                                               : (hit_pos[i] + 1 - max_mate_edit_distance);   /* :392-394 */
+        uint32_t edit_distance;
+        ref_pos_t relative_end_pos;
+        lm->preprocessRawSeq(seq, len, paired_dir);
+        bool ok = lm->dynamicProgramming(start_pos, distanceThreshold + 2 * max_mate_edit_distance, max_mate_edit_distance,
+                                         relative_end_pos, edit_distance);
+        if (!ok)
+            continue;
+        o.aligned = 1;
+        if (paired_dir == genome_t::direct)
+            gen->copy_direct(read_codes.data() + 1, seq, len);
+        else
+            gen->convert_to_rev_comp(read_codes.data() + 1, seq, len);
+        gen->ref_copy_direct(ref_codes.data(), const_cast<uint8_t*>(genome), start_pos,
+                             distanceThreshold + 2 * max_mate_edit_distance);
+        uchar_t* ext_cigar;
+        double affine_score;
+        uint32_t num_events;
+        pool.Reserve(ext_cigar);
+        ref_pos_t relative_begin_pos = lm->getExtCigar(ext_cigar, ref_codes.data(), read_codes.data(), nullptr, relative_end_pos,
+                                                        edit_distance, len, paired_dir, model.getScoring(), affine_score,
+                                                        num_events);
+        if (box.params.enable_short_indel_refinement)
+            gen->refine_ext_cigar(ext_cigar, ref_codes.data() + relative_begin_pos, edit_distance, num_events, affine_score);
+        uint32_t paired_raw_pos = start_pos + relative_begin_pos;
+        o.pos = paired_raw_pos;
+        o.cigar_events = num_events;
+        std::string paired_ref_seq_name;
+        int32_t paired_ref_seq_pos = 0, paired_ref_seq_id = 0;
+        bool pushed = false;
+        if (desc.Translate(paired_raw_pos, paired_ref_seq_name, paired_ref_seq_pos, paired_ref_seq_id, name)) {
+            o.ref_seq_pos = paired_ref_seq_pos;
+            if (num_events <= max_mate_edit_distance / 2 && hit_seq_id[i] == paired_ref_seq_id &&
+                hit_num_events[i] <= max_mate_edit_distance / 2) {
+                candidate_mapping_t paired_mapping =
+                    candidate_mapping_t::construct<mapping_type_t::lev>(paired_raw_pos, paired_dir, edit_distance);
+                mapping_desc_t mate_hit(paired_mapping, paired_ref_seq_id, paired_ref_seq_pos, (uint16_t)len, ext_cigar,
+                                        box.params.gap_del_open, box.params.gap_del_extend, box.params.gap_ins_open,
+                                        box.params.gap_ins_extend, box.params.mismatch_score);
+                mate_hit.method = MatchingMethod::Enumeration::LevMyers;
+                mate_hit.ref_length = relative_end_pos - relative_begin_pos;
+                mate_hit.score = affine_score;
+                mate_hit.score_type = ScoringType::Affine;
+                clip.clipIllegalPositions(mate_hit, model.getScoring(), desc.GetDescription(), pool);
+                if (prm->enable_boundary_clipping)
+                    clip.clipBoundaryPositions(mate_hit, model.getScoring());
+                o.ok = 1;
+                o.score = mate_hit.score;
+                o.ref_seq_pos = mate_hit.ref_seq_pos;
+                o.ref_length = mate_hit.ref_length;
+                o.err_edit_distance = mate_hit.err_edit_distance;
+                o.left_clipping = mate_hit.left_clipping;
+                o.right_clipping = mate_hit.right_clipping;
+                o.ext_cigar_len = (uint32_t)strlen((const char*)mate_hit.ext_cigar);
+                if (o.ext_cigar_len + 1 > ext_stride)
+                    return WAMD_ERR_INVALID_ARG;
+                memcpy(ec, mate_hit.ext_cigar, o.ext_cigar_len + 1);
+                pool.Free(mate_hit.ext_cigar);
+                pushed = true;
+            }
+        }
+        if (!pushed)
+            pool.Free(ext_cigar);
+    }
+    return WAMD_OK;
+}

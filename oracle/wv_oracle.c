@@ -2649,3 +2649,71 @@ int wo_result_groups_batch(uint32_t n_tasks, const wamd_commit_task* tasks, cons
     free(h);
     return rc;
 }
+
+/* ---- find_pairs<LevMyers>'s chain per hit (sam_matching.cpp:379-457) -----------------------------------------------
+ * The mate of a hit aligned in the window the insert-size model allows, made a mapping_desc_t, clipped. */
+int wo_rescue_mates_batch(const uint8_t* genome, const uint8_t* reads, const uint64_t* offsets, const uint32_t* lens,
+                          const wamd_rescue_task* tasks, uint32_t n, const wamd_rescue_params* prm, const wamd_scoring* sc,
+                          wamd_rescue_result* results, uint8_t* ext_cigars, uint32_t ext_stride)
+{
+    int rc = 0;
+    for (uint32_t i = 0; i < n && !rc; ++i) {
+        const wamd_rescue_task* t = &tasks[i];
+        wamd_rescue_result* o = &results[i];
+        uint8_t* ec = ext_cigars + (size_t)i * ext_stride;
+        const uint32_t m = lens[t->mate_read_idx];
+        const uint32_t k = t->max_mate_edit_distance;
+        memset(o, 0, sizeof(*o));
+        ec[0] = 0;
+        wamd_dist_task dt;
+        wamd_align_result ar;
+        /* :392-400, ref_pos_t arithmetic */
+        dt.read_idx = t->mate_read_idx;
+        dt.ref_pos = t->paired_dir_direct ? t->hit_pos + m - t->distance_threshold : t->hit_pos + 1u - k;
+        dt.max_distance_in_ref = t->distance_threshold + 2u * k;
+        dt.max_ed = (uint16_t)k;
+        dt.variant = WAMD_VARIANT_AUTO;
+        dt.flags = t->paired_dir_direct ? 0 : WAMD_TASK_FLAG_REV_COMP;
+        rc = wo_align_batch(genome, reads, offsets, lens, WAMD_READS_ASCII, &dt, 1, 0,
+                            (int)prm->enable_short_indel_refinement, 16384, sc, &ar, ec, ext_stride);
+        if (rc)
+            break;
+        if (!ar.ok) {   /* :402 */
+            ec[0] = 0;
+            continue;
+        }
+        o->aligned = 1;
+        o->pos = dt.ref_pos + ar.begin_pos;                                     /* :422 */
+        o->cigar_events = ar.num_events;
+        o->ref_seq_pos = (int32_t)((int64_t)o->pos + t->seq_delta);            /* ref_desc.cpp:109-115 */
+        const uint32_t p1 = o->pos + 1u;
+        const int same_seq = p1 > t->seq_lo && p1 <= t->seq_hi;                /* Translate gives the hit's chromosome */
+        if (!(same_seq && ar.num_events <= k / 2 && t->hit_num_events <= k / 2)) {   /* :424-427; the ext-CIGAR is freed */
+            ec[0] = 0;
+            continue;
+        }
+        o->ok = 1;
+        wamd_clip_record rec;
+        memset(&rec, 0, sizeof(rec));
+        rec.ref_seq_pos = o->ref_seq_pos;
+        rec.ref_length = (uint16_t)(ar.end_pos - ar.begin_pos);                /* :439 */
+        rec.err_edit_distance = (uint16_t)(ar.edit_distance + (ar.refined ? 1u : 0u));   /* construct<lev>(.., edit_distance) */
+        rec.score = ar.affine_score;                                           /* :442 */
+        wamd_clip_illegal_task it;
+        it.ref_size = t->ref_size;
+        it.read_length = (uint16_t)m;
+        it.perfect = 0;
+        if (wo_clip_illegal(&rec, &it, ec, ext_stride, sc))                    /* :445 */
+            rc = WAMD_ERR_INVALID_ARG;
+        if (prm->enable_boundary_clipping)                                     /* :447-450 */
+            wo_clip_boundary(&rec, ec, sc);
+        o->score = rec.score;
+        o->ref_seq_pos = rec.ref_seq_pos;
+        o->ref_length = rec.ref_length;
+        o->err_edit_distance = rec.err_edit_distance;
+        o->left_clipping = rec.left_clipping;
+        o->right_clipping = rec.right_clipping;
+        o->ext_cigar_len = (uint32_t)strlen((const char*)ec);
+    }
+    return rc;
+}

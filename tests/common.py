@@ -945,3 +945,106 @@ def with_reverse_reads(reads):
         out.append(c[:int(lens[i])])
     rc = [synth.rev_comp(torch.from_numpy(c.copy())).numpy() for c in out]
     return mixed_reads(out + rc, 0)
+
+
+# ---- find_pairs<LevMyers>'s chain per hit (sam_matching.cpp:379-457) ---------------------------------------------------
+RESCUE_MODEL = (330.0, 12.0)       # mean, deviation: distanceThreshold = (ref_pos_t)(mean + 7 dev) = 414
+
+
+def rescue_workload(n, seed, m=150, gen=None, frac=0.09):
+    """Hits of one read of a pair and the mate the rescue looks for beside them: mates with substitutions, short
+    indels, the refinement pattern, junk ends (boundary clipping), too many events (the num_events test), nothing to
+    find; hits whose mate lies over the chromosome's end (clipIllegalPositions), in the separator or in the next
+    chromosome (Translate's verdict), hits that themselves have too many events.  Returns (genome, mate reads as
+    ASCII codes (blob, off, lens), chromosome table, and per task: mate_read_idx, hit_pos, hit_seq_id, hit_num_events,
+    paired_dir_direct, max_mate_edit_distance)."""
+    import torch
+    codes, packed = gen if gen is not None else genome()
+    G = codes.numel()
+    desc = chromosomes(G)
+    g = torch.Generator().manual_seed(seed)
+    thr = int(RESCUE_MODEL[0] + 7.0 * RESCUE_MODEL[1])
+    k = int(m * frac) * 2
+
+    def rnd(lo, hi):
+        return int(torch.randint(lo, hi, (1,), generator=g))
+
+    clean = codes.clone()
+    clean[clean > 3] = 0
+    reads = []
+    hit_pos, seq_id, events, direct = np.zeros(n, np.uint32), np.zeros(n, np.int32), np.zeros(n, np.uint16), np.zeros(n, np.uint8)
+    for i in range(n):
+        kind = i % 12
+        c = rnd(0, 3)
+        c_pos, c_size = int(desc[c, 1]), int(desc[c, 0])
+        isize = rnd(m + 40, thr - 4)
+        mate_direct = bool(rnd(0, 2))
+        x = c_pos + rnd(1000, c_size - 2000)              # the mate's first base
+        if kind == 9:                                      # over the end of the chromosome: clipped, still this chromosome
+            x = c_pos + c_size - m + rnd(1, 40)
+        elif kind == 10:                                   # begins in the separator behind it / in the next chromosome
+            x = c_pos + c_size + rnd(SEPARATE_N_LEN // 2 - 60, SEPARATE_N_LEN // 2 + 200) if c < 2 else x
+        src = clean[x:x + m + 8].clone()
+        if len(src) < m + 8:
+            src = torch.cat([src, torch.zeros(m + 8 - len(src), dtype=torch.uint8)])
+        q = src[:m].clone()
+        if kind in (0, 1, 9, 10):
+            for _ in range(rnd(0, 6)):
+                z = rnd(0, m)
+                q[z] = (int(q[z]) + rnd(1, 4)) & 3
+        elif kind == 2:                                    # a short deletion / insertion
+            z = rnd(10, m - 20)
+            q = torch.cat([src[:z], src[z + 2:m + 2]]) if rnd(0, 2) else torch.cat([src[:z], torch.tensor([rnd(0, 4)], dtype=torch.uint8), src[z:m - 1]])
+        elif kind == 3:                                    # 1I2M1D: what refine_ext_cigar rewrites
+            z = rnd(10, m - 20)
+            y = (int(src[z + 3]) + 1) & 3
+            q = torch.cat([src[:z], torch.tensor([y], dtype=torch.uint8), src[z:z + 2], src[z + 3:]])[:m]
+        elif kind == 4:                                    # junk ends
+            cj = rnd(8, 24)
+            if rnd(0, 2):
+                q[:cj] = torch.randint(0, 4, (cj,), generator=g, dtype=torch.uint8)
+            else:
+                q[m - cj:] = torch.randint(0, 4, (cj,), generator=g, dtype=torch.uint8)
+        elif kind == 5:                                    # many scattered indels: aligned, but too many events
+            out, z = [], 0
+            for _ in range(k // 2 + 2):
+                step = rnd(4, 9)
+                out.append(src[z:z + step])
+                z += step + 1                              # one deleted base each
+            out.append(src[z:])
+            q = torch.cat(out)[:m]
+        elif kind == 6:                                    # nothing to find
+            q = torch.randint(0, 4, (m,), generator=g, dtype=torch.uint8)
+        elif kind == 7:                                    # many substitutions: within the distance, few events
+            for z in range(5, m, 9):
+                q[z] = (int(q[z]) + 1) & 3
+        q = q[:m].clone()
+        reads.append(q if mate_direct else synth.rev_comp(q))
+        direct[i] = mate_direct
+        # the hit: leftmost base of its span (what the window formulas of :392-394 assume)
+        hit_pos[i] = x + isize - m if mate_direct else x - (isize - m)
+        seq_id[i] = c
+        events[i] = rnd(0, 4) if kind != 8 else k // 2 + rnd(1, 4)     # kind 8: the hit itself has too many events
+    blob, off, lens = mixed_reads(reads, 1)
+    return (codes, packed), (blob, off, lens), desc, np.arange(n, dtype=np.uint32), hit_pos, seq_id, events, direct, \
+        np.full(n, k, np.uint16)
+
+
+def rescue_tasks(desc, mate, hit_pos, seq_id, events, direct, k, model=RESCUE_MODEL):
+    """wamd_rescue_task as a host would fill it from its chromosome table (ref_desc.cpp:81-118)."""
+    from oracle import bindings as ob
+    n = len(mate)
+    t = np.zeros(n, ob.RESCUE_TASK)
+    d = desc.astype(np.int64)
+    t["mate_read_idx"] = mate
+    t["hit_pos"] = hit_pos
+    t["distance_threshold"] = int(model[0] + 7.0 * model[1])
+    t["seq_lo"] = d[seq_id, 1] + SEPARATE_N_LEN // 2
+    nxt = np.minimum(seq_id + 1, len(d) - 1)
+    t["seq_hi"] = np.where(seq_id + 1 < len(d), d[nxt, 1] + SEPARATE_N_LEN // 2, d[seq_id, 1] + d[seq_id, 0] + 2 * SEPARATE_N_LEN)
+    t["seq_delta"] = d[seq_id, 2] - d[seq_id, 4] + 1 - d[seq_id, 1]
+    t["ref_size"] = d[seq_id, 0] + d[seq_id, 3] + d[seq_id, 2]
+    t["max_mate_edit_distance"] = k
+    t["hit_num_events"] = events
+    t["paired_dir_direct"] = direct
+    return t

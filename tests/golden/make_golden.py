@@ -149,6 +149,26 @@ def make_finish(ref, codes, packed, ref_size):
     print("finish_m150_frompair methods", np.bincount(res["method"], minlength=27), "not finished", int((res["ok"] == 0).sum()))
 
 
+def make_rescue(ref, codes, packed, ref_size):
+    """find_pairs<LevMyers>'s chain per hit (sam_matching.cpp:379-457): the reference's own statements on its own
+    objects (oracle/ref_shim.cpp: ref_rescue_mates_batch) - preprocessRawSeq, dynamicProgramming, getExtCigar,
+    refine_ext_cigar, Translate, the mate's mapping_desc_t, clipIllegalPositions, clipBoundaryPositions.  `tasks` is
+    what the GPU entry point takes."""
+    for name, n, seed, m, scn in (("rescue_m150", 600, 8300, 150, None), ("rescue_m100_sc_odd", 300, 8301, 100, "odd")):
+        sc = common.scoring(scn) if scn else bindings.default_scoring()
+        (_, _), (blob, off, lens), desc, mate, hit_pos, seq_id, events, direct, k = common.rescue_workload(
+            n, seed, m, gen=(codes, packed))
+        rc, tasks, res, ext = ref.rescue_mates(packed, ref_size, desc, blob, off, lens, mate, hit_pos, seq_id, events, direct, k,
+                                               scoring=sc, model=common.RESCUE_MODEL, ext_stride=512)
+        assert rc == 0
+        w = (int(res["ext_cigar_len"].max()) + 4) // 4 * 4
+        extra = {} if scn is None else {"scoring": np.array(common.SCORING_VALUES[scn])}
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), kind="rescue", packed=packed, ref_size=np.uint32(ref_size),
+                            blob=blob, off=off, lens=lens, desc=desc, tasks=tasks, results=res, ext=ext[:, :w], **extra)
+        print(name, "ok", int(res["ok"].sum()), "aligned", int(res["aligned"].sum()), "clipped",
+              int(((res["left_clipping"] > 0) | (res["right_clipping"] > 0)).sum()))
+
+
 def make_groups(ref):
     """Verified candidates -> committed mappings -> result-group bytes, by the reference's construct<lev>, better,
     CMappingsHeapGatherer and CMappingResultsCollector::Push (oracle/ref_shim.cpp: ref_commit_batch,
@@ -379,6 +399,9 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "finish":
         make_finish(ref, codes, packed, ref_size)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "rescue":
+        make_rescue(ref, codes, packed, ref_size)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "saloop":
         make_sa_loops(ref)

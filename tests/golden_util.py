@@ -19,7 +19,7 @@ def cases(kind):
             continue
         prefix = {"distance": "dist_", "levdiag": "lev_", "align": "align_", "indel": "indel_",
                   "clip": "clip_", "cf": "cf_", "samcigar": "samcigar_", "clipillegal": "clipillegal_",
-                  "clippairs": "clippairs_", "softclip": "softclip_", "finish": "finish_", "groups": "groups_", "saloop": "saloop_"}[kind]
+                  "clippairs": "clippairs_", "softclip": "softclip_", "finish": "finish_", "groups": "groups_", "saloop": "saloop_", "rescue": "rescue_"}[kind]
         if name.startswith(prefix):
             out.append(name)
     return out

@@ -92,6 +92,19 @@ COMMIT_TASK = np.dtype([("lev_pos", "<u4"), ("lev_errors", "<u4"), ("max_mismatc
 assert COMMIT_TASK.itemsize == 16
 
 
+RESCUE_TASK = np.dtype([("mate_read_idx", "<u4"), ("hit_pos", "<u4"), ("distance_threshold", "<u4"), ("seq_lo", "<u4"),
+                        ("seq_hi", "<u4"), ("seq_delta", "<i4"), ("ref_size", "<i4"), ("max_mate_edit_distance", "<u2"),
+                        ("hit_num_events", "<u2"), ("paired_dir_direct", "u1"), ("reserved", "u1", (3,))])
+RESCUE_RESULT = np.dtype([("score", "<f8"), ("ok", "<u4"), ("aligned", "<u4"), ("pos", "<u4"), ("ref_seq_pos", "<i4"),
+                          ("ref_length", "<u2"), ("err_edit_distance", "<u2"), ("left_clipping", "<u2"),
+                          ("right_clipping", "<u2"), ("ext_cigar_len", "<u4"), ("cigar_events", "<u4")])
+assert RESCUE_TASK.itemsize == 36 and RESCUE_RESULT.itemsize == 40
+
+
+class RescueParams(C.Structure):
+    _fields_ = [("enable_short_indel_refinement", C.c_uint32), ("enable_boundary_clipping", C.c_uint32)]
+
+
 class SaBatch(C.Structure):
     """wamd_sa_batch: what a stage of the suffix-array loops holds fixed (mapping_core_sa.cpp:193-348)."""
     _fields_ = [("read_first", C.c_uint32), ("n_reads", C.c_uint32), ("reverse_read_offset", C.c_uint32),
@@ -146,7 +159,8 @@ STATUS = {0: "WAMD_OK", 1: "WAMD_ERR_INVALID_ARG", 2: "WAMD_ERR_HIP", 3: "WAMD_E
 EXPORTS = [
     "wamd_version", "wamd_last_error", "wamd_device_count", "wamd_ctx_create",
     "wamd_sa_candidates_workspace_bytes", "wamd_verify_sa_candidates_dev", "wamd_verify_sa_candidates", "wamd_host_alloc",
-    "wamd_host_free", "wamd_reads_upload_stream", "wamd_reads_refill",
+    "wamd_host_free", "wamd_reads_upload_stream", "wamd_reads_refill", "wamd_rescue_workspace_bytes", "wamd_rescue_mates",
+    "wamd_rescue_mates_dev",
     "wamd_ctx_create_dev", "wamd_ctx_destroy", "wamd_ctx_set_scoring",
     "wamd_ctx_set_max_text_len", "wamd_ctx_set_distance_mode", "wamd_ctx_set_reference_params", "wamd_ctx_stream",
     "wamd_ctx_synchronize", "wamd_ctx_take_flags", "wamd_reads_upload", "wamd_reads_free",
@@ -214,6 +228,7 @@ def lib():
         L.wamd_result_groups_workspace_bytes.restype = C.c_uint64
         L.wamd_filter_verify_workspace_bytes.restype = C.c_uint64
         L.wamd_sa_candidates_workspace_bytes.restype = C.c_uint64
+        L.wamd_rescue_workspace_bytes.restype = C.c_uint64
         _lib = L
     return _lib
 
@@ -520,6 +535,25 @@ class Context:
                                        C.c_uint32(ext_stride), _ptr(cig), C.c_uint32(cig.shape[1]), _ptr(mdz),
                                        C.c_uint32(mdz.shape[1])))
         return res, ext, cig, mdz
+
+    def rescue_mates(self, reads, tasks, params=None, ext_stride=512):
+        """find_pairs<LevMyers>'s chain per hit (sam_matching.cpp:379-457): results and the mates' ext-CIGARs."""
+        t = np.ascontiguousarray(tasks, RESCUE_TASK)
+        prm = params or RescueParams(1, 1)
+        res = np.zeros(len(t), RESCUE_RESULT)
+        ext = np.zeros((len(t), ext_stride), np.uint8)
+        _check(lib().wamd_rescue_mates(self.h, reads.h, _ptr(t), C.c_uint32(len(t)), C.byref(prm), _ptr(res), _ptr(ext),
+                                       C.c_uint32(ext_stride)))
+        return res, ext
+
+    def rescue_workspace_bytes(self, reads, n, max_ed):
+        return int(lib().wamd_rescue_workspace_bytes(reads.h, C.c_uint32(n), C.c_uint32(max_ed)))
+
+    def rescue_mates_dev(self, reads, d_tasks, n, d_results, d_ext, ext_stride, d_ws, ws_bytes, params=None, stream=None):
+        prm = params or RescueParams(1, 1)
+        _check(lib().wamd_rescue_mates_dev(self.h, reads.h, _ptr(d_tasks), C.c_uint32(n), C.byref(prm), _ptr(d_results),
+                                           _ptr(d_ext), C.c_uint32(ext_stride), _ptr(d_ws), C.c_uint64(ws_bytes),
+                                           C.c_void_p(stream or 0)))
 
     def finish_workspace_bytes(self, reads, n_pairs):
         return int(lib().wamd_finish_workspace_bytes(reads.h, C.c_uint32(n_pairs)))

@@ -346,6 +346,15 @@ int launch_post_passes(wamd_ctx* ctx, uint32_t n, const wamd_clip_illegal_task* 
                               d_cigars, cigar_stride, d_mdz, mdz_stride, nullptr, 0, d_lens, s, d_mid);
 }
 
+// clipIllegalPositions and (optionally) clipBoundaryPositions of n independent records (the mate rescue, sam_matching.cpp:444-450)
+int launch_clip_records(wamd_ctx* ctx, uint32_t n, const wamd_clip_illegal_task* d_it, wamd_clip_record* d_rec, uint8_t* d_ext,
+                        uint32_t ext_stride, const uint32_t* d_cap_hint, int do_boundary, hipStream_t s)
+{
+    WAMD_HIP(hipSetDevice(ctx->device));
+    return launch_post_kernel(ctx, n, d_it, nullptr, d_rec, d_ext, ext_stride, d_cap_hint,
+                              POST_ILLEGAL | (do_boundary ? POST_BOUNDARY : 0), nullptr, 0, nullptr, 0, nullptr, 0, nullptr, s);
+}
+
 int launch_sam_cigar(wamd_ctx* ctx, uint32_t n, const uint8_t* d_ext, uint32_t ext_stride, uint8_t* d_cigars,
                      uint32_t cigar_stride, uint8_t* d_mdz, uint32_t mdz_stride, uint32_t* d_bin, uint32_t bin_stride,
                      wamd_sam_cigar_len* d_lens, hipStream_t s)

@@ -1359,6 +1359,72 @@ int wamd_finish_pairs(wamd_ctx* ctx, const wamd_reads* reads, const wamd_finish_
     return rc ? rc : flags_to_status(flags);
 }
 
+uint64_t wamd_rescue_workspace_bytes(const wamd_reads* reads, uint32_t n, uint32_t max_mate_edit_distance)
+{
+    return reads ? rescue_workspace_bytes(reads, n, max_mate_edit_distance) : 0;
+}
+
+int wamd_rescue_mates_dev(wamd_ctx* ctx, const wamd_reads* reads, const wamd_rescue_task* d_tasks, uint32_t n,
+                          const wamd_rescue_params* params, wamd_rescue_result* d_results, uint8_t* d_ext_cigars,
+                          uint32_t ext_stride, void* d_workspace, uint64_t workspace_bytes, void* stream)
+{
+    if (n == 0)
+        return WAMD_OK;
+    int rc = check_batch(ctx, reads, d_tasks, d_results, "wamd_rescue_mates_dev");
+    if (rc)
+        return rc;
+    if (!params || !d_ext_cigars || !d_workspace || ((uintptr_t)d_workspace & 255u) ||
+        workspace_bytes < rescue_workspace_bytes(reads, n, 0)) {
+        set_error("wamd_rescue_mates_dev: missing argument, or a workspace that is not 256-byte aligned or below "
+                  "wamd_rescue_workspace_bytes");
+        return WAMD_ERR_INVALID_ARG;
+    }
+    return launch_rescue_mates(ctx, reads, d_tasks, n, params, d_results, d_ext_cigars, ext_stride, d_workspace,
+                               workspace_bytes, pick(ctx, stream));
+}
+
+int wamd_rescue_mates(wamd_ctx* ctx, const wamd_reads* reads, const wamd_rescue_task* tasks, uint32_t n,
+                      const wamd_rescue_params* params, wamd_rescue_result* results, uint8_t* ext_cigars, uint32_t ext_stride)
+{
+    if (n == 0)
+        return WAMD_OK;
+    int rc = check_batch(ctx, reads, tasks, results, "wamd_rescue_mates");
+    if (rc)
+        return rc;
+    if (!params || !ext_cigars)
+        return WAMD_ERR_INVALID_ARG;
+    WAMD_HIP(hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> hold(ctx->host_mutex);
+    auto up = [](uint64_t x) { return (x + 255) / 256 * 256; };
+    uint32_t max_ed = 0;
+    for (uint32_t i = 0; i < n; ++i)
+        max_ed = tasks[i].max_mate_edit_distance > max_ed ? tasks[i].max_mate_edit_distance : max_ed;
+    const uint64_t tb = (uint64_t)n * sizeof(wamd_rescue_task), rb = (uint64_t)n * sizeof(wamd_rescue_result),
+                   eb = (uint64_t)n * ext_stride, wb = rescue_workspace_bytes(reads, n, max_ed);
+    rc = ensure_stage(ctx, up(tb) + up(rb) + up(eb) + up(wb) + 256, 0);
+    if (rc)
+        return rc;
+    char* base = (char*)(((uintptr_t)ctx->d_stage + 255) & ~(uintptr_t)255);
+    auto* d_tasks = (wamd_rescue_task*)base;
+    auto* d_res = (wamd_rescue_result*)(base + up(tb));
+    auto* d_ext = (uint8_t*)(base + up(tb) + up(rb));
+    void* d_ws = d_ext + up(eb);
+    hipStream_t s = ctx->stream;
+    WAMD_HIP(hipMemcpyAsync(d_tasks, tasks, tb, hipMemcpyHostToDevice, s));
+    rc = wamd_rescue_mates_dev(ctx, reads, d_tasks, n, params, d_res, d_ext, ext_stride, d_ws, wb, s);
+    if (rc)
+        return rc;
+    WAMD_HIP(hipMemcpyAsync(results, d_res, rb, hipMemcpyDeviceToHost, s));
+    WAMD_HIP(hipMemcpyAsync(ext_cigars, d_ext, eb, hipMemcpyDeviceToHost, s));
+    uint32_t flags = 0;
+    rc = fetch_flags(ctx, s, &flags);
+    if (!rc && (flags & FLAG_CIGAR)) {
+        set_error("wamd_rescue_mates: an ext-CIGAR does not fit ext_stride");
+        return WAMD_ERR_INVALID_ARG;
+    }
+    return rc ? rc : flags_to_status(flags);
+}
+
 int wamd_emit_lev_records_static_dev(wamd_ctx* ctx, uint32_t n, const wamd_dist_task* d_tasks,
                                      const wamd_dist_result* d_results, const uint32_t* d_record_pos,
                                      const uint8_t* d_direction, uint8_t* d_records, uint32_t* d_count, void* stream)

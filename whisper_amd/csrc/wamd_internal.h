@@ -177,6 +177,13 @@ int launch_post_passes(wamd_ctx* ctx, uint32_t n, const wamd_clip_illegal_task* 
                        int do_boundary, int do_pairs, uint8_t* d_cigars, uint32_t cigar_stride, uint8_t* d_mdz,
                        uint32_t mdz_stride, wamd_sam_cigar_len* d_lens, int2* d_mid, hipStream_t s);
 
+int launch_clip_records(wamd_ctx* ctx, uint32_t n, const wamd_clip_illegal_task* d_it, wamd_clip_record* d_rec, uint8_t* d_ext,
+                        uint32_t ext_stride, const uint32_t* d_cap_hint, int do_boundary, hipStream_t s);
+uint64_t rescue_workspace_bytes(const wamd_reads* r, uint32_t n, uint32_t max_ed);
+int launch_rescue_mates(wamd_ctx* ctx, const wamd_reads* r, const wamd_rescue_task* d_tasks, uint32_t n,
+                        const wamd_rescue_params* prm, wamd_rescue_result* d_results, uint8_t* d_ext, uint32_t ext_stride,
+                        void* d_ws, uint64_t ws_bytes, hipStream_t s);
+
 int launch_cf_filter(wamd_ctx* ctx, const wamd_reads* r, const wamd_cf_task* d_tasks, uint32_t n,
                      uint32_t* d_results, hipStream_t s);
 
