@@ -490,8 +490,33 @@ def test_softclip_match(ctx, oracle, lowcx, fresh, enc, W):
         assert bytes(gcig[i, :n]) == bytes(wcig[i, :n]), i
 
 
+@pytest.mark.parametrize("m,W,mql", [(700, 2000, 1024), (1000, 3000, 1024), (400, 1200, 700)])
+def test_softclip_match_long_reads(oracle, m, W, mql):
+    """Reads of 700 and 1 000 symbols (tables of 32 768 and 65 536 cells, two-byte read positions): the sizes every
+    other entry point takes.  Low-complexity text as well, where chains are long and the queue is served in passes."""
+    from oracle import bindings as ob
+    for gen in (common.genome(), common.low_complexity_genome()):
+        codes, packed, (blob, off, lens), tasks = common.softclip_workload(300, seed=m + W, m=m, W=W, encoding=1, gen=gen,
+                                                                           lens_jitter=True)
+        _, want, wcig = oracle.softclip_match(packed, blob, off, lens, 1, tasks,
+                                              ob.default_softclip_params(max_query_len=mql, fresh_object=0), cigar_stride=1536)
+        c2 = api.Context(packed, ref_size=codes.numel(), cur_offset=0)
+        try:
+            reads = c2.upload_reads(blob, off, lens, 1, orientations=3)
+            got, gcig = c2.softclip_match(reads, tasks, api.default_softclip_params(max_query_len=mql, fresh_object=0),
+                                          cigar_stride=1536)
+            reads.free()
+        finally:
+            c2.destroy()
+        assert want["found"].sum() > 150
+        np.testing.assert_array_equal(got, want)
+        for i in range(len(want)):
+            n = want["cigar_len"][i] + 1
+            assert bytes(gcig[i, :n]) == bytes(wcig[i, :n]), i
+
+
 def test_softclip_match_errors(ctx, oracle):
-    """Reads shorter than one 20-mer and windows above max_text_len are errors, as is a table beyond LDS."""
+    """Reads shorter than one 20-mer and windows above max_text_len are errors, as is a table of more than 65 536 cells."""
     codes, packed, (blob, off, lens), tasks = common.softclip_workload(64, seed=3, W=300)
     reads = ctx.upload_reads(blob, off, lens, 1, orientations=3)
     bad = tasks.copy()

@@ -240,6 +240,23 @@ def test_softclip_match(oracle, reference, lowcx, fresh, enc, W):
     assert (a["no_mismatches"] > 0).sum() > 20 and (a["found"] == 0).sum() > 100
 
 
+@pytest.mark.parametrize("m,W,mql", [(700, 2000, 1024), (1000, 3000, 1024)])
+def test_softclip_match_long_reads(oracle, reference, m, W, mql):
+    """The same for reads of 700 and 1 000 symbols (max_query_len 1 024: a table of 65 536 cells), the lengths the
+    GPU path takes since round 3 - the oracle's table follows the reference's there as well."""
+    from oracle import bindings as ob
+    for gen in (None, common.low_complexity_genome()):
+        codes, packed, (blob, off, lens), tasks = common.softclip_workload(200, seed=m + W, m=m, W=W, encoding=1, gen=gen,
+                                                                           lens_jitter=True)
+        prm = ob.default_softclip_params(max_query_len=mql, fresh_object=0)
+        rc1, a, ca = oracle.softclip_match(packed, blob, off, lens, 1, tasks, prm, cigar_stride=1536)
+        rc2, b, cb = reference.softclip_match(packed, blob, off, lens, 1, tasks, prm, cigar_stride=1536)
+        assert rc1 == 0 and rc2 == 0
+        np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(ca, cb)
+        assert a["found"].sum() > 100
+
+
 @pytest.mark.parametrize("seed,m", [(21, 150), (22, 250), (23, 100)])
 def test_finish_pairs_chain(oracle, reference, seed, m):
     """The chosen pair from its wire records to the SAM fields (sam.cpp:1555-1580, 1871-1900, 1992-2007): the
