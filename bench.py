@@ -736,6 +736,37 @@ def run_extras(ctx, device, genome_symbols, stream, n_small, gather_cabi=False):
                     "roofline": roof_valu(count, cols_ * (dw_ * 10 + 20), ms_,
                                           "myers_distance_kernel<%d> over the whole window, then the traceback "
                                           "(its work is not in the model)" % dw_)}
+        if tag == "S3_rescue_150bp":
+            # the same hits through the one call find_pairs<LevMyers> becomes (sam_matching.cpp:379-457): window
+            # arithmetic, align, Translate's verdict, the num_events tests, the mate's record, the two clipping passes
+            thr_ = W - 2 * k
+            rt_ = np.zeros(count, api.RESCUE_TASK)
+            direct_ = t_["flags"] == 0
+            start_ = t_["ref_pos"].astype(np.int64)
+            rt_["mate_read_idx"] = t_["read_idx"]
+            rt_["hit_pos"] = np.where(direct_, start_ - m + thr_, start_ - 1 + k).astype(np.uint32)
+            rt_["distance_threshold"] = thr_
+            rt_["seq_lo"] = 0
+            rt_["seq_hi"] = genome_symbols
+            rt_["seq_delta"] = 1
+            rt_["ref_size"] = genome_symbols
+            rt_["max_mate_edit_distance"] = k
+            rt_["hit_num_events"] = 2
+            rt_["paired_dir_direct"] = direct_
+            d_rt_ = dev_bytes(rt_)
+            d_rr_ = torch.zeros(count * api.RESCUE_RESULT.itemsize, dtype=torch.uint8, device=device)
+            wsr_ = ctx.rescue_workspace_bytes(reads_, count, k)
+            d_wr_ = torch.zeros(wsr_, dtype=torch.uint8, device=device)
+            ms_c = timed(lambda: ctx.rescue_mates_dev(reads_, d_rt_, count, d_rr_, d_c_, stride_, d_wr_, wsr_),
+                         tag="N2_rescue_chain", units=count)
+            rr_ = d_rr_.cpu().numpy().view(api.RESCUE_RESULT)
+            out["N2_rescue_chain"] = {"shape": "wamd_rescue_mates_dev on S3's hits: find_pairs<LevMyers>'s chain per hit "
+                                               "(window, align in accepted-only mode, Translate, num_events, record, "
+                                               "clipIllegal / clipBoundary)", "tasks": count, "total_ms": ms_c,
+                                      "hits_per_s": count / ms_c * 1e3, "aligned_fraction": float(rr_["aligned"].mean()),
+                                      "pair_candidate_fraction": float(rr_["ok"].mean()),
+                                      "same_alignments_as_S3": bool(((rr_["aligned"] == 1) == (res_["ok"] == 1)).all())}
+            del d_rt_, d_rr_, d_wr_
         reads_.free()
 
     rescue("S3_rescue_150bp", 150, 26, 660, 83, na // 4)
