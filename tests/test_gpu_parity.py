@@ -490,10 +490,11 @@ def test_softclip_match(ctx, oracle, lowcx, fresh, enc, W):
         assert bytes(gcig[i, :n]) == bytes(wcig[i, :n]), i
 
 
-@pytest.mark.parametrize("m,W,mql", [(700, 2000, 1024), (1000, 3000, 1024), (400, 1200, 700)])
+@pytest.mark.parametrize("m,W,mql", [(700, 2000, 1024), (1000, 3000, 1024), (400, 1200, 700), (650, 12000, 655)])
 def test_softclip_match_long_reads(oracle, m, W, mql):
     """Reads of 700 and 1 000 symbols (tables of 32 768 and 65 536 cells, two-byte read positions): the sizes every
-    other entry point takes.  Low-complexity text as well, where chains are long and the queue is served in passes."""
+    other entry point takes.  Low-complexity text as well, where chains are long and the queue is served in passes; the last
+    case leaves room for two windows per wave instead of four."""
     from oracle import bindings as ob
     for gen in (common.genome(), common.low_complexity_genome()):
         codes, packed, (blob, off, lens), tasks = common.softclip_workload(300, seed=m + W, m=m, W=W, encoding=1, gen=gen,

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(64) void softclip_match_kernel(GenomeView g, ReadsV
                                                             const wamd_softclip_task* __restrict__ tasks, uint32_t n,
                                                             wamd_softclip_params prm, wamd_scoring sc,
                                                             uint32_t ht_size, uint32_t max_window, uint32_t max_len,
-                                                            uint32_t max_text_len, SliceLayout lay,
+                                                            uint32_t max_text_len, SliceLayout lay, uint32_t groups,
                                                             wamd_softclip_result* __restrict__ results,
                                                             uint8_t* __restrict__ cigars, uint32_t cigar_stride,
                                                             uint32_t* __restrict__ flags)
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(64) void softclip_match_kernel(GenomeView g, ReadsV
     constexpr uint32_t EMPTY = (uint32_t)(CELL)~(CELL)0;   // EMPTY_CELL / empty_pos_in_query in a cell
     Slice<CELL> L;
     {
-        uint8_t* base = reinterpret_cast<uint8_t*>(lds_raw) + (size_t)(lane / GROUP) * lay.bytes;
+        uint8_t* base = reinterpret_cast<uint8_t*>(lds_raw) + (size_t)min(lane / GROUP, groups - 1) * lay.bytes;
         L.occ = reinterpret_cast<uint32_t*>(base);
         L.text = reinterpret_cast<uint32_t*>(base + lay.text);
         L.query = reinterpret_cast<uint32_t*>(base + lay.query);
@@ -150,13 +150,16 @@ __global__ __launch_bounds__(64) void softclip_match_kernel(GenomeView g, ReadsV
     }
     const uint32_t ht_mask = ht_size - 1, occ_dw = lay.occ_dw;
 
-    for (uint32_t i = gl; i < occ_dw; i += GROUP)
-        L.occ[i] = 0;
+    if (lane / GROUP < groups)
+        for (uint32_t i = gl; i < occ_dw; i += GROUP)
+            L.occ[i] = 0;
     __syncthreads();
 
-    for (uint32_t first = blockIdx.x * GROUPS; first < n; first += gridDim.x * GROUPS) {
+    // (groups: how many of the wave's four groups hold a window - fewer when long reads in long windows leave no room
+    //  for four sets of arrays in LDS; the others sit idle)
+    for (uint32_t first = blockIdx.x * groups; first < n; first += gridDim.x * groups) {
         const uint32_t task = first + lane / GROUP;
-        bool live = task < n;
+        bool live = task < n && lane / GROUP < groups;
         const wamd_softclip_task t = tasks[live ? task : first];
         wamd_softclip_result res;
         res.affine_score = 0;
@@ -824,9 +827,12 @@ int launch_softclip_match(wamd_ctx* ctx, const wamd_reads* r, const wamd_softcli
         return WAMD_ERR_TOO_LONG;
     }
     const SliceLayout lay = softclip_layout(ht_size, bytes ? 1 : 2, max_window, r->max_len);
-    const uint64_t lds = (uint64_t)GROUPS * lay.bytes;
+    uint32_t groups = GROUPS;
+    while (groups > 1 && (uint64_t)groups * lay.bytes > 160 * 1024)
+        groups /= 2;
+    const uint64_t lds = (uint64_t)groups * lay.bytes;
     if (lds > 160 * 1024) {
-        set_error("wamd_softclip_match: windows of %u symbols and reads of %u need %llu bytes of LDS per wave (limit 163840)",
+        set_error("wamd_softclip_match: a window of %u symbols and a read of %u need %llu bytes of LDS (limit 163840)",
                   max_window, r->max_len, (unsigned long long)lds);
         return WAMD_ERR_TOO_LONG;
     }
@@ -836,16 +842,16 @@ int launch_softclip_match(wamd_ctx* ctx, const wamd_reads* r, const wamd_softcli
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     uint32_t per_cu = (uint32_t)((160 * 1024) / lds);
     per_cu = per_cu < 1 ? 1 : (per_cu > 16 ? 16 : per_cu);
-    const uint32_t waves = (n + GROUPS - 1) / GROUPS;
+    const uint32_t waves = (n + groups - 1) / groups;
     const uint32_t blocks = waves < 256u * per_cu ? waves : 256u * per_cu;
     if (bytes)
         hipLaunchKernelGGL(softclip_match_kernel<uint8_t>, dim3(blocks), dim3(64), (uint32_t)lds, s, genome_view(ctx),
                            r->view(), d_tasks, n, *prm, ctx->scoring, ht_size, max_window, r->max_len,
-                           ctx->max_text_len, lay, d_results, d_cigars, cigar_stride, ctx->d_flags);
+                           ctx->max_text_len, lay, groups, d_results, d_cigars, cigar_stride, ctx->d_flags);
     else
         hipLaunchKernelGGL(softclip_match_kernel<uint16_t>, dim3(blocks), dim3(64), (uint32_t)lds, s, genome_view(ctx),
                            r->view(), d_tasks, n, *prm, ctx->scoring, ht_size, max_window, r->max_len,
-                           ctx->max_text_len, lay, d_results, d_cigars, cigar_stride, ctx->d_flags);
+                           ctx->max_text_len, lay, groups, d_results, d_cigars, cigar_stride, ctx->d_flags);
     WAMD_HIP(hipGetLastError());
     return WAMD_OK;
 }
