@@ -119,9 +119,12 @@ __global__ __launch_bounds__(BLOCK) void levdiag_kernel(GenomeView g, ReadsView 
                                                         const wamd_levdiag_task* __restrict__ tasks, uint32_t n,
                                                         uint32_t ref_size, uint32_t cur_offset,
                                                         uint32_t* __restrict__ results, uint32_t* __restrict__ flags,
-                                                        int chained, const uint32_t* __restrict__ n_dev)
+                                                        int chained, const uint32_t* __restrict__ n_dev,
+                                                        const uint32_t* __restrict__ only_deferred)
 {
     constexpr int GW = PW + 2;
+    if (only_deferred && *only_deferred == 0)   // the banded kernel left nothing
+        return;
     __shared__ uint32_t pat_lds[PW * BLOCK];   // [dword][lane]: pad, read symbols, pad
     __shared__ uint32_t gen_lds[GW * BLOCK];   // [dword][lane]: pad, window of m + 2k + 1 symbols, pad
 
@@ -523,7 +526,8 @@ template <int NW, int BLOCK, bool PF>
 __device__ __forceinline__ void levdiag_band_body(const GenomeView& g, const ReadsView& rv,
                                                              const wamd_levdiag_task* __restrict__ tasks, uint32_t n,
                                                              uint32_t ref_size, uint32_t cur_offset,
-                                                             uint32_t* __restrict__ results, uint32_t* __restrict__ flags, uint32_t* pm_lds)
+                                                             uint32_t* __restrict__ results, uint32_t* __restrict__ flags, uint32_t* pm_lds,
+                                                             uint32_t* __restrict__ deferred)
 {
     constexpr int ROWS = NW + 2 * LDB_PAD;
 
@@ -655,6 +659,9 @@ __device__ __forceinline__ void levdiag_band_body(const GenomeView& g, const Rea
     }
     if (valid)
         results[gid] = (odd & read_odd) ? LD_DEFERRED : (alive ? (uint32_t)(ep + es) : k + 1);
+    // the run-extension kernel behind this one only asks "any?": one word, written by the waves that still read 0
+    if (deferred && __any(valid && (odd & read_odd)) && (tid & 63u) == 0 && *reinterpret_cast<volatile uint32_t*>(deferred) == 0)
+        *reinterpret_cast<volatile uint32_t*>(deferred) = 1u;
 }
 
 // 90 VGPRs: five waves per SIMD, which is also what the planes' LDS allows at 160 symbols (four at 256)
@@ -663,7 +670,7 @@ __global__ __launch_bounds__(BLOCK) void levdiag_band_kernel(GenomeView g, Reads
                                                              const wamd_levdiag_task* __restrict__ tasks, uint32_t n,
                                                              uint32_t ref_size, uint32_t cur_offset,
                                                              uint32_t* __restrict__ results, uint32_t* __restrict__ flags,
-                                                             const uint32_t* __restrict__ n_dev)
+                                                             const uint32_t* __restrict__ n_dev, uint32_t* __restrict__ deferred)
 {
     __shared__ uint32_t pm_lds[(NW + 2 * LDB_PAD) * 3 * BLOCK];
     if (n_dev) {
@@ -671,28 +678,29 @@ __global__ __launch_bounds__(BLOCK) void levdiag_band_kernel(GenomeView g, Reads
         if (blockIdx.x * BLOCK >= n)
             return;
     }
-    levdiag_band_body<NW, BLOCK, true>(g, rv, tasks, n, ref_size, cur_offset, results, flags, pm_lds);
+    levdiag_band_body<NW, BLOCK, true>(g, rv, tasks, n, ref_size, cur_offset, results, flags, pm_lds, deferred);
 }
 template <int NW, int BLOCK>
 static int launch_ld_band(wamd_ctx* ctx, const wamd_reads* r, const wamd_levdiag_task* d_tasks, uint32_t n,
-                          uint32_t* d_results, hipStream_t s, const uint32_t* n_dev)
+                          uint32_t* d_results, hipStream_t s, const uint32_t* n_dev, uint32_t* deferred)
 {
     const uint32_t blocks = (n + BLOCK - 1) / BLOCK;
     hipLaunchKernelGGL((levdiag_band_kernel<NW, BLOCK>), dim3(blocks), dim3(BLOCK), 0, s, genome_view(ctx), r->view(),
-                       d_tasks, n, ctx->ref_size, ctx->cur_offset, d_results, ctx->d_flags, n_dev);
+                       d_tasks, n, ctx->ref_size, ctx->cur_offset, d_results, ctx->d_flags, n_dev, deferred);
     WAMD_HIP(hipGetLastError());
     return WAMD_OK;
 }
 
 template <int PW, int BLOCK>
 static int launch_ld(wamd_ctx* ctx, const wamd_reads* r, const wamd_levdiag_task* d_tasks, uint32_t n,
-                     uint32_t* d_results, hipStream_t s, const uint32_t* n_dev, int chained = 0)
+                     uint32_t* d_results, hipStream_t s, const uint32_t* n_dev, int chained = 0,
+                     const uint32_t* only_deferred = nullptr)
 {
     uint32_t blocks = (n + BLOCK - 1) / BLOCK;
     if (chained && blocks > 1024)
         blocks = 1024;
     hipLaunchKernelGGL((levdiag_kernel<PW, BLOCK>), dim3(blocks), dim3(BLOCK), 0, s, genome_view(ctx), r->view(),
-                       d_tasks, n, ctx->ref_size, ctx->cur_offset, d_results, ctx->d_flags, chained, n_dev);
+                       d_tasks, n, ctx->ref_size, ctx->cur_offset, d_results, ctx->d_flags, chained, n_dev, only_deferred);
     WAMD_HIP(hipGetLastError());
     return WAMD_OK;
 }
@@ -706,18 +714,22 @@ int launch_levdiag(wamd_ctx* ctx, const wamd_reads* r, const wamd_levdiag_task* 
     // staged dwords per lane: read symbols / 8 plus a pad dword at either end
     const uint32_t need = (r->max_len + 7) / 8 + 2;
     // reads up to 256 symbols, uploaded in the direct orientation: the banded bit-vector kernel, then the
-    // run-extension kernel for the lanes it deferred (none in practice: 16 us)
+    // run-extension kernel for the lanes it deferred (none in practice: it leaves at once on the band kernel's word)
     const bool band = (r->orientations & 1) && r->max_len <= 256 && !(ctx->test_hooks & HOOK_LEVDIAG_RUNS);
+    uint32_t* deferred = nullptr;   // (the word is the stream's first of myers_distance.hip's pair: launches on a stream are ordered)
     if (band) {
-        int rc = r->words32 <= 5 ? launch_ld_band<5, 128>(ctx, r, d_tasks, n, d_results, s, n_dev)
-                                 : launch_ld_band<8, 128>(ctx, r, d_tasks, n, d_results, s, n_dev);
+        deferred = band_flags(ctx, s);
+        if (deferred)
+            WAMD_HIP(hipMemsetAsync(deferred, 0, sizeof(uint32_t), s));
+        int rc = r->words32 <= 5 ? launch_ld_band<5, 128>(ctx, r, d_tasks, n, d_results, s, n_dev, deferred)
+                                 : launch_ld_band<8, 128>(ctx, r, d_tasks, n, d_results, s, n_dev, deferred);
         if (rc)
             return rc;
     }
     if (need <= 22)
-        return launch_ld<22, 256>(ctx, r, d_tasks, n, d_results, s, n_dev, band);   // reads up to 160 symbols
+        return launch_ld<22, 256>(ctx, r, d_tasks, n, d_results, s, n_dev, band, deferred);   // reads up to 160 symbols
     if (need <= 34)
-        return launch_ld<34, 128>(ctx, r, d_tasks, n, d_results, s, n_dev, band);   // up to 256
+        return launch_ld<34, 128>(ctx, r, d_tasks, n, d_results, s, n_dev, band, deferred);   // up to 256
     if (need <= 66)
         return launch_ld<66, 64>(ctx, r, d_tasks, n, d_results, s, n_dev);    // up to 512
     return launch_ld<130, 64>(ctx, r, d_tasks, n, d_results, s, n_dev);       // up to 1024

@@ -1043,7 +1043,7 @@ static int launch_exact(const GenomeView& g, const ReadsView& rv, const wamd_dis
 // The pair of "something was deferred" flags of a stream: a stream keeps the pair it was given at
 // its first accepted-only launch (launches on one stream are ordered, so they may share it).
 // nullptr once BAND_SLOTS streams have been seen: the chain then runs without the early-out.
-static uint32_t* band_flags(wamd_ctx* ctx, hipStream_t s)
+uint32_t* band_flags(wamd_ctx* ctx, hipStream_t s)
 {
     while (__sync_lock_test_and_set(&ctx->band_lock, 1)) {
     }

@@ -202,6 +202,9 @@ int launch_sam_cigar(wamd_ctx* ctx, uint32_t n, const uint8_t* d_ext, uint32_t e
                      uint32_t cigar_stride, uint8_t* d_mdz, uint32_t mdz_stride, uint32_t* d_bin, uint32_t bin_stride,
                      wamd_sam_cigar_len* d_lens, hipStream_t s);
 
+// a stream's pair of "something was left to the next kernel of the chain" words (myers_distance.hip); nullptr when
+// more streams than there are pairs have asked
+uint32_t* band_flags(wamd_ctx* ctx, hipStream_t s);
 int launch_softclip_match(wamd_ctx* ctx, const wamd_reads* r, const wamd_softclip_task* d_tasks, uint32_t n,
                           const wamd_softclip_params* prm, uint32_t max_window, wamd_softclip_result* d_results,
                           uint8_t* d_cigars, uint32_t cigar_stride, hipStream_t s);
