@@ -771,6 +771,14 @@ int wamd_verify_sa_candidates(wamd_ctx* ctx, const wamd_reads* reads, const wamd
         return rc;
     uint32_t r0 = 0, c0 = 0, chunk = 0;
     uint64_t seen = 0;
+    // (an error inside the loop must not return past the synchronisation below: copies into the caller's buffers
+    //  may still be on their way)
+#define PIPE_HIP(call)                                                                  \
+    do {                                                                                \
+        hipError_t e_ = (call);                                                         \
+        if (e_ != hipSuccess && !rc)                                                    \
+            rc = ::wamd::hip_fail(e_, #call, __FILE__, __LINE__);                       \
+    } while (0)
     while (r0 < batch->n_reads) {
         uint32_t r1 = r0, c = 0;
         while (r1 < batch->n_reads && r1 - r0 < CHUNK_R && c < CHUNK_C) {
@@ -786,26 +794,31 @@ int wamd_verify_sa_candidates(wamd_ctx* ctx, const wamd_reads* reads, const wamd
             wamd_sa_batch b = *batch;
             b.read_first = batch->read_first + r0;
             b.n_reads = r1 - r0;
-            WAMD_HIP(hipMemcpyAsync(slot + o_counts, counts + 2 * (uint64_t)r0, (uint64_t)(r1 - r0) * 4, hipMemcpyHostToDevice, st));
-            WAMD_HIP(hipMemcpyAsync(slot + o_pos, sa_positions + c0, (uint64_t)c * 4, hipMemcpyHostToDevice, st));
+            PIPE_HIP(hipMemcpyAsync(slot + o_counts, counts + 2 * (uint64_t)r0, (uint64_t)(r1 - r0) * 4, hipMemcpyHostToDevice, st));
+            PIPE_HIP(hipMemcpyAsync(slot + o_pos, sa_positions + c0, (uint64_t)c * 4, hipMemcpyHostToDevice, st));
             if (read_max_mismatches)
-                WAMD_HIP(hipMemcpyAsync(slot + o_k, read_max_mismatches + r0, r1 - r0, hipMemcpyHostToDevice, st));
+                PIPE_HIP(hipMemcpyAsync(slot + o_k, read_max_mismatches + r0, r1 - r0, hipMemcpyHostToDevice, st));
+            if (rc)
+                break;
             rc = launch_sa_candidates(ctx, reads, &b, (const uint16_t*)(slot + o_counts),
                                       read_max_mismatches ? (const uint8_t*)(slot + o_k) : nullptr, (const uint32_t*)(slot + o_pos), c,
                                       (uint8_t*)(slot + o_err), end_positions ? (uint32_t*)(slot + o_end) : nullptr,
                                       slot + o_ws, st);
             if (rc)
                 break;
-            WAMD_HIP(hipMemcpyAsync(errors + c0, slot + o_err, c, hipMemcpyDeviceToHost, st));
+            PIPE_HIP(hipMemcpyAsync(errors + c0, slot + o_err, c, hipMemcpyDeviceToHost, st));
             if (end_positions)
-                WAMD_HIP(hipMemcpyAsync(end_positions + c0, slot + o_end, (uint64_t)c * 4, hipMemcpyDeviceToHost, st));
+                PIPE_HIP(hipMemcpyAsync(end_positions + c0, slot + o_end, (uint64_t)c * 4, hipMemcpyDeviceToHost, st));
+            if (rc)
+                break;
             ++chunk;
         }
         r0 = r1;
         c0 += c;
     }
     for (hipStream_t ps : ctx->pipe)
-        WAMD_HIP(hipStreamSynchronize(ps));
+        PIPE_HIP(hipStreamSynchronize(ps));
+#undef PIPE_HIP
     if (rc)
         return rc;
     if (seen != n_candidates) {
