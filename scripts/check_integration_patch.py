@@ -3,7 +3,7 @@
 
 What this does: builds a scratch tree OUTSIDE the repository (a temporary directory) whose
 files are symlinks into /root/reference/src, except the five files the patch touches, which
-are copied there and edited at the lines INTEGRATION.md sections 3 and 4 name; then compiles the
+(six in the per-bin form) are copied there and edited at the lines INTEGRATION.md sections 3 and 4 name; then compiles the
 patched translation units with g++ (-fsyntax-only, the flags of the reference's makefile)
 against whisper_amd/host/gpu_verifier.hpp and include/whisper_amd.h.
 
@@ -22,7 +22,8 @@ Two forms of the patch are compiled, each in its own scratch tree:
              form of wamd_verify_sa_candidates: the CF pre-filter runs on the device), process_reads keeps one
              record per read of the bin, the bin is flushed ONCE behind its read loop, and what the loop did
              with a read's answers (Push, best_error, pass_read - mapping_core.cpp:973-1036) runs read by read
-             afterwards, in the same order.  Suffix-array ranges a malicious group takes stay on the host path.
+             afterwards, in the same order.  A malicious group's q-gram filter (search_in_malicious_group_with_DP)
+             stays on the host; the entries it lets through are enqueued like the others.
 """
 import os
 import shutil
@@ -267,7 +268,7 @@ HEADER_CORE_BIN = [
 	whisper_amd::GpuIndelMatching* gpu_indel_rc;
 	struct wamd_strand_t {
 		bool enqueued = false, known_range = false;
-		uint32_t mismatch = 0;                           // the host path's answer (malicious groups, no range) ...
+		uint32_t mismatch = 0;                           // the host path's answer (no range; a malicious group in sensitive mode) ...
 		std::vector<candidate_mapping_t> positions;      // ... and what it pushed
 		std::vector<size_t> indel_tickets;               // sensitive mode: one per enqueued entry
 	};
@@ -419,7 +420,7 @@ uint32_t CMappingCore::wamd_consume(wamd_read_t& wr, bool dir_gen_flag)
 {
 	wamd_strand_t& s = wr.strand[dir_gen_flag ? 0 : 1];
 	std::vector<candidate_mapping_t>& out = dir_gen_flag ? dir_match_positions : rc_match_positions;
-	if (!s.enqueued)		// a malicious group, or no range with this anchor: the host path has answered already
+	if (!s.enqueued)		// no range with this anchor, or a malicious group that is not searched (:29-35): the host path has answered already
 	{
 		out = s.positions;
 		return s.mismatch;
@@ -533,6 +534,20 @@ SA_CPP_BIN = [
 
 
 
+# search_in_malicious_group_with_DP (mapping_core_dp.cpp:23-201): the q-gram filter of the group stays on the host (its
+# lists are the host's); what it lets through goes the way of every other suffix-array entry of the bin.  The CF
+# vectors the loop compares (:132, :161) are those of calculate_CF_128b_SEE_for_dir_and_rc_gen, the ones the device
+# filter computes; the positions pushed (:192, :195) are the unknown-range loop's expressions.
+DP_CPP_BIN = [
+    (122, 123, "lev_alg_thr", """	wamd_cur_strand->enqueued = true;
+	wamd_cur_strand->known_range = false;
+"""),
+    (125, 198, "sum_of_localizations", """	for (auto p = (*sum_of_localizations).begin(); p != q; ++p)
+		gpu_bin->candidate(sub_SA[*p], dir_gen_flag);		// (identical_sequences_* is all false: its only writer is compiled out, :305-326)
+"""),
+]
+
+
 def apply(src_lines, edits):
     out = list(src_lines)
     for first, last, ident, repl in sorted(edits, key=lambda e: -e[0]):
@@ -569,7 +584,7 @@ def check(name, patched, keep):
                  "-I", os.path.join(scratch, "libs"), "-I", os.path.join(REPO, "whisper_amd", "host"),
                  "-I", os.path.join(REPO, "include")]
         rc = 0
-        for f in ("mapping_core_sa.cpp", "mapping_core.cpp", "sam_matching.cpp"):
+        for f in ("mapping_core_sa.cpp", "mapping_core.cpp", "sam_matching.cpp") + (("mapping_core_dp.cpp",) if "mapping_core_dp.cpp" in patched else ()):
             cmd = [os.environ.get("CXX", "g++")] + flags + [os.path.join(scratch, "mapper", f)]
             r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
             print("%-10s %-22s %s" % (name, f, "compiles" if r.returncode == 0 else "FAILS"))
@@ -600,6 +615,7 @@ def main():
         "mapping_core.h": HEADER_CORE_BIN,
         "mapping_core.cpp": CORE_CPP_BIN,
         "mapping_core_sa.cpp": SA_CPP_BIN,
+        "mapping_core_dp.cpp": DP_CPP_BIN,
         "sam.h": HEADER_SAM,
         "sam_matching.cpp": SAM_MATCHING_CPP,
     }

@@ -180,7 +180,8 @@ def test_integration_patch_compiles():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_integration_patch.py")],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0, r.stdout
-    assert r.stdout.count("compiles") == 6 and "per-bin    mapping_core.cpp       compiles" in r.stdout
+    assert r.stdout.count("compiles") == 7 and "per-bin    mapping_core.cpp       compiles" in r.stdout
+    assert "per-bin    mapping_core_dp.cpp    compiles" in r.stdout   # the malicious groups' loop
 
 
 def _bin_expected(oracle, z, per_cand_k):
