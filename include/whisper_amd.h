@@ -782,11 +782,14 @@ typedef struct wamd_rescue_task {
 typedef struct wamd_rescue_result {
     double score;                     /* affine, after the clipping passes                                */
     uint32_t ok;                      /* the pair candidate exists                                        */
-    uint32_t aligned;                 /* dynamicProgramming returned true (:402)                          */
+    uint16_t aligned;                 /* dynamicProgramming returned true (:402)                          */
+    uint16_t edit_distance;           /* its edit distance, + 1 when refine_ext_cigar rewrote (:425): the mate's    *
+                                       * mapping.no_mismatches and mapping_desc_t::num_events (the clipping passes  *
+                                       * change err_edit_distance only)                                            */
     uint32_t pos;                     /* paired_raw_pos                                                   */
     int32_t ref_seq_pos;
     uint16_t ref_length;
-    uint16_t err_edit_distance;       /* = num_events of the mate's mapping_desc_t (lev)                  */
+    uint16_t err_edit_distance;       /* after the clipping passes                                        */
     uint16_t left_clipping;
     uint16_t right_clipping;
     uint32_t ext_cigar_len;

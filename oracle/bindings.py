@@ -555,7 +555,7 @@ Reference.search_reads = _r_search_reads
 RESCUE_TASK = np.dtype([("mate_read_idx", "<u4"), ("hit_pos", "<u4"), ("distance_threshold", "<u4"), ("seq_lo", "<u4"),
                         ("seq_hi", "<u4"), ("seq_delta", "<i4"), ("ref_size", "<i4"), ("max_mate_edit_distance", "<u2"),
                         ("hit_num_events", "<u2"), ("paired_dir_direct", "u1"), ("reserved", "u1", (3,))])
-RESCUE_RESULT = np.dtype([("score", "<f8"), ("ok", "<u4"), ("aligned", "<u4"), ("pos", "<u4"), ("ref_seq_pos", "<i4"),
+RESCUE_RESULT = np.dtype([("score", "<f8"), ("ok", "<u4"), ("aligned", "<u2"), ("edit_distance", "<u2"), ("pos", "<u4"), ("ref_seq_pos", "<i4"),
                           ("ref_length", "<u2"), ("err_edit_distance", "<u2"), ("left_clipping", "<u2"),
                           ("right_clipping", "<u2"), ("ext_cigar_len", "<u4"), ("cigar_events", "<u4")])
 assert RESCUE_TASK.itemsize == 36 and RESCUE_RESULT.itemsize == 40

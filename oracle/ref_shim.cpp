@@ -1264,6 +1264,7 @@ REF_API int ref_rescue_mates_batch(const uint8_t* genome, uint32_t ref_size, con
         if (box.params.enable_short_indel_refinement)
             gen->refine_ext_cigar(ext_cigar, ref_codes.data() + relative_begin_pos, edit_distance, num_events, affine_score);
         uint32_t paired_raw_pos = start_pos + relative_begin_pos;
+        o.edit_distance = (uint16_t)edit_distance;   /* as :438 hands it to construct<lev> */
         o.pos = paired_raw_pos;
         o.cigar_events = num_events;
         std::string paired_ref_seq_name;

@@ -2683,6 +2683,7 @@ int wo_rescue_mates_batch(const uint8_t* genome, const uint8_t* reads, const uin
             continue;
         }
         o->aligned = 1;
+        o->edit_distance = (uint16_t)(ar.edit_distance + (ar.refined ? 1u : 0u));   /* :402, :425 */
         o->pos = dt.ref_pos + ar.begin_pos;                                     /* :422 */
         o->cigar_events = ar.num_events;
         o->ref_seq_pos = (int32_t)((int64_t)o->pos + t->seq_delta);            /* ref_desc.cpp:109-115 */

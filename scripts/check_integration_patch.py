@@ -224,10 +224,76 @@ HEADER_SAM = [
     (89, 89, "softClipping", '''	CSoftClipping* softClipping;
 	whisper_amd::GpuReference* gpu_ref;
 	whisper_amd::GpuLevMyersAligner* gpu_aligner;
+	whisper_amd::GpuMateRescue* gpu_rescue;
 '''),
 ]
 
 SAM_MATCHING_CPP = [
+    # find_pairs<LevMyers> (318-504): the chain per hit (379-457) through GpuMateRescue / wamd_rescue_mates - every hit
+    # of the pair enqueued (the fill_cigar of an unmatched hit stays in front, :386-387), one flush (per block of pairs
+    # in production), then the loop's second half in the loop's order
+    (331, 338, "LevMyers", ""),
+    (352, 482, "for (uint32_t r = 0", '''	struct wamd_hit_t {
+		mapping_desc_t* h;
+		uint32_t r;
+		size_t ticket;
+		genome_t paired_dir;
+	};
+	std::vector<wamd_hit_t> wamd_hits;
+	const uint32_t wamd_mate[2] = { gpu_rescue->addMate(sequence[0], sequence_len[0]), gpu_rescue->addMate(sequence[1], sequence_len[1]) };
+	for (uint32_t r = 0; r < 2; ++r) {
+		for (auto h : hits[r]) {
+			if (h->err_edit_distance < editDistanceRange.first || h->err_edit_distance > editDistanceRange.second)
+				continue; // ignore hits if edit distance is outside specified range
+			mapping_desc_t& this_hit = *h;
+			if (this_hit.method == MatchingMethod::Enumeration::Unmatched)
+				fill_cigar(this_hit, id[r], sequence[r], sequence_len[r], quality[r], false, true);
+			genome_t paired_dir = get_direction_using_orientation(this_hit.mapping.direction, mapping_orientation);
+			uint32_t max_mate_edit_distance = (uint32_t)(sequence_len[!r] * max_mate_edit_distance_frac) * 2;
+			wamd_hits.push_back({ h, r, gpu_rescue->hit(wamd_mate[!r], this_hit.mapping.pos, distanceThreshold, max_mate_edit_distance,
+				paired_dir, this_hit.num_events, ref_seq_desc->GetDescription(), this_hit.ref_seq_id, SEPARATE_N_LEN), paired_dir });
+		}
+	}
+	gpu_rescue->flush();
+	for (auto& wh : wamd_hits) {
+		const uint32_t r = wh.r;
+		mapping_desc_t& this_hit = *wh.h;
+		const wamd_rescue_result& wr = gpu_rescue->result(wh.ticket);
+		if (!wr.ok)		// dynamicProgramming, Translate or one of the num_events tests said no (:407, :430-433)
+			continue;
+		uchar_t* ext_cigar;
+		mp_ext_cigar->Reserve(ext_cigar);
+		memcpy(ext_cigar, gpu_rescue->extCigar(wh.ticket), (size_t) wr.ext_cigar_len + 1);
+		paired_raw_pos = wr.pos;
+		paired_ref_seq_id = this_hit.ref_seq_id;
+
+		candidate_mapping_t paired_mapping = candidate_mapping_t::construct<mapping_type_t::lev>(paired_raw_pos, wh.paired_dir, wr.edit_distance);
+
+		mapping_desc[!r].emplace_back(paired_mapping, paired_ref_seq_id, wr.ref_seq_pos, sequence_len[!r], ext_cigar,
+			params->gap_del_open, params->gap_del_extend, params->gap_ins_open, params->gap_ins_extend, params->mismatch_score);
+		auto& mate_hit = mapping_desc[!r].back();
+
+		// the mate as clipIllegalPositions / clipBoundaryPositions left it on the device (:444-456)
+		mate_hit.method = MatchingMethod::Enumeration::LevMyers;
+		mate_hit.ref_length = wr.ref_length;
+		mate_hit.err_edit_distance = wr.err_edit_distance;
+		mate_hit.left_clipping = wr.left_clipping;
+		mate_hit.right_clipping = wr.right_clipping;
+		mate_hit.score = wr.score;
+		mate_hit.score_type = ScoringType::Affine;
+
+		softClipping->clipIllegalPositions(this_hit, insertSizeModel->getScoring(), ref_seq_desc->GetDescription(), *mp_ext_cigar);
+		if (params->enable_boundary_clipping)
+			softClipping->clipBoundaryPositions(this_hit, insertSizeModel->getScoring());
+
+		mapping_pair_t candidate(
+			r == 0 ? &this_hit : &mate_hit,
+			r == 0 ? &mate_hit : &this_hit);
+
+		candidate.score = pairEvaluator(candidate);
+		pushMappingHeap(mapping_pairs, candidate, mapping_heap_size);
+	}
+'''),
     # fill_cigar_with_lev (689-752): preprocessRawSeq + dynamicProgramming, then getExtCigar + refine_ext_cigar
     (691, 694, "LevMyers", ""),
     (702, 703, "preprocessRawSeq", '''	gpu_aligner->preprocessRawSeq(sequence, sequence_len, mapping_desc.mapping.direction);

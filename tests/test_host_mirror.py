@@ -170,6 +170,46 @@ def test_rescue_mirrors_match_oracle(tmp_path, oracle):
         assert bytes(got_c[i, :n]) == bytes(want_c[i, :n]), i
 
 
+@pytest.mark.gpu
+def test_mate_rescue_mirror_matches_oracle(tmp_path, oracle):
+    """GpuMateRescue (find_pairs<LevMyers>'s chain per hit, sam_matching.cpp:379-457): addMate per read, hit per task from
+    the reference's own quantities - the hit's position, the chromosome table as CRefSeqDesc::GetDescription() holds it -
+    one flush; against the oracle on the tasks the reference's own statements produce (tests/test_rescue_chain.py)."""
+    from oracle import bindings as ob
+    from whisper_amd import api
+    (codes, packed), (blob, off, lens), desc, mate, hit_pos, seq_id, events, direct, k = common.rescue_workload(1500, 23, 150)
+    tasks = common.rescue_tasks(desc, mate, hit_pos, seq_id, events, direct, k)
+    stride = 768
+    prm = ob.RescueParams(1, 1)
+    rc, want, wext = oracle.rescue_mates(packed, blob, off, lens, tasks, params=prm, ext_stride=stride)
+    assert rc == 0 and want["ok"].sum() > 400 and (want["aligned"] != want["ok"]).sum() > 100
+    hits = np.zeros(len(tasks), np.dtype([("mate", "<u4"), ("hit_pos", "<u4"), ("thr", "<u4"), ("k", "<u4"), ("events", "<u4"),
+                                          ("seq_id", "<i4"), ("direct", "<u4"), ("reserved", "<u4")]))
+    hits["mate"], hits["hit_pos"], hits["thr"] = mate, hit_pos, tasks["distance_threshold"]
+    hits["k"], hits["events"], hits["seq_id"], hits["direct"] = k, events, seq_id, direct
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(fin, "wb") as f:
+        f.write(struct.pack("<4I", codes.numel(), 0, stride, common.SEPARATE_N_LEN))
+        f.write(_vec(packed))
+        f.write(struct.pack("<Q", 1) + bytes(api.RescueParams(1, 1)))
+        f.write(struct.pack("<Q", 1) + bytes(api.default_scoring()))
+        f.write(struct.pack("<Q", len(desc)) + np.ascontiguousarray(desc, np.uint64).tobytes())   # rows = SeqDesc
+        f.write(_vec(blob))
+        f.write(_vec(off.astype(np.uint64)))
+        f.write(_vec(lens.astype(np.uint32)))
+        f.write(_vec(hits))
+    subprocess.run([BIN, "--mates", str(fin), str(fout)], check=True, timeout=120)
+    raw = np.fromfile(fout, np.uint8)
+    a = len(tasks) * want.dtype.itemsize
+    got = raw[:a].view(want.dtype)
+    gext = raw[a:].reshape(len(tasks), stride)
+    for fld in want.dtype.names:
+        np.testing.assert_array_equal(got[fld], want[fld], err_msg=fld)
+    for i in np.nonzero(want["ok"])[0]:
+        e = want["ext_cigar_len"][i] + 1
+        assert bytes(gext[i, :e]) == bytes(wext[i, :e]), i
+
+
 def test_integration_patch_compiles():
     """INTEGRATION.md sections 3-4 as an edit of a scratch copy of the reference's mapping_core_sa.cpp,
     mapping_core.cpp and sam_matching.cpp (outside the repository), compiled against gpu_verifier.hpp.

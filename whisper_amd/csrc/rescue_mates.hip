@@ -104,6 +104,7 @@ __global__ __launch_bounds__(256) void rescue_merge_kernel(ReadsView rv, const w
         const uint32_t half = t.max_mate_edit_distance / 2u;
         ok = same_seq && a.num_events <= half && t.hit_num_events <= half;      // :426-427
         o.aligned = 1;
+        o.edit_distance = (uint16_t)(a.edit_distance + (a.refined ? 1u : 0u));
         o.pos = paired_raw_pos;
         o.cigar_events = a.num_events;
         o.ref_seq_pos = (int32_t)((int64_t)paired_raw_pos + t.seq_delta);

@@ -246,6 +246,87 @@ private:
     uint32_t cur_flags_ = 0;
 };
 
+// Mirrors find_pairs<LevMyers>'s chain per hit (mapper/sam_matching.cpp:379-457) through wamd_rescue_mates: the window
+// beside the hit (:392-400), preprocessRawSeq + dynamicProgramming, getExtCigar (+ refine_ext_cigar), Translate's
+// verdict, the num_events tests, the mate's mapping_desc_t (lev), clipIllegalPositions and clipBoundaryPositions - one
+// device call for every hit enqueued since the last flush.  The hit's own two clipping passes (:451, :455) stay where
+// they are (or go through wamd_clip_illegal / wamd_clip_boundary on the caller's records).
+class GpuMateRescue {
+public:
+    GpuMateRescue(GpuReference& ref, uint32_t max_cigar_len, bool short_indel_refinement, bool boundary_clipping)
+        : ref_(ref), stride_((max_cigar_len + 3) / 4 * 4)
+    {
+        prm_.enable_short_indel_refinement = short_indel_refinement;
+        prm_.enable_boundary_clipping = boundary_clipping;
+    }
+    // the mate's sequence as find_pairs holds it (sequence[!r], ASCII); returns the handle hits refer to
+    uint32_t addMate(const uchar_t* seq, uint32_t seq_len)
+    {
+        offsets_.push_back(blob_.size());
+        lens_.push_back(seq_len);
+        blob_.insert(blob_.end(), seq, seq + seq_len);
+        return (uint32_t)lens_.size() - 1;
+    }
+    // one hit: this_hit.mapping.pos, distanceThreshold (:348), max_mate_edit_distance (:390), paired_dir (:389),
+    // this_hit.num_events, and the hit's chromosome: seq_desc = CRefSeqDesc::GetDescription(), this_hit.ref_seq_id
+    // indexes it (ref_desc.cpp:81-118 is what the four derived fields restate; separate_n_len = SEPARATE_N_LEN)
+    template <class G, class SeqDescVector>
+    size_t hit(uint32_t mate, ref_pos_t hit_pos, ref_pos_t distance_threshold, uint32_t max_mate_edit_distance, G paired_dir,
+               uint32_t hit_num_events, const SeqDescVector& seq_desc, int32_t ref_seq_id, uint32_t separate_n_len)
+    {
+        const auto& d = seq_desc.at((size_t)ref_seq_id);
+        wamd_rescue_task t{};
+        t.mate_read_idx = mate;
+        t.hit_pos = hit_pos;
+        t.distance_threshold = distance_threshold;
+        t.seq_lo = (uint32_t)(d.pos_in_ref_seq + separate_n_len / 2);
+        t.seq_hi = (size_t)ref_seq_id + 1 < seq_desc.size()
+                       ? (uint32_t)(seq_desc[(size_t)ref_seq_id + 1].pos_in_ref_seq + separate_n_len / 2)
+                       : (uint32_t)(d.pos_in_ref_seq + d.size + 2 * separate_n_len);
+        t.seq_delta = (int32_t)((int64_t)d.no_initial_Ns - (int64_t)d.no_starting_Ns + 1 - (int64_t)d.pos_in_ref_seq);
+        t.ref_size = (int32_t)(d.size + d.no_final_Ns + d.no_initial_Ns);
+        t.max_mate_edit_distance = (uint16_t)max_mate_edit_distance;
+        t.hit_num_events = (uint16_t)hit_num_events;
+        t.paired_dir_direct = is_rev_comp(paired_dir) ? 0 : 1;
+        tasks_.push_back(t);
+        return tasks_.size() - 1;
+    }
+    void flush()
+    {
+        results_.assign(tasks_.size(), wamd_rescue_result{});
+        cigars_.assign(tasks_.size() * (size_t)stride_, 0);
+        if (tasks_.empty())
+            return;
+        offsets_.push_back(blob_.size());
+        wamd_reads* reads = nullptr;
+        check(wamd_reads_upload(ref_.ctx(), blob_.data(), offsets_.data(), lens_.data(), (uint32_t)lens_.size(),
+                                WAMD_READS_ASCII, 3, &reads), "wamd_reads_upload");
+        int rc = wamd_rescue_mates(ref_.ctx(), reads, tasks_.data(), (uint32_t)tasks_.size(), &prm_, results_.data(),
+                                   cigars_.data(), stride_);
+        wamd_reads_free(reads);
+        blob_.clear();
+        offsets_.clear();
+        lens_.clear();
+        tasks_.clear();
+        check(rc, "wamd_rescue_mates");
+    }
+    // ok: the pair candidate exists (:430-433 all passed); then pos / ref_seq_pos / ref_length / err_edit_distance /
+    // clippings / score are the mate's mapping_desc_t behind :456 and extCigar its ext-CIGAR
+    const wamd_rescue_result& result(size_t ticket) const { return results_.at(ticket); }
+    const uchar_t* extCigar(size_t ticket) const { return cigars_.data() + ticket * (size_t)stride_; }
+
+private:
+    GpuReference& ref_;
+    uint32_t stride_;
+    wamd_rescue_params prm_{};
+    std::vector<uchar_t> blob_;
+    std::vector<uint64_t> offsets_;
+    std::vector<uint32_t> lens_;
+    std::vector<wamd_rescue_task> tasks_;
+    std::vector<wamd_rescue_result> results_;
+    std::vector<uchar_t> cigars_;
+};
+
 // Mirrors CIndelMatching (mapper/indels.h:277-286) for the sensitive-mode matcher of the mapping stages
 // (mapper/mapping_core_sa.cpp:258-272, 310-326): Preprocess + Match enqueue, flush() runs wamd_indel_match,
 // result(ticket, candidate_mapping) fills the reference's candidate_mapping_t (common/types.h:224-318) the way

@@ -3,6 +3,7 @@
 // Input / output are flat binary files written and checked by tests/test_host_mirror.py.
 //   replay_batch <in.bin> <out.bin> [--accepted-only]
 //   replay_batch --rescue <in.bin> <out.bin>
+//   replay_batch --mates <in.bin> <out.bin>           find_pairs<LevMyers>'s chain per hit through GpuMateRescue
 //   replay_batch --bin <in.bin> <out.bin> [repeats]   one bin of one stage through GpuSaBin: per read addRead(), per
 //                                           suffix-array entry candidate(), ONE flush; prints host-to-host candidates/s
 #include <chrono>
@@ -75,6 +76,51 @@ static int replay_rescue(const char* in, const char* out)
     for (size_t i = 0; i < stasks.size(); ++i)
         o.write((const char*)sc.extCigar(st[i]), hdr[2]);
     std::cout << "replayed " << itasks.size() << " Match and " << stasks.size() << " match calls\n";
+    return 0;
+}
+
+// replay_batch --mates <in.bin> <out.bin>: the hits of find_pairs<LevMyers> (sam_matching.cpp:379-457) through
+// GpuMateRescue - addMate per read, hit per task with the chromosome table as CRefSeqDesc::GetDescription() hands it
+// out (the five numeric fields of seq_desc_t), one flush.
+struct SeqDesc {   // the fields of seq_desc_t (common/types.h:145-153) the mirror reads
+    uint64_t size, pos_in_ref_seq, no_initial_Ns, no_final_Ns, no_starting_Ns;
+};
+struct MateHit {
+    uint32_t mate, hit_pos, distance_threshold, max_mate_edit_distance, hit_num_events;
+    int32_t ref_seq_id;
+    uint32_t paired_dir_direct, reserved;
+};
+static int replay_mates(const char* in, const char* out)
+{
+    std::ifstream f(in, std::ios::binary);
+    uint32_t hdr[4];   // ref_size, cur_offset, ext-CIGAR stride, SEPARATE_N_LEN
+    f.read((char*)hdr, sizeof(hdr));
+    auto genome = read_vec<uchar_t>(f);
+    auto prm = read_vec<wamd_rescue_params>(f);
+    auto sc = read_vec<wamd_scoring>(f);
+    auto desc = read_vec<SeqDesc>(f);
+    auto blob = read_vec<uchar_t>(f);            // ASCII mates
+    auto off = read_vec<uint64_t>(f);
+    auto len = read_vec<uint32_t>(f);
+    auto hits = read_vec<MateHit>(f);
+    GpuReference ref(0, genome.data(), genome.size(), hdr[0], hdr[1]);
+    ref.setMaxTextLen(16384);   // sam.cpp:190
+    check(wamd_ctx_set_scoring(ref.ctx(), &sc.at(0)), "wamd_ctx_set_scoring");
+    GpuMateRescue rescue(ref, hdr[2] - 1, prm.at(0).enable_short_indel_refinement != 0, prm.at(0).enable_boundary_clipping != 0);
+    for (uint32_t r = 0; r < len.size(); ++r)
+        rescue.addMate(blob.data() + off[r], len[r]);
+    std::vector<size_t> t(hits.size());
+    for (size_t i = 0; i < hits.size(); ++i)
+        t[i] = rescue.hit(hits[i].mate, hits[i].hit_pos, hits[i].distance_threshold, hits[i].max_mate_edit_distance,
+                          hits[i].paired_dir_direct ? genome_t::direct : genome_t::rev_comp, hits[i].hit_num_events, desc,
+                          hits[i].ref_seq_id, hdr[3]);
+    rescue.flush();
+    std::ofstream o(out, std::ios::binary);
+    for (size_t i = 0; i < hits.size(); ++i)
+        o.write((const char*)&rescue.result(t[i]), sizeof(wamd_rescue_result));
+    for (size_t i = 0; i < hits.size(); ++i)
+        o.write((const char*)rescue.extCigar(t[i]), hdr[2]);
+    std::cout << "replayed " << hits.size() << " hits\n";
     return 0;
 }
 
@@ -168,6 +214,14 @@ int main(int argc, char** argv)
             return replay_bin(argv[2], argv[3], argc == 5 ? atoi(argv[4]) : 1);
         } catch (const std::exception& e) {
             std::cerr << "error: " << e.what() << "\n";
+            return 1;
+        }
+    }
+    if (argc == 4 && std::string(argv[1]) == "--mates") {
+        try {
+            return replay_mates(argv[2], argv[3]);
+        } catch (const std::exception& e) {
+            std::cerr << "replay_batch: " << e.what() << "\n";
             return 1;
         }
     }
