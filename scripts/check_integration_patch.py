@@ -225,6 +225,8 @@ HEADER_SAM = [
 	whisper_amd::GpuReference* gpu_ref;
 	whisper_amd::GpuLevMyersAligner* gpu_aligner;
 	whisper_amd::GpuMateRescue* gpu_rescue;
+	whisper_amd::GpuSoftClipping* gpu_softclip;
+	whisper_amd::GpuIndelExtCigar* gpu_indel_cigar;
 '''),
 ]
 
@@ -294,6 +296,41 @@ SAM_MATCHING_CPP = [
 		pushMappingHeap(mapping_pairs, candidate, mapping_heap_size);
 	}
 '''),
+    # find_pairs<Clipping> (507-639): preprocessRawSeq + match + getExtCigar through GpuSoftClipping / wamd_softclip_match.
+    # A first pass in front of the loop enqueues every hit's window (the fill_cigar of an unmatched hit with it: the
+    # loop then finds the hit matched), one flush, and the loop reads its answers in its own order.
+    (528, 527, "", '''	std::vector<size_t> wamd_clip_tickets;
+	for (uint32_t r = 0; r < 2; ++r) {
+		for (auto h : hits[r]) {
+			if (h->err_edit_distance < editDistanceRange.first || h->err_edit_distance > editDistanceRange.second ||
+				h->method == MatchingMethod::Enumeration::LevMyers) {
+				wamd_clip_tickets.push_back((size_t) -1);	// (fill_cigar below may move err_edit_distance: the loop must not ask again)
+				continue;
+			}
+			if (h->method == MatchingMethod::Enumeration::Unmatched)
+				fill_cigar(*h, id[r], sequence[r], sequence_len[r], quality[r], false, true);
+			genome_t wamd_dir = get_direction_using_orientation(h->mapping.direction, mapping_orientation);
+			gpu_softclip->preprocessRawSeq(sequence[!r], sequence_len[!r], wamd_dir);
+			wamd_clip_tickets.push_back(gpu_softclip->match(
+				wamd_dir == genome_t::direct ? h->mapping.pos - distanceThreshold + sequence_len[!r] : h->mapping.pos + 1,
+				distanceThreshold, HashTable::hash_len));
+		}
+	}
+	gpu_softclip->flush();		// per block of pairs in production
+	size_t wamd_clip_next = 0;
+'''),
+    (530, 533, "editDistanceRange", '''			const size_t wamd_t = wamd_clip_tickets[wamd_clip_next++];
+			if (wamd_t == (size_t) -1)
+				continue; // ignored in the first pass: edit distance outside the range, or a LevMyers hit
+'''),
+    (556, 558, "preprocessRawSeq", '''			if (gpu_softclip->result(wamd_t, relative_begin_pos, left_clipping, right_clipping,
+				left_match, right_match, del_size, no_mismatches)) {
+'''),
+    (562, 575, "direct", '''						uchar_t* ext_cigar;
+						mp_ext_cigar->Reserve(ext_cigar);
+						memcpy(ext_cigar, gpu_softclip->extCigar(wamd_t), (size_t) gpu_softclip->result(wamd_t).cigar_len + 1);
+						double affine_score = gpu_softclip->result(wamd_t).affine_score;
+'''),
     # fill_cigar_with_lev (689-752): preprocessRawSeq + dynamicProgramming, then getExtCigar + refine_ext_cigar
     (691, 694, "LevMyers", ""),
     (702, 703, "preprocessRawSeq", '''	gpu_aligner->preprocessRawSeq(sequence, sequence_len, mapping_desc.mapping.direction);
@@ -317,6 +354,41 @@ SAM_MATCHING_CPP = [
 			++stat_refined_short_indels_mapping;
 			mapping_desc.err_edit_distance = (uint16_t) (mapping_desc.err_edit_distance + 1);
 		}
+'''),
+    # fill_cigar_with_clipping (755-821): a mapping the matcher found, located again by the hashing rescue
+    (771, 774, "preprocessRawSeq", '''	gpu_softclip->preprocessRawSeq(sequence, sequence_len, mapping_desc.mapping.direction);
+	const size_t wamd_ct = gpu_softclip->match(examined_start_pos, examined_size, HashTable::hash_len);
+	gpu_softclip->flush();		// per block of reads in production
+
+	if (gpu_softclip->result(wamd_ct, relative_begin_pos, left_clipping, right_clipping,
+		left_match, right_match, del_size, no_mismatches))
+'''),
+    (783, 797, "direct", '''			if (!mapping_desc.ext_cigar)
+				mp_ext_cigar->Reserve(mapping_desc.ext_cigar);
+			memcpy(mapping_desc.ext_cigar, gpu_softclip->extCigar(wamd_ct), (size_t) gpu_softclip->result(wamd_ct).cigar_len + 1);
+			double affine_score = gpu_softclip->result(wamd_ct).affine_score;
+'''),
+    # fill_cigar_with_indel_matching (824-852): GetExtCigarNew of the matcher's record
+    (831, 837, "PreprocessRawSeq", '''	gpu_indel_cigar->PreprocessRawSeq(sequence, sequence_len, mapping_desc.mapping.direction);
+	const size_t wamd_it = gpu_indel_cigar->GetExtCigarNew(mapping_desc.mapping, examined_start_pos);
+	gpu_indel_cigar->flush();		// per block of reads in production
+	const wamd_indel_cigar_result& wamd_ir = gpu_indel_cigar->result(wamd_it);
+
+	if (!mapping_desc.ext_cigar)
+		mp_ext_cigar->Reserve(mapping_desc.ext_cigar);
+	if (wamd_ir.ok)
+	{
+		memcpy(mapping_desc.ext_cigar, gpu_indel_cigar->extCigar(wamd_it), (size_t) wamd_ir.cigar_len + 1);
+		mapping_desc.score = wamd_ir.score;
+		mapping_desc.score_type = ScoringType::Affine;
+		mapping_desc.err_edit_distance = wamd_ir.err_edit_distance;
+		mapping_desc.num_events = wamd_ir.num_events;
+		mapping_desc.ref_length = wamd_ir.ref_length;
+		mapping_desc.left_clipping = wamd_ir.left_clipping;
+		mapping_desc.right_clipping = wamd_ir.right_clipping;
+		mapping_desc.method = (MatchingMethod::Enumeration) wamd_ir.method;
+	}
+	if (wamd_ir.ok)
 '''),
 ]
 

@@ -123,8 +123,9 @@ def test_two_threads_flush_on_one_context(oracle):
 
 @pytest.mark.gpu
 def test_rescue_mirrors_match_oracle(tmp_path, oracle):
-    """GpuIndelMatching (CIndelMatching::Preprocess + Match) and GpuSoftClipping (CSoftClipping::preprocessRawSeq +
-    match + getExtCigar) driven per read / per candidate by the replay program."""
+    """GpuIndelMatching (CIndelMatching::Preprocess + Match), GpuIndelExtCigar (PreprocessRawSeq + GetExtCigarNew of what
+    Match found) and GpuSoftClipping (CSoftClipping::preprocessRawSeq + match + getExtCigar) driven per read / per
+    candidate by the replay program."""
     from oracle import bindings as ob
     from whisper_amd import api
     codes, packed, (iblob, ioff, ilen), itasks = common.indel_workload(1500, 150, seed=77)
@@ -139,11 +140,15 @@ def test_rescue_mirrors_match_oracle(tmp_path, oracle):
     stride = want_c.shape[1]
     assert stride % 4 == 0
     assert want_i["found"].sum() > 300 and want_s["found"].sum() > 600
+    ct = common.indel_cigar_tasks(itasks, want_i)
+    istride = 4 * ((2 * (150 + 2 * 50 + 20) + 8 + 3) // 4)
+    _, want_g, want_gc = oracle.indel_ext_cigar(packed, iblob, ioff, ilen, 0, ct, cigar_stride=istride)
+    assert len(ct) == want_i["found"].astype(bool).sum() and want_g["ok"].all()
     ip = api.default_indel_params(1.0)
     gsp = api.default_softclip_params(fresh_object=0)
     fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
     with open(fin, "wb") as f:
-        f.write(struct.pack("<4I", codes.numel(), 0, stride, 0))
+        f.write(struct.pack("<4I", codes.numel(), 0, stride, istride))
         f.write(_vec(packed))
         f.write(struct.pack("<Q", 1) + bytes(ip))
         f.write(_vec(iblob))
@@ -162,7 +167,15 @@ def test_rescue_mirrors_match_oracle(tmp_path, oracle):
     b = a + ns * want_s.dtype.itemsize
     got_i = raw[:a].view(want_i.dtype)
     got_s = raw[a:b].view(want_s.dtype)
-    got_c = raw[b:].reshape(ns, stride)
+    c = b + ns * stride
+    d = c + len(ct) * want_g.dtype.itemsize
+    got_c = raw[b:c].reshape(ns, stride)
+    got_g = raw[c:d].view(want_g.dtype)
+    got_gc = raw[d:].reshape(len(ct), istride)
+    np.testing.assert_array_equal(got_g, want_g)
+    for i in range(len(ct)):
+        n = want_g["cigar_len"][i] + 1
+        assert bytes(got_gc[i, :n]) == bytes(want_gc[i, :n]), i
     np.testing.assert_array_equal(got_i, want_i)
     np.testing.assert_array_equal(got_s, want_s)
     for i in range(ns):

@@ -431,6 +431,76 @@ private:
     bool need_rc_ = false;
 };
 
+// Mirrors CIndelMatching::{PreprocessRawSeq, prefetch_genome, GetExtCigarNew} as fill_cigar_with_indel_matching uses them
+// (mapper/sam_matching.cpp:824-852): the ext-CIGAR, score and error counts of a mapping the matcher found in the mapping
+// stage, rebuilt from its compact record.  M is the reference's candidate_mapping_t (its mapping_type_t values are the
+// WAMD_MAP_* values).
+class GpuIndelExtCigar {
+public:
+    GpuIndelExtCigar(GpuReference& ref, uint32_t max_cigar_len) : ref_(ref), stride_((max_cigar_len + 3) / 4 * 4) {}
+
+    template <class G>
+    bool PreprocessRawSeq(const uchar_t* seq, uint32_t seq_len, G orientation)
+    {
+        offsets_.push_back(blob_.size());
+        lens_.push_back(seq_len);
+        blob_.insert(blob_.end(), seq, seq + seq_len);
+        cur_read_ = (uint32_t)lens_.size() - 1;
+        cur_flags_ = is_rev_comp(orientation) ? WAMD_TASK_FLAG_REV_COMP : 0;
+        return true;
+    }
+    template <class M>
+    size_t GetExtCigarNew(const M& mapping, ref_pos_t examined_start_pos)
+    {
+        wamd_indel_cigar_task t{};
+        t.read_idx = cur_read_;
+        t.examined_start_pos = examined_start_pos;
+        t.type = (uint32_t)mapping.type;
+        t.matching_len1 = mapping.matching_len1;
+        t.matching_len2 = mapping.matching_len2;
+        t.indel_len1 = mapping.indel_len1;
+        t.indel_len2 = mapping.indel_len2;
+        t.clipping_len = mapping.clipping_len;
+        t.flags = cur_flags_;
+        tasks_.push_back(t);
+        return tasks_.size() - 1;
+    }
+    void flush()
+    {
+        results_.assign(tasks_.size(), wamd_indel_cigar_result{});
+        cigars_.assign(tasks_.size() * (size_t)stride_, 0);
+        if (tasks_.empty())
+            return;
+        offsets_.push_back(blob_.size());
+        wamd_reads* reads = nullptr;
+        check(wamd_reads_upload(ref_.ctx(), blob_.data(), offsets_.data(), lens_.data(), (uint32_t)lens_.size(),
+                                WAMD_READS_ASCII, 3, &reads), "wamd_reads_upload");
+        const int rc = wamd_indel_ext_cigar(ref_.ctx(), reads, tasks_.data(), (uint32_t)tasks_.size(), results_.data(),
+                                            cigars_.data(), stride_);
+        wamd_reads_free(reads);
+        blob_.clear();
+        offsets_.clear();
+        lens_.clear();
+        tasks_.clear();
+        check(rc, "wamd_indel_ext_cigar");
+    }
+    // ok = GetExtCigarNew's bool; the other fields are what it leaves in mapping_desc_t
+    const wamd_indel_cigar_result& result(size_t ticket) const { return results_.at(ticket); }
+    const uchar_t* extCigar(size_t ticket) const { return cigars_.data() + ticket * (size_t)stride_; }
+
+private:
+    GpuReference& ref_;
+    uint32_t stride_;
+    std::vector<uchar_t> blob_;
+    std::vector<uint64_t> offsets_;
+    std::vector<uint32_t> lens_;
+    std::vector<wamd_indel_cigar_task> tasks_;
+    std::vector<wamd_indel_cigar_result> results_;
+    std::vector<uchar_t> cigars_;
+    uint32_t cur_read_ = 0;
+    uint32_t cur_flags_ = 0;
+};
+
 // Mirrors CSoftClipping's rescue use (mapper/soft_clipping.h:122-137; sam_matching.cpp:556-575, 771-797):
 // preprocessRawSeq + match enqueue, flush() runs wamd_softclip_match (match and getExtCigar in one go),
 // result(ticket) holds match's out-parameters, extCigar(ticket) / result(ticket).affine_score getExtCigar's.

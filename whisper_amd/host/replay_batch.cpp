@@ -30,7 +30,7 @@ template <class T> static std::vector<T> read_vec(std::ifstream& f)
 static int replay_rescue(const char* in, const char* out)
 {
     std::ifstream f(in, std::ios::binary);
-    uint32_t hdr[4];   // ref_size, cur_offset, cigar stride of the rescue, unused
+    uint32_t hdr[4];   // ref_size, cur_offset, cigar stride of the rescue, cigar stride of GetExtCigarNew
     f.read((char*)hdr, sizeof(hdr));
     auto genome = read_vec<uchar_t>(f);
     auto ip = read_vec<wamd_indel_params>(f);
@@ -56,6 +56,28 @@ static int replay_rescue(const char* in, const char* out)
                              itasks[k].fixed_segment_size, itasks[k].max_no_mismatches);
     }
     im.flush();
+    // GetExtCigarNew of what Match found, as fill_cigar_with_indel_matching asks for it (sam_matching.cpp:824-852): the
+    // read as ASCII through PreprocessRawSeq, the record, the window start
+    GpuIndelExtCigar ic(ref, hdr[3] - 1);
+    std::vector<size_t> ict;
+    {
+        std::vector<uchar_t> ascii;
+        for (size_t i = 0; i < itasks.size(); ++i) {
+            const wamd_mapping& mp = im.result(it[i]);
+            if (!mp.found)
+                continue;
+            const uint32_t r = itasks[i].read_idx;
+            ascii.resize(ilen[r]);
+            for (uint32_t p = 0; p < ilen[r]; ++p) {
+                const uchar_t b = iblob[ioff[r] + (p >> 1)];
+                const uint32_t c = (p & 1u) ? (b & 15u) : (b >> 4);
+                ascii[p] = (uchar_t)"ACGTN"[c < 4 ? c : 4];
+            }
+            ic.PreprocessRawSeq(ascii.data(), ilen[r], genome_t::direct);
+            ict.push_back(ic.GetExtCigarNew(mp, mp.pos));
+        }
+    }
+    ic.flush();
     GpuSoftClipping sc(ref, sp.at(0), hdr[2] - 1);
     std::vector<size_t> st(stasks.size());
     k = 0;
@@ -75,6 +97,10 @@ static int replay_rescue(const char* in, const char* out)
         o.write((const char*)&sc.result(st[i]), sizeof(wamd_softclip_result));
     for (size_t i = 0; i < stasks.size(); ++i)
         o.write((const char*)sc.extCigar(st[i]), hdr[2]);
+    for (size_t t : ict)
+        o.write((const char*)&ic.result(t), sizeof(wamd_indel_cigar_result));
+    for (size_t t : ict)
+        o.write((const char*)ic.extCigar(t), hdr[3]);
     std::cout << "replayed " << itasks.size() << " Match and " << stasks.size() << " match calls\n";
     return 0;
 }
