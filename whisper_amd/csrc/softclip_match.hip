@@ -130,7 +130,7 @@ __global__ __launch_bounds__(64) void softclip_match_kernel(GenomeView g, ReadsV
                                                             uint32_t max_text_len, SliceLayout lay, uint32_t groups,
                                                             wamd_softclip_result* __restrict__ results,
                                                             uint8_t* __restrict__ cigars, uint32_t cigar_stride,
-                                                            uint32_t* __restrict__ flags)
+                                                            uint32_t* __restrict__ flags, uint32_t* __restrict__ work)
 {
     extern __shared__ uint32_t lds_raw[];
     const uint32_t lane = threadIdx.x, gl = lane & (GROUP - 1), gbase = lane & ~(GROUP - 1);
@@ -157,7 +157,24 @@ __global__ __launch_bounds__(64) void softclip_match_kernel(GenomeView g, ReadsV
 
     // (groups: how many of the wave's four groups hold a window - fewer when long reads in long windows leave no room
     //  for four sets of arrays in LDS; the others sit idle)
-    for (uint32_t first = blockIdx.x * groups; first < n; first += gridDim.x * groups) {
+    // Windows differ a great deal in what they cost (nothing found / a read's whole diagonal served), so the waves take
+    // their next four from a counter (`work`, zeroed by the launcher) instead of a fixed share; without a counter
+    // (more streams than the context keeps words for) they stride.
+    // (eight steps' worth per visit to the counter: unrelated windows take so little that one address would not keep up)
+    constexpr uint32_t GRAB = 8;
+    uint32_t grabbed = 0;
+    for (uint32_t first = blockIdx.x * groups;; first += work ? groups : gridDim.x * groups) {
+        if (work && grabbed == 0) {
+            uint32_t f = 0;
+            if (lane == 0)
+                f = atomicAdd(work, groups * GRAB);
+            first = (uint32_t)__builtin_amdgcn_readfirstlane((int)f);
+            grabbed = GRAB;
+        }
+        if (work)
+            --grabbed;
+        if (first >= n)
+            break;
         const uint32_t task = first + lane / GROUP;
         bool live = task < n && lane / GROUP < groups;
         const wamd_softclip_task t = tasks[live ? task : first];
@@ -796,11 +813,11 @@ static SliceLayout softclip_layout(uint32_t ht_size, uint32_t cell_bytes, uint32
     o += round_up(max_len * cell_bytes, 4);
     l.left = o;
     o += round_up((max_window + 2) * cell_bytes, 4) + 4;   // cleared a dword at a time
+    // (the log of cells is through with when the values are in place, before the first position is queued: one space)
     l.cell = o;
-    o += round_up(2 * (max_len + 1), 4);
     l.queue = o;
     l.queue_cap = round_up(max_len + 16, GROUP) + FILL * GROUP;   // a read's own hits and a few strangers: one pass as a rule
-    o += 2 * l.queue_cap;
+    o += round_up(2 * (l.queue_cap > max_len + 1 ? l.queue_cap : max_len + 1), 4);
     // an odd number of 64-byte lines: the four slices start on different halves of the banks
     o = round_up(o, 64);
     if (!((o / 64) & 1))
@@ -840,18 +857,26 @@ int launch_softclip_match(wamd_ctx* ctx, const wamd_reads* r, const wamd_softcli
         WAMD_HIP(hipFuncSetAttribute(bytes ? (const void*)softclip_match_kernel<uint8_t>
                                            : (const void*)softclip_match_kernel<uint16_t>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    uint32_t per_cu = (uint32_t)((160 * 1024) / lds);
-    per_cu = per_cu < 1 ? 1 : (per_cu > 16 ? 16 : per_cu);
+    // persistent blocks, as many as are resident at once by the runtime's count (one fewer when they have to stride: a
+    // block too many per CU would run its share in a second round, alone - and the count has been seen one too high)
+    int resident = 0;
+    WAMD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, bytes ? (const void*)softclip_match_kernel<uint8_t>
+                                                                           : (const void*)softclip_match_kernel<uint16_t>,
+                                                          64, (size_t)lds));
+    uint32_t* work = band_flags(ctx, s);   // the stream's first word (myers_distance.hip): launches on a stream are ordered
+    if (work)
+        WAMD_HIP(hipMemsetAsync(work, 0, sizeof(uint32_t), s));
+    const uint32_t per_cu = resident < 1 ? 1u : (uint32_t)(work || resident < 2 ? resident : resident - 1);
     const uint32_t waves = (n + groups - 1) / groups;
-    const uint32_t blocks = waves < 256u * per_cu ? waves : 256u * per_cu;
+    const uint32_t blocks = waves < 256u * per_cu ? waves : 256u * per_cu;   // 256 CUs
     if (bytes)
         hipLaunchKernelGGL(softclip_match_kernel<uint8_t>, dim3(blocks), dim3(64), (uint32_t)lds, s, genome_view(ctx),
                            r->view(), d_tasks, n, *prm, ctx->scoring, ht_size, max_window, r->max_len,
-                           ctx->max_text_len, lay, groups, d_results, d_cigars, cigar_stride, ctx->d_flags);
+                           ctx->max_text_len, lay, groups, d_results, d_cigars, cigar_stride, ctx->d_flags, work);
     else
         hipLaunchKernelGGL(softclip_match_kernel<uint16_t>, dim3(blocks), dim3(64), (uint32_t)lds, s, genome_view(ctx),
                            r->view(), d_tasks, n, *prm, ctx->scoring, ht_size, max_window, r->max_len,
-                           ctx->max_text_len, lay, groups, d_results, d_cigars, cigar_stride, ctx->d_flags);
+                           ctx->max_text_len, lay, groups, d_results, d_cigars, cigar_stride, ctx->d_flags, work);
     WAMD_HIP(hipGetLastError());
     return WAMD_OK;
 }
