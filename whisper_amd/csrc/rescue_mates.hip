@@ -166,10 +166,12 @@ int launch_rescue_mates(wamd_ctx* ctx, const wamd_reads* r, const wamd_rescue_ta
     const uint32_t blocks = (n + 255) / 256;
     hipLaunchKernelGGL(rescue_prepare_kernel, dim3(blocks), dim3(256), 0, s, rv, d_tasks, n, w.dt, ctx->d_flags);
     WAMD_HIP(hipGetLastError());
-    // CSamGenerator's verifier objects only ever see preprocessRawSeq: last_symbol stays 0; nothing of a rejected
-    // window's distance is used (:402), so the first pass takes the banded kernels where the band fits
+    // CSamGenerator's verifier objects only ever see preprocessRawSeq: last_symbol stays 0.  Nothing of a rejected
+    // window's distance is used (:402), so the banded first pass would do - but the band never fits here (it needs
+    // W + 2k - 61 <= m, and the window is the insert-size model's, several reads long): its two kernels only found
+    // that out for every task (0.13 ms per 2^18), so the first pass is the whole-column kernel at once
     int rc = launch_align(ctx, r, w.dt, n, 0, prm->enable_short_indel_refinement ? 1 : 0, w.ar, d_ext, ext_stride, w.align_ws,
-                          (ws_bytes - (uint64_t)((char*)w.align_ws - (char*)d_ws)) & ~255ull, s, WAMD_DISTANCE_ACCEPTED_ONLY);
+                          (ws_bytes - (uint64_t)((char*)w.align_ws - (char*)d_ws)) & ~255ull, s, WAMD_DISTANCE_EXACT);
     if (rc)
         return rc;
     hipLaunchKernelGGL(rescue_merge_kernel, dim3(blocks), dim3(256), 0, s, rv, d_tasks, n, w.ar, w.rec, w.it, d_results, d_ext,
