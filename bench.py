@@ -250,7 +250,7 @@ def boundary_compact(ctx, device, blob, off, lens, tasks, n, ref_size):
     k = K_ERR
     fl, fr = synth.stage_segments(M, k)[1]
     n_reads = n // c
-    bins = 4
+    bins = int(os.environ.get("WAMD_BENCH_BINS", "4"))
     per = n_reads // bins
     rng = np.random.default_rng(1234)
     out = {"candidates_per_read": c, "reads_per_bin": per, "bins": bins,
@@ -318,21 +318,41 @@ def boundary_compact(ctx, device, blob, off, lens, tasks, n, ref_size):
         a, e = b * per, (b + 1) * per
         batch[b & 1].refill(p_blob.array[bin_base[b]:], p_off.array[a:e], p_lens.array[a:e], stream=up_stream.cuda_stream)
 
+    # one worker thread fills the other batch while this thread verifies (what a mapper's reader thread would do)
+    import queue
+    todo, done = queue.Queue(), queue.Queue()
+
+    def worker():
+        while True:
+            b = todo.get()
+            if b is None:
+                return
+            try:
+                refill(b)
+                done.put(None)
+            except BaseException as e:     # hand the failure to the timing thread instead of dying silently
+                done.put(e)
+
+    th = threading.Thread(target=worker, daemon=True)
+    th.start()
+
     def pipeline():
         refill(0)
         for b in range(bins):
-            th = None
             if b + 1 < bins:
-                th = threading.Thread(target=refill, args=(b + 1,))
-                th.start()
+                todo.put(b + 1)
             verify(b, batch[b & 1])
-            if th:
-                th.join()
+            if b + 1 < bins:
+                e = done.get()
+                if e is not None:
+                    raise e
 
     pipeline()      # (the first pass pays for the second thread's first calls into the runtime)
     t0 = time.perf_counter()
     pipeline()
     dt = time.perf_counter() - t0
+    todo.put(None)
+    th.join()
     out["host_to_host_compact_with_reads_upload_candidates_per_s"] = bins * per * c / dt
     t0 = time.perf_counter()
     refill(0)
