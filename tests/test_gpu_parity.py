@@ -516,6 +516,43 @@ def test_softclip_match_long_reads(oracle, m, W, mql):
             assert bytes(gcig[i, :n]) == bytes(wcig[i, :n]), i
 
 
+def test_empty_batches(ctx):
+    """Every host-pointer entry point with no tasks (an empty bin, a pair block with no rescue to do) is a no-op that
+    returns empty results and leaves no error behind."""
+    codes, packed, (blob, off, lens), tasks = common.softclip_workload(8, seed=1, W=300)
+    reads = ctx.upload_reads(blob, off, lens, 1, orientations=3)
+    z = lambda dt: np.zeros(0, dt)
+    assert len(ctx.dynamic_programming(reads, z(api.DIST_TASK), -1)) == 0
+    assert len(ctx.lev_diag(reads, z(api.LEVDIAG_TASK))) == 0
+    assert len(ctx.cf_filter(reads, z(api.CF_TASK))) == 0
+    res, cig = ctx.align(reads, z(api.DIST_TASK))
+    assert len(res) == 0 and cig.shape[0] == 0
+    assert len(ctx.indel_match(reads, z(api.INDEL_TASK))) == 0
+    res, cig = ctx.indel_ext_cigar(reads, z(api.INDEL_CIGAR_TASK))
+    assert len(res) == 0
+    res, cig = ctx.softclip_match(reads, tasks[:0])
+    assert len(res) == 0
+    res, ext = ctx.rescue_mates(reads, z(api.RESCUE_TASK))
+    assert len(res) == 0
+    out = ctx.finish_pairs(reads, z(api.FINISH_TASK))
+    assert len(out[0]) == 0
+    rec, cg = ctx.clip_boundary(z(api.CLIP_RECORD), np.zeros((0, 64), np.uint8))
+    assert len(rec) == 0
+    rec, cg = ctx.clip_illegal(z(api.CLIP_ILLEGAL_TASK), z(api.CLIP_RECORD), np.zeros((0, 64), np.uint8))
+    assert len(rec) == 0
+    rec, cg = ctx.clip_overlapping_pairs(z(api.CLIP_PAIR_TASK), z(api.CLIP_RECORD), np.zeros((0, 64), np.uint8))
+    assert len(rec) == 0
+    out = ctx.sam_cigar(np.zeros((0, 64), np.uint8))
+    assert len(out[0]) == 0
+    err = ctx.verify_sa_candidates(reads, api.sa_batch(len(lens), 5, (50, 75), 0, api.SA_VERIFIER_DISTANCE),
+                                   np.zeros(2 * len(lens), np.uint16), z(np.uint32))
+    assert len(err[0] if isinstance(err, tuple) else err) == 0
+    wire, sizes = ctx.serialize_mappings(z(api.MAPPING), z(np.uint8))
+    assert len(sizes) == 0
+    assert ctx.take_flags() == 0
+    reads.free()
+
+
 def test_softclip_match_errors(ctx, oracle):
     """Reads shorter than one 20-mer and windows above max_text_len are errors, as is a table of more than 65 536 cells."""
     codes, packed, (blob, off, lens), tasks = common.softclip_workload(64, seed=3, W=300)
