@@ -339,7 +339,8 @@ WAMD_API uint32_t wamd_reads_count(const wamd_reads* reads);
  * last_symbol: WAMD_LAST_SYMBOL_FROM_READ after preprocess() (mapping stage), or the
  * value the object's last preprocess() left behind when the read came through
  * preprocessRawSeq() (0 in CSamGenerator) - only the M256 tie-break reads it
- * (LevMyers256.hpp:191-196). */
+ * (LevMyers256.hpp:191-196).  WAMD_LAST_SYMBOL_FROM_READ with reads uploaded as WAMD_READS_ASCII
+ * means 0, the value of an object that has only seen preprocessRawSeq() (LevMyers64.cpp:35). */
 WAMD_API int wamd_verify_distance(wamd_ctx* ctx, const wamd_reads* reads,
                                   const wamd_dist_task* tasks, uint32_t n, int last_symbol,
                                   wamd_dist_result* results);

@@ -1065,6 +1065,10 @@ int launch_distance(wamd_ctx* ctx, const wamd_reads* r, const wamd_dist_task* d_
     WAMD_HIP(hipSetDevice(ctx->device));
     if (n == 0)
         return WAMD_OK;
+    // WAMD_LAST_SYMBOL_FROM_READ is what preprocess() leaves behind (LevMyers64.cpp:182, 192).  preprocessRawSeq() never
+    // writes last_symbol, so a batch that came in as ASCII gets what a fresh object holds: 0 (LevMyers64.cpp:35)
+    if (last_symbol < 0 && r->encoding == WAMD_READS_ASCII)
+        last_symbol = 0;
     const GenomeView g = genome_view(ctx);
     const ReadsView rv = r->view();
     const uint32_t mt = ctx->max_text_len;
