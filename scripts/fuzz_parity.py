@@ -336,6 +336,78 @@ def check_rescue(ctx, oracle, rng, gen, report):
     report("rescue mates m %d %s" % (m, name), len(tasks), np.nonzero(badm)[0], tasks, got, want)
 
 
+def saloop_case(rng, ref):
+    """A fresh workload of the suffix-array loops, run through the reference's own loops (as tests/golden/make_golden.py
+    makes the saloop_* fixtures): the dictionary tests/test_gpu_sa_loop.py reads."""
+    m = int(rng.choice([100, 150, 151, 250]))
+    sensitive = int(rng.integers(0, 2))
+    k = int(rng.integers(8, 17)) if sensitive else int(rng.integers(1, 13))
+    stage = int(k / 2.5) if sensitive else k
+    segi = int(rng.integers(0, stage + 1))
+    seg = common.stage_segments(m, stage)[segi]
+    codes, packed, reads, sa_dir, sa_rc = common.sa_loop_workload(int(rng.integers(1, 1 << 30)), 200, 3, m, k, seg, min_read_len=m)
+    ref_size = codes.numel()
+    prm = ob.default_indel_params(0.6)
+    rc, ranges, best, pushed, pdir, pread = ref.search_reads(packed, ref_size, *reads, sa_dir, sa_rc, seg, m, k,
+                                                             sensitive=sensitive, enable_indels=sensitive, params=prm)
+    assert rc == 0, rc
+    n = len(reads[2])
+    reads2 = common.with_reverse_reads(reads)
+    cf, dist, lev, indel, commit, read_first = common.sa_loop_tasks(ranges, reads[2], sa_dir, sa_rc, ref_size, seg, m, k, 50)
+    committed = np.zeros(len(commit), ob.MAPPING)
+    cand_read = np.repeat(np.arange(n), np.diff(read_first).astype(np.int64))
+    j = 0
+    for i in range(len(commit)):
+        if j < len(pushed) and pread[j] == cand_read[i] and pdir[j] == commit["direct"][i] and (
+                int(pushed[j]["pos"]) == int(commit[i]["lev_pos"]) if pushed[j]["type"] == 0
+                else abs(int(pushed[j]["pos"]) - int(commit[i]["lev_pos"])) <= m + 64):
+            committed[i] = pushed[j]
+            committed[i]["found"] = 1
+            j += 1
+        else:
+            committed[i]["type"] = 8
+    assert j == len(pushed), (j, len(pushed))
+    read_ids = (np.arange(n, dtype=np.uint64) * 3 + (5 << 32)).astype(np.uint64)
+    commit_full = commit.copy()
+    commit_full["has_indel"] = sensitive
+    rc, group = ref.result_groups(commit_full, committed, read_first, read_ids, ob.GroupParams(5, 4, 1024, 0))
+    assert rc == 0
+    blob, off, lens = reads2
+    z = dict(packed=packed, ref_size=np.uint32(ref_size), blob=blob, off=off, lens=lens, n_reads=n,
+             seg=np.array(seg, np.uint32), k=k, min_read_len=m, sensitive=sensitive, min_clipped_factor=0.6, cf=cf, dist=dist,
+             lev=lev, indel=indel, commit=commit, read_first=read_first, read_ids=read_ids, pushed=pushed, pushed_direct=pdir,
+             group_bytes=group)
+    return "m %d k %d seg %d sensitive %d (%d candidates, %d pushed)" % (m, k, segi, sensitive, len(commit), len(pushed)), z
+
+
+def check_saloop(ctx, oracle, rng, gen, report):
+    """The device leg of the mapping loop (filter + verify -> Match -> commit -> result groups, and the compact form)
+    against the reference's search_in_*_range_dir_and_rc on a fresh workload; needs oracle/_ref."""
+    if not ob.have_reference():
+        return
+    label, z = saloop_case(rng, ob.Reference())
+    if isinstance(ctx, RefCtx):     # the CPU run stops at "the reference's loops ran and their pushes are accounted for"
+        report("saloop " + label, len(z["commit"]), np.zeros(0, int), None, None, None)
+        return
+    import golden_util
+    import test_gpu_sa_loop as T
+    keep = golden_util.load
+    golden_util.load = lambda name: z
+    bad = np.zeros(0, int)
+    try:
+        for mode in (api.DISTANCE_EXACT, api.DISTANCE_ACCEPTED_ONLY):
+            T.test_device_loop_equals_the_reference_loop("fuzz", mode)
+        for filtered in (True, False):
+            T.test_compact_form_equals_the_task_form("fuzz", filtered)
+    except AssertionError:
+        import traceback
+        print(traceback.format_exc()[-1500:], flush=True)
+        bad = np.arange(1)
+    finally:
+        golden_util.load = keep
+    report("saloop " + label, len(z["commit"]), bad, [label], ["see above"], [""])
+
+
 class RefCtx:
     """The reference's own LevMyers objects behind the calls check_distance makes (--cpu-reference)."""
 
@@ -381,7 +453,7 @@ class RefCtx:
 
 
 FAMILIES = {"distance": check_distance, "levdiag": check_levdiag, "cf": check_cf, "indel": check_indel,
-            "softclip": check_softclip, "post": check_post, "finish": check_finish, "rescue": check_rescue}
+            "softclip": check_softclip, "post": check_post, "finish": check_finish, "rescue": check_rescue, "saloop": check_saloop}
 
 
 def main():
@@ -399,7 +471,7 @@ def main():
     gen = common.genome()
     if args.cpu_reference:
         ctx = RefCtx(gen)
-        args.families = "distance"
+        args.families = ",".join(f for f in args.families.split(",") if f in ("distance", "saloop"))
     else:
         ctx = api.Context(gen[1], ref_size=gen[0].numel(), cur_offset=0)
     totals, failed = {}, []

@@ -173,6 +173,9 @@ def test_compact_form_equals_the_task_form(name, filtered):
         lev_t, dist_t = z["lev"].copy(), z["dist"].copy()
         lev_t["max_mismatches"] = per_cand
         dist_t["max_ed"] = per_cand
+        # the loops take the window from the same max_mismatches (mapping_core_sa.cpp:237: sa - start_pos - k, len + 2k)
+        dist_t["ref_pos"] = dist_t["ref_pos"] + (k - per_cand)
+        dist_t["max_distance_in_ref"] = dist_t["max_distance_in_ref"] - 2 * (k - per_cand.astype(np.uint32))
         d_lev2, d_dist2 = dev(lev_t), dev(dist_t)
         torch.cuda.synchronize()
         with torch.cuda.stream(ts):
@@ -186,7 +189,7 @@ def test_compact_form_equals_the_task_form(name, filtered):
         want2 = np.where(e2 <= per_cand, e2, per_cand.astype(np.uint32) + 1).astype(np.uint8)
         got2 = ctx.verify_sa_candidates(reads, b, counts, sa, read_k=read_k)
         np.testing.assert_array_equal(got2, want2)
-        assert (want2 != want_e).any()
+        assert (want2 != want_e).any() or (read_k == k).all()     # (the per-read k changed something, where it could)
         # counts that do not add up are an error, on either path
         bad = counts.copy()
         bad[0, 0] += 1
