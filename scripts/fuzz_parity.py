@@ -336,6 +336,28 @@ def check_rescue(ctx, oracle, rng, gen, report):
     report("rescue mates m %d %s" % (m, name), len(tasks), np.nonzero(badm)[0], tasks, got, want)
 
 
+def check_groups(ctx, oracle, rng, gen, report):
+    """The commit block of the mapping loop and the bin's result-group bytes (rows K / (f)3)."""
+    n_reads = int(rng.integers(200, 6000))
+    k = int(rng.integers(1, 17))
+    max_cand = int(rng.integers(1, 40))
+    mnm = int(rng.choice([1, 2, 3, 8, 60, 1024]))
+    id_bytes = int(rng.integers(3, 9))
+    t, indel, read_first, read_ids = common.commit_workload(oracle, n_reads, int(rng.integers(1, 1 << 30)), k=k, max_cand=max_cand)
+    if id_bytes < 8:
+        read_ids = read_ids & np.uint64((1 << (8 * id_bytes)) - 1)
+    _, want_c = oracle.commit(t, indel)
+    rc, want = oracle.result_groups(t, want_c, read_first, read_ids, ob.GroupParams(id_bytes, 4, mnm, 0))
+    assert rc == 0
+    committed, data, offs, flags, _ = common.gpu_result_groups(ctx, t, indel, read_first, read_ids, id_bytes, mnm)
+    bad = np.nonzero(committed != want_c)[0]
+    if not len(bad) and (flags or len(data) != len(want) or bytes(data) != bytes(want)):
+        print("   group bytes differ: flags %d, %d bytes against %d" % (flags, len(data), len(want)))
+        bad = np.arange(1)
+    report("groups reads %d k %d max_cand %d max_no_mappings %d id_bytes %d" % (n_reads, k, max_cand, mnm, id_bytes),
+           len(t), bad, t, committed, want_c)
+
+
 def saloop_case(rng, ref):
     """A fresh workload of the suffix-array loops, run through the reference's own loops (as tests/golden/make_golden.py
     makes the saloop_* fixtures): the dictionary tests/test_gpu_sa_loop.py reads."""
@@ -453,7 +475,8 @@ class RefCtx:
 
 
 FAMILIES = {"distance": check_distance, "levdiag": check_levdiag, "cf": check_cf, "indel": check_indel,
-            "softclip": check_softclip, "post": check_post, "finish": check_finish, "rescue": check_rescue, "saloop": check_saloop}
+            "softclip": check_softclip, "post": check_post, "finish": check_finish, "rescue": check_rescue, "groups": check_groups,
+            "saloop": check_saloop}
 
 
 def main():

@@ -113,8 +113,10 @@ __global__ __launch_bounds__(256) void commit_kernel(uint32_t n, const wamd_comm
         if (cm.type == WAMD_MAP_NONE || !x_lt_y)
             cm = y;
     }
-    if (cm.type != WAMD_MAP_NONE && cm.penalty > t.max_mismatches)   // :338
+    if (cm.type != WAMD_MAP_NONE && cm.penalty > t.max_mismatches) {   // :338: nothing of it is pushed
+        cm = wamd_mapping{};
         cm.type = WAMD_MAP_NONE;
+    }
     cm.found = cm.type != WAMD_MAP_NONE;
     out[i] = cm;
 }
