@@ -291,11 +291,23 @@ def boundary_compact(ctx, device, blob, off, lens, tasks, n, ref_size):
 
     # (1) reads resident
     resident = [upload(b) for b in range(bins)]
-    verify(0, resident[0])                      # staging buffers and streams exist after this
-    t0 = time.perf_counter()
-    for b in range(bins):
-        verify(b, resident[b])
-    dt = time.perf_counter() - t0
+    for b in range(bins):                       # staging buffers and streams exist after this, and every stream has
+        verify(b, resident[b])                  # copied from every buffer once (the first such copy is slow)
+    def median_pass(fn, passes=5):
+        # a pass over the bins is a few milliseconds of host-driven work: one stall of the host shows in it, so the
+        # rate is the median of five passes
+        ts = []
+        for _ in range(passes):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts))
+
+    def resident_pass():
+        for b in range(bins):
+            verify(b, resident[b])
+
+    dt = median_pass(resident_pass)
     out["host_to_host_compact_candidates_per_s"] = bins * per * c / dt
     # parity: the task form of bin 0's candidates through the synchronous host-pointer call, clamped at k + 1
     tt = np.zeros(per * c, api.DIST_TASK)
@@ -348,12 +360,41 @@ def boundary_compact(ctx, device, blob, off, lens, tasks, n, ref_size):
                     raise e
 
     pipeline()      # (the first pass pays for the second thread's first calls into the runtime)
-    t0 = time.perf_counter()
-    pipeline()
-    dt = time.perf_counter() - t0
+    dt = median_pass(pipeline)
     todo.put(None)
     th.join()
     out["host_to_host_compact_with_reads_upload_candidates_per_s"] = bins * per * c / dt
+    # the same with wamd_reads_refill_async (sizes stated, no host pass, no wait): one host thread enqueues bin b + 1's
+    # reads on the upload stream, verifies bin b, and waits for the upload stream before it goes on
+    max_len = int(lens[:n_reads].max())
+    bin_bytes = [(int(off[(b + 1) * per - 1]) + (int(lens[(b + 1) * per - 1]) + 1) // 2) - int(off[b * per]) for b in range(bins)]
+
+    def refill_async(b):
+        a, e = b * per, (b + 1) * per
+        batch[b & 1].refill_async(p_blob.array[bin_base[b]:], bin_bytes[b], p_off.array[a:e], p_lens.array[a:e], max_len,
+                                  stream=up_stream.cuda_stream)
+
+    def pipeline_async():
+        refill_async(0)
+        up_stream.synchronize()
+        for b in range(bins):
+            if b + 1 < bins:
+                refill_async(b + 1)
+            verify(b, batch[b & 1])
+            up_stream.synchronize()
+
+    pipeline_async()
+    pipeline_async()      # (two passes before the clock: the first calls on a new path are slow twice over)
+    p_err.array[:] = 0xEE
+    dt = median_pass(pipeline_async)
+    out["host_to_host_compact_with_async_reads_refill_candidates_per_s"] = bins * per * c / dt
+    out["async_refill_matches_task_form"] = bool((np.minimum(want, k + 1) == p_err.array[:per * c]).all()) and \
+        ctx.take_flags(up_stream.cuda_stream) == 0
+    t0 = time.perf_counter()
+    refill_async(0)
+    out["reads_refill_async_enqueue_ms_per_bin"] = (time.perf_counter() - t0) * 1e3
+    up_stream.synchronize()
+    out["reads_refill_async_ms_per_bin"] = (time.perf_counter() - t0) * 1e3
     t0 = time.perf_counter()
     refill(0)
     out["reads_refill_ms_per_bin"] = (time.perf_counter() - t0) * 1e3

@@ -330,6 +330,18 @@ WAMD_API int wamd_reads_upload_stream(wamd_ctx* ctx, const uint8_t* data, const 
  * kernel may still be reading the batch.  On failure the batch is left empty. */
 WAMD_API int wamd_reads_refill(wamd_reads* reads, const uint8_t* data, const uint64_t* offsets,
                                const uint32_t* lens, uint32_t n, void* stream);
+/* The same without a host pass over the reads, and without waiting: the caller states what its bin already knows -
+ * the bytes of `data` and an upper bound on the read lengths (the reference sizes every buffer of a stage by
+ * params->max_read_len, mapping_core.cpp:95-108, and a bin arrives as one block) - and the call returns with its
+ * copies and kernels enqueued on `stream` (NULL = the context's): data / offsets / lens must stay untouched until that
+ * stream has passed them, and verification calls on other streams must wait for it.  The device holds every read
+ * against the two statements first; a read of length 0, longer than max_len or reaching past data_bytes raises error
+ * bit 5 (wamd_ctx_take_flags; WAMD_ERR_INVALID_ARG from the host-pointer calls) and is replaced by a one-symbol read -
+ * such a batch must not be used.  The batch's dword count follows max_len (results do not depend on it).
+ * wamd_reads_refill spends 0.5 of its 1.5 ms per 2^19 reads in that host pass and 0.1 in the wait. */
+WAMD_API int wamd_reads_refill_async(wamd_reads* reads, const uint8_t* data, uint64_t data_bytes,
+                                     const uint64_t* offsets, const uint32_t* lens, uint32_t n,
+                                     uint32_t max_len, void* stream);
 WAMD_API int wamd_reads_free(wamd_reads* reads);
 WAMD_API uint32_t wamd_reads_count(const wamd_reads* reads);
 

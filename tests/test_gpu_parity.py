@@ -872,3 +872,73 @@ def test_reads_refill_and_stream_upload(ctx, oracle):
         assert bytes(got[1][i, :e]) == bytes(want[1][i, :e]), i
     r2.free()
     r3.free()
+
+
+def test_reads_refill_async(ctx, oracle):
+    """wamd_reads_refill_async: stated sizes instead of a host pass, no wait.  Page-locked and pageable sources, a
+    max_len above the longest read (more dwords per vector: same answers), mixed lengths, LevDiag and the alignment on
+    the refilled batch; a read that breaks what was stated raises the malformed-task bit and cannot reach past its
+    buffers."""
+    import torch
+    st = torch.cuda.Stream()
+    w1 = common.distance_workload(150, 12, 3000, seed=911)
+    w2 = common.distance_workload(100, 10, 5000, seed=912)
+    w3 = common.distance_workload(250, 17, 700, seed=913)
+    reads = ctx.upload_reads(*w1[2], api.READS_NIBBLE)
+    for (codes, packed, (blob, off, lens), tasks), max_len in ((w2, 100), (w3, 256), (w1, 150), (w1, 190)):
+        rc, want = oracle.distance(packed, blob, off, lens, 0, tasks, -1)
+        pb, po, pl = api.PinnedBuffer(len(blob) + 64, np.uint8), api.PinnedBuffer(len(lens), np.uint64), \
+            api.PinnedBuffer(len(lens), np.uint32)
+        pb.array[:len(blob)] = blob
+        po.array[:] = off[:len(lens)]
+        pl.array[:] = lens
+        reads.refill_async(pb.array, len(blob), po.array, pl.array, max_len, stream=st.cuda_stream)
+        st.synchronize()
+        assert ctx.take_flags(st.cuda_stream) == 0
+        np.testing.assert_array_equal(ctx.dynamic_programming(reads, tasks), want)
+        for b in (pb, po, pl):
+            b.free()
+    # pageable arrays (the copies are then synchronous, the call still correct), other strands, the alignment
+    codes, packed, (blob, off, lens), tasks = common.distance_workload(150, 13, 1500, seed=914, encoding=1, W=177)
+    r3 = ctx.upload_reads(*common.distance_workload(120, 9, 900, seed=915, encoding=1)[2], 1)
+    want = oracle.align(packed, blob, off, lens, 1, tasks, 0, 1, cigar_stride=512)
+    off_n = np.ascontiguousarray(off[:len(lens)])
+    r3.refill_async(blob, len(blob), off_n, lens, 150, stream=st.cuda_stream)
+    st.synchronize()
+    got = ctx.align(r3, tasks, 0, 1, cigar_stride=512)
+    np.testing.assert_array_equal(got[0], want[1])
+    for i in np.nonzero(want[1]["ok"])[0]:
+        e = want[1]["cigar_len"][i] + 1
+        assert bytes(got[1][i, :e]) == bytes(want[2][i, :e]), i
+    r3.free()
+    # mixed lengths + LevDiag (direct orientation only)
+    codes, packed, (blob, off, lens), tasks = common.levdiag_odd_workload(2000, 77)
+    rc, want = oracle.levdiag(packed, codes.numel(), 0, blob, off, lens, tasks)
+    r4 = ctx.upload_reads(*common.levdiag_workload(100, 3, 25, 50, 500, seed=5)[2], 0, orientations=1)
+    off_n = np.ascontiguousarray(off[:len(lens)])
+    r4.refill_async(blob, len(blob), off_n, lens, int(lens.max()), stream=st.cuda_stream)
+    st.synchronize()
+    np.testing.assert_array_equal(ctx.lev_diag(r4, tasks), want)
+    r4.free()
+    # reads that break the statements: longer than max_len, empty, reaching past the block
+    codes, packed, (blob, off, lens), tasks = w1
+    for what in ("long", "empty", "past"):
+        l2, o2 = lens.copy(), np.ascontiguousarray(off[:len(lens)]).copy()
+        if what == "long":
+            l2[17] = 900
+        elif what == "empty":
+            l2[18] = 0
+        else:
+            o2[19] = len(blob) - 10
+        reads.refill_async(blob, len(blob), o2, l2, 150, stream=st.cuda_stream)
+        st.synchronize()
+        assert ctx.take_flags(st.cuda_stream) & 32, what
+        with pytest.raises(api.WamdError):
+            reads.refill_async(blob, 0, o2, l2, 150, stream=st.cuda_stream)
+    # and the batch is good again after a clean refill
+    reads.refill_async(blob, len(blob), np.ascontiguousarray(off[:len(lens)]), lens, 150, stream=st.cuda_stream)
+    st.synchronize()
+    assert ctx.take_flags(st.cuda_stream) == 0
+    rc, want = oracle.distance(packed, blob, off, lens, 0, tasks, -1)
+    np.testing.assert_array_equal(ctx.dynamic_programming(reads, tasks), want)
+    reads.free()

@@ -159,7 +159,7 @@ STATUS = {0: "WAMD_OK", 1: "WAMD_ERR_INVALID_ARG", 2: "WAMD_ERR_HIP", 3: "WAMD_E
 EXPORTS = [
     "wamd_version", "wamd_last_error", "wamd_device_count", "wamd_ctx_create",
     "wamd_sa_candidates_workspace_bytes", "wamd_verify_sa_candidates_dev", "wamd_verify_sa_candidates", "wamd_host_alloc",
-    "wamd_host_free", "wamd_reads_upload_stream", "wamd_reads_refill", "wamd_rescue_workspace_bytes", "wamd_rescue_mates",
+    "wamd_host_free", "wamd_reads_upload_stream", "wamd_reads_refill", "wamd_reads_refill_async", "wamd_rescue_workspace_bytes", "wamd_rescue_mates",
     "wamd_rescue_mates_dev",
     "wamd_ctx_create_dev", "wamd_ctx_destroy", "wamd_ctx_set_scoring",
     "wamd_ctx_set_max_text_len", "wamd_ctx_set_distance_mode", "wamd_ctx_set_reference_params", "wamd_ctx_stream",
@@ -275,6 +275,18 @@ class Reads:
         self.max_len = int(lens.max()) if self.n else 0
         _check(lib().wamd_reads_refill(self.h, _ptr(data), _ptr(offsets), _ptr(lens), C.c_uint32(self.n),
                                        C.c_void_p(stream or 0)))
+
+    def refill_async(self, data, data_bytes, offsets, lens, max_len, stream=None):
+        """wamd_reads_refill_async: no host pass over the reads, no wait.  The arrays are the caller's (page-locked ones
+        make the copies asynchronous) and must stay untouched until `stream` has passed the call; they are kept referenced
+        here until the next refill."""
+        assert data.dtype == np.uint8 and offsets.dtype == np.uint64 and lens.dtype == np.uint32
+        assert data.flags.c_contiguous and offsets.flags.c_contiguous and lens.flags.c_contiguous
+        self.n = len(lens)
+        self.max_len = int(max_len)
+        self._pending = (data, offsets, lens)
+        _check(lib().wamd_reads_refill_async(self.h, _ptr(data), C.c_uint64(int(data_bytes)), _ptr(offsets), _ptr(lens),
+                                             C.c_uint32(self.n), C.c_uint32(int(max_len)), C.c_void_p(stream or 0)))
 
     def free(self):
         if self.h:

@@ -351,10 +351,34 @@ __global__ __launch_bounds__(256) void code_off_spread_kernel(uint32_t n, const 
         code_off[n] = base + incl;
 }
 
-int launch_reads_prepare(wamd_ctx* ctx, wamd_reads* r, const uint8_t* d_raw,
-                         const uint64_t* d_raw_off, hipStream_t s)
+// wamd_reads_refill_async: the caller stated the block's bytes and its longest read and no host pass has looked at
+// the reads.  Every read is held against both before any kernel uses it; one that breaks them raises the malformed-task
+// flag and becomes a one-symbol read at the start of the block, so that nothing downstream leaves its buffers.
+__global__ __launch_bounds__(256) void reads_check_kernel(uint32_t n, uint32_t* __restrict__ lens, uint64_t* __restrict__ raw_off,
+                                                          uint32_t max_len, uint64_t data_bytes, int nibble,
+                                                          uint32_t* __restrict__ flags)
 {
-    (void)ctx;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const uint32_t len = lens[i];
+    const uint64_t off = raw_off[i];
+    const uint64_t bytes = nibble ? ((uint64_t)len + 1) / 2 : len;
+    if (len == 0 || len > max_len || off > data_bytes || bytes > data_bytes - off) {
+        raise_flag(flags, FLAG_ARG);
+        lens[i] = 1;
+        raw_off[i] = 0;
+    }
+}
+
+int launch_reads_prepare(wamd_ctx* ctx, wamd_reads* r, const uint8_t* d_raw,
+                         const uint64_t* d_raw_off, hipStream_t s, uint64_t stated_bytes)
+{
+    if (stated_bytes) {
+        hipLaunchKernelGGL(reads_check_kernel, dim3((r->n + 255) / 256), dim3(256), 0, s, r->n, r->d_lens, r->d_raw_off,
+                           r->max_len, stated_bytes, r->encoding == WAMD_READS_NIBBLE ? 1 : 0, ctx->d_flags);
+        WAMD_HIP(hipGetLastError());
+    }
     const uint32_t dwords_per_read = ((r->max_len + 1) / 2 + 3) / 4;
     {   // d_meta (4 bytes per read and orientation) lends its front to the block sums; it is cleared afterwards
         const uint32_t nb = (r->n + 255) / 256;

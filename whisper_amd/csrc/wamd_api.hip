@@ -347,8 +347,16 @@ int wamd_ctx_take_flags(wamd_ctx* ctx, void* stream, uint32_t* flags)
 
 // ---- reads -----------------------------------------------------------------------
 
+// what a batch's buffers are sized by: found by a host pass over offsets / lens, or stated by the caller
+struct ReadSizes {
+    uint32_t max_len;
+    uint64_t raw_end;   // bytes of `data` the reads reach
+    uint64_t acc;       // bytes of all reads' canonical codes (an upper bound when stated)
+    bool stated;        // the device holds every read against max_len / raw_end before anything uses it
+};
 static int reads_upload_on(wamd_ctx* ctx, const uint8_t* data, const uint64_t* offsets, const uint32_t* lens, uint32_t n,
-                           int encoding, int orientations, hipStream_t s, wamd_reads* reuse, wamd_reads** out);
+                           int encoding, int orientations, hipStream_t s, wamd_reads* reuse, wamd_reads** out,
+                           const ReadSizes* stated = nullptr);
 
 int wamd_reads_upload(wamd_ctx* ctx, const uint8_t* data, const uint64_t* offsets,
                       const uint32_t* lens, uint32_t n, int encoding, int orientations,
@@ -380,6 +388,23 @@ int wamd_reads_refill(wamd_reads* reads, const uint8_t* data, const uint64_t* of
                            stream ? (hipStream_t)stream : reads->ctx->stream, reads, &same);
 }
 
+int wamd_reads_refill_async(wamd_reads* reads, const uint8_t* data, uint64_t data_bytes, const uint64_t* offsets,
+                            const uint32_t* lens, uint32_t n, uint32_t max_len, void* stream)
+{
+    if (!reads || max_len == 0 || max_len > WAMD_MAX_READ_LEN || (n && data_bytes == 0)) {
+        set_error("wamd_reads_refill_async: null batch, no bytes, or max_len outside 1..%u", WAMD_MAX_READ_LEN);
+        return WAMD_ERR_INVALID_ARG;
+    }
+    ReadSizes sz;
+    sz.max_len = max_len;
+    sz.raw_end = data_bytes;
+    sz.acc = (uint64_t)n * (((uint64_t)(max_len + 1) / 2 + 3) / 4 * 4);
+    sz.stated = true;
+    wamd_reads* same = nullptr;
+    return reads_upload_on(reads->ctx, data, offsets, lens, n, reads->encoding, reads->orientations,
+                           stream ? (hipStream_t)stream : reads->ctx->stream, reads, &same, &sz);
+}
+
 // device buffer of at least `want` bytes; an existing one that is large enough stays (a refill allocates nothing)
 static hipError_t reads_buffer(void** p, uint64_t* cap, uint64_t want, bool generous)
 {
@@ -397,7 +422,8 @@ static hipError_t reads_buffer(void** p, uint64_t* cap, uint64_t want, bool gene
 }
 
 static int reads_upload_on(wamd_ctx* ctx, const uint8_t* data, const uint64_t* offsets, const uint32_t* lens, uint32_t n,
-                           int encoding, int orientations, hipStream_t s, wamd_reads* reuse, wamd_reads** out)
+                           int encoding, int orientations, hipStream_t s, wamd_reads* reuse, wamd_reads** out,
+                           const ReadSizes* stated)
 {
     if (!ctx || !out || (n && (!data || !offsets || !lens)) ||
         (encoding != WAMD_READS_NIBBLE && encoding != WAMD_READS_ASCII) || orientations < 1 ||
@@ -412,13 +438,19 @@ static int reads_upload_on(wamd_ctx* ctx, const uint8_t* data, const uint64_t* o
     uint64_t acc = 0;     // bytes of all reads' codes (where each read's start: a scan on the device)
     uint32_t min_len = n ? 0xffffffffu : 1u;
     const uint32_t nib = encoding == WAMD_READS_NIBBLE ? 1u : 0u;
-    for (uint32_t i = 0; i < n; ++i) {     // (no early exit: the loop vectorises)
+    for (uint32_t i = 0; i < n && !stated; ++i) {     // (no early exit inside: the loop vectorises)
         const uint32_t len = lens[i];
         max_len = len > max_len ? len : max_len;
         min_len = len < min_len ? len : min_len;
         const uint64_t end = offsets[i] + (nib ? (len + 1) / 2 : len);
         raw_end = end > raw_end ? end : raw_end;
         acc += ((uint64_t)(len + 1) / 2 + 3) / 4 * 4;
+    }
+    if (stated) {     // wamd_reads_refill_async: no host pass (half a millisecond per 2^19 reads); the device checks
+        max_len = stated->max_len;
+        raw_end = stated->raw_end;
+        acc = stated->acc;
+        min_len = 1;
     }
     if (min_len == 0 || max_len > WAMD_MAX_READ_LEN) {
         uint32_t i = 0;
@@ -477,8 +509,10 @@ static int reads_upload_on(wamd_ctx* ctx, const uint8_t* data, const uint64_t* o
             rc = hip_fail(e, "reads upload", __FILE__, __LINE__);
             break;
         }
-        rc = launch_reads_prepare(ctx, r, r->d_raw, r->d_raw_off, s);
+        rc = launch_reads_prepare(ctx, r, r->d_raw, r->d_raw_off, s, stated ? raw_end : 0);
         if (rc != WAMD_OK)
+            break;
+        if (stated)     // returns with its work enqueued: the caller's buffers stay untouched until `s` has passed it
             break;
         if ((e = hipStreamSynchronize(s)) != hipSuccess) {
             rc = hip_fail(e, "reads prepare", __FILE__, __LINE__);
@@ -766,7 +800,12 @@ int wamd_verify_sa_candidates(wamd_ctx* ctx, const wamd_reads* reads, const wamd
                    o_err = o_pos + up((uint64_t)cmax * 4),
                    o_end = o_err + up(cmax), o_ws = o_end + (end_positions ? up((uint64_t)cmax * 4) : 0),
                    slot_bytes = o_ws + up(sa_candidates_workspace_bytes(cmax, rmax));
-    rc = ensure_stage(ctx, 2 * slot_bytes, 0);
+    // chunks in flight: with two, the copies of chunk i + 2 wait for everything of chunk i (same stream, same slot) and
+    // the kernels run dry between them whenever the link is shared with a reads upload; four keep the link busy
+    constexpr uint32_t DEPTH = sizeof(ctx->pipe) / sizeof(ctx->pipe[0]);
+    const uint32_t n_chunks_est = (n_candidates + CHUNK_C - 1) / CHUNK_C;
+    const uint32_t depth = n_chunks_est < 2 ? 2u : (n_chunks_est < DEPTH ? n_chunks_est : DEPTH);
+    rc = ensure_stage(ctx, depth * slot_bytes, 0);
     if (rc)
         return rc;
     uint32_t r0 = 0, c0 = 0, chunk = 0;
@@ -789,8 +828,8 @@ int wamd_verify_sa_candidates(wamd_ctx* ctx, const wamd_reads* reads, const wamd
         if (seen > n_candidates)
             break;
         if (c) {
-            char* slot = (char*)ctx->d_stage + (uint64_t)(chunk & 1u) * slot_bytes;
-            hipStream_t st = ctx->pipe[chunk & 1u];
+            char* slot = (char*)ctx->d_stage + (uint64_t)(chunk % depth) * slot_bytes;
+            hipStream_t st = ctx->pipe[chunk % depth];
             wamd_sa_batch b = *batch;
             b.read_first = batch->read_first + r0;
             b.n_reads = r1 - r0;

@@ -93,7 +93,7 @@ struct wamd_ctx {
     uint64_t d_stage_bytes;
     void* h_stage;
     uint64_t h_stage_bytes;
-    hipStream_t pipe[2];        // wamd_verify_sa_candidates: chunks alternate between these (created at first use)
+    hipStream_t pipe[4];        // wamd_verify_sa_candidates: chunks take turns on these (created at first use)
     // Host-pointer entry points share d_stage, h_flags and `stream`: each of them holds this lock
     // from its first use of the staging buffer to its last read of the results, so worker threads
     // that flush on one shared context are serialised, never interleaved.
@@ -146,7 +146,7 @@ int flags_to_status(uint32_t flags);
 
 // kernel launchers (each defined next to its kernel)
 int launch_reads_prepare(wamd_ctx* ctx, wamd_reads* r, const uint8_t* d_raw,
-                         const uint64_t* d_raw_off, hipStream_t s);
+                         const uint64_t* d_raw_off, hipStream_t s, uint64_t stated_bytes = 0);
 int ensure_pm(const wamd_reads* r, hipStream_t s);
 int launch_distance(wamd_ctx* ctx, const wamd_reads* r, const wamd_dist_task* d_tasks, uint32_t n,
                     int last_symbol, wamd_dist_result* d_results, int mode, hipStream_t s,
