@@ -670,6 +670,7 @@ public:
         if (which == 1)      // LevDiag on the other strand verifies the reversed read itself (:291)
             memcpy(s.rc_blob.append(bytes), rc_data, bytes);
         s.lens.push_back(size);
+        s.max_len = size > s.max_len ? size : s.max_len;
         s.k.push_back((uint8_t)max_mismatches);
         s.counts.push_back(0);
         s.counts.push_back(0);
@@ -710,8 +711,12 @@ public:
             if (!s.reads)
                 check(wamd_reads_upload(ref_.ctx(), s.blob.data(), s.off.data(), s.lens.data(), n_up, WAMD_READS_NIBBLE, 3,
                                         &s.reads), "wamd_reads_upload");
-            else
-                check(wamd_reads_refill(s.reads, s.blob.data(), s.off.data(), s.lens.data(), n_up, nullptr), "wamd_reads_refill");
+            else {
+                // the bin's bytes and its longest read are known here: no second pass over the reads on the host
+                check(wamd_reads_refill_async(s.reads, s.blob.data(), s.blob.size(), s.off.data(), s.lens.data(), n_up,
+                                              s.max_len, nullptr), "wamd_reads_refill_async");
+                check(wamd_ctx_synchronize(ref_.ctx()), "wamd_ctx_synchronize");   // the verification runs on other streams
+            }
             wamd_sa_batch b{};
             b.read_first = 0;
             b.n_reads = n;
@@ -746,8 +751,10 @@ private:
         PinnedVec<uint8_t> errors;
         std::vector<uint32_t> first;
         wamd_reads* reads = nullptr;
+        uint32_t max_len = 0;
         void clear()
         {
+            max_len = 0;
             blob.clear(); rc_blob.clear(); off.clear(); lens.clear(); counts.clear(); k.clear(); sa.clear(); errors.clear();
             first.clear();
         }
