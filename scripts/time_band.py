@@ -20,7 +20,7 @@ packed = synth.pack_nibbles(codes)
 ctx = api.Context(packed, ref_size=codes.numel(), cur_offset=0, device=0)
 stream = torch.cuda.ExternalStream(ctx.stream(), device=dev)
 for m, k in ((150, 12), (250, 17), (150, 5)):
-    rd = synth.make_reads(codes, n, m, k, 1234, chunk=1 << 16)
+    rd = synth.make_reads(codes, n, m, k, 1234, chunk=1 << 16, true_frac=float(os.environ.get("WAMD_TRUE_FRAC", "0.5")))
     blob, off, lens = synth.pack_reads(rd["codes"], 0)
     reads = ctx.upload_reads(blob.cpu().numpy(), off.cpu().numpy().astype(np.uint64),
                              lens.cpu().numpy().astype(np.uint32), api.READS_NIBBLE, orientations=3)

@@ -777,7 +777,21 @@ __device__ __forceinline__ void slide_group(uint32_t grp_addr, uint32_t syms, ui
     slide_column<NB, BLOCK, 7, Z>(grp_addr, syms, symsA, rowmask, s0, raw, VP, VN, cnt);
 }
 
-template <int NB, int BLOCK>
+// PACK (reads up to 256 symbols): the lanes a block still needs are moved together once the
+// band has shown which candidates are hopeless.  An accepted candidate has a path of cost <= k inside the band, and
+// from column n_cols - m + k + 1 on every such path has left row 0 and crosses each column in one of the frame's
+// cells: a column whose 64 band values all exceed k ends the candidate ({k + 1, 0}; while paths may still start the
+// frame holds a phantom row of value 0 and the test cannot fire).  The test runs once the frame's top row has 4 k read
+// symbols above it (unrelated text collects 0.3 errors a row: every cell is above k by then; column 96 of S1's 173), or
+// at the end of the sliding phase if that comes sooner.  It is a bound, not the minimum: the column's values at every
+// eighth row are exact (population counts of the vertical deltas), between two of them a walk of eight steps of +-1
+// cannot dip more than (8 - |difference|) / 2 below the smaller.  The survivors' state - ten words - goes through the
+// LDS the rows occupied into the block's first lanes, which re-stage their new reads' rows, and waves left without a
+// lane leave.  Barriers all outside wave-divergent code; FS and the tie-break rule are the block's, not the wave's, so
+// that lanes can change waves.
+constexpr uint32_t PACK_MIN = 64;   // no test before this column: too few rows for it to say anything
+
+template <int NB, int BLOCK, bool PACK>
 __global__ __launch_bounds__(BLOCK) void myers_band_kernel(
     GenomeView g, ReadsView rv, const wamd_dist_task* __restrict__ tasks, uint32_t n, int last_symbol,
     uint32_t max_text_len, wamd_dist_result* __restrict__ results, uint32_t* __restrict__ flags,
@@ -787,6 +801,13 @@ __global__ __launch_bounds__(BLOCK) void myers_band_kernel(
     // [the read's words32 dwords][A,C,G,T][lane], as in the exact kernel
     extern __shared__ uint32_t pm_band[];
     constexpr uint32_t ROW = 4u * BLOCK;   // dwords per vector dword
+    constexpr int WAVES = BLOCK / 64;
+    // the block's few shared words sit BEHIND the rows (PACK launches bring 64 bytes more): the rows must start at LDS
+    // address 0, the symbol's row offset is OR-ed into a lane's address (load_eq, slide_load)
+    uint32_t* const sh_fs = pm_band + rv.words32 * ROW;
+    uint32_t* const sh_rule = sh_fs + WAVES;
+    uint32_t* const sh_cnt = sh_rule + WAVES;
+    uint32_t* const sh_at = sh_cnt + WAVES;
 
     if (only_deferred && *only_deferred == 0)
         return;
@@ -796,11 +817,11 @@ __global__ __launch_bounds__(BLOCK) void myers_band_kernel(
             return;
     }
     const uint32_t tid = threadIdx.x;
-    const uint32_t gid = blockIdx.x * BLOCK + tid;
+    uint32_t gid = blockIdx.x * BLOCK + tid;
     bool valid = gid < n;
     if (valid && chained && results[gid].edit_distance != RESULT_DEFERRED)
         valid = false;
-    if (chained && !__any(valid))
+    if (!PACK && chained && !__any(valid))
         return;
 
     Lane t{};
@@ -834,7 +855,7 @@ __global__ __launch_bounds__(BLOCK) void myers_band_kernel(
         valid = false;
     }
 
-    // ---- does the lane fit the band, and where does the wave's fixed phase start ----------------
+    // ---- does the lane fit the band, and where does the wave's (PACK: the block's) fixed phase start ----
     const uint32_t fm_own = t.n_cols + t.k > 32u * NB ? t.n_cols + t.k - 32u * NB : 0u;
     const bool selffit = valid && t.k < t.m && fm_own + t.k + 2u <= t.m && t.m + t.n_cols < 32000u;
     uint32_t FS = selffit ? fm_own : 0u;
@@ -843,7 +864,32 @@ __global__ __launch_bounds__(BLOCK) void myers_band_kernel(
         FS = max(FS, (uint32_t)__shfl_xor((int)FS, o));
     FS = __builtin_amdgcn_readfirstlane((FS + 7u) & ~7u);
     const uint64_t cand = __ballot(selffit);
-    const uint32_t rule0 = __builtin_amdgcn_readfirstlane(__shfl((int)t.rule, cand ? __ffsll((long long)cand) - 1 : 0));
+    uint32_t rule0 = __builtin_amdgcn_readfirstlane(__shfl((int)t.rule, cand ? __ffsll((long long)cand) - 1 : 0));
+    int32_t test_at = 0;   // PACK: the column of the test, relative to FS (block-uniform)
+    if (PACK) {
+        // the frame's top row at column f is row m - FS - 32 NB + f: it reaches 4 k at f = FS + (32 NB - m + 4 k)
+        int32_t a = selffit ? 32 * NB - (int32_t)t.m + 4 * (int32_t)t.k : INT32_MIN;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            a = max(a, __shfl_xor(a, o));
+        if ((tid & 63u) == 0) {
+            sh_fs[tid >> 6] = FS;
+            sh_rule[tid >> 6] = cand ? rule0 : 0xffu;
+            sh_at[tid >> 6] = (uint32_t)a;
+        }
+        __syncthreads();
+        uint32_t r = 0xffu;
+        test_at = INT32_MIN;
+#pragma unroll
+        for (int w = WAVES - 1; w >= 0; --w) {
+            FS = max(FS, sh_fs[w]);
+            r = sh_rule[w] != 0xffu ? sh_rule[w] : r;
+            test_at = max(test_at, (int32_t)sh_at[w]);
+        }
+        FS = __builtin_amdgcn_readfirstlane(FS);
+        rule0 = __builtin_amdgcn_readfirstlane(r);
+        test_at = __builtin_amdgcn_readfirstlane(test_at);
+    }
     const bool fit = selffit && t.rule == rule0 && FS + t.k + 2u <= t.m;
     if (valid && !fit) {
         results[gid].edit_distance = RESULT_DEFERRED;
@@ -857,12 +903,13 @@ __global__ __launch_bounds__(BLOCK) void myers_band_kernel(
             *reinterpret_cast<volatile uint32_t*>(deferred) = 1u;
     }
     valid = fit;
-    if (!__any(valid))   // wave-uniform; the block has no barriers
+    if (!PACK && !__any(valid))   // wave-uniform; without PACK the block has no barriers
         return;
 
     // ---- rows -> LDS ----------------------------------------------------------------------------
     const uint32_t W32 = rv.words32;
-    {
+    const uint8_t* my_codes = rv.codes;
+    auto stage_rows = [&]() {   // this lane's rows into its column of pm_band, its read's facts into t
         const uint32_t slot = valid ? (uint32_t)(t.rev ? rv.slot_rc : rv.slot_direct) : 0;
         const uint4* src = reinterpret_cast<const uint4*>(rv.pm32) + ((uint64_t)read_idx * rv.n_orient + slot) * rv.pm32_stride;
         for (uint32_t d = 0; d < W32; ++d) {
@@ -879,11 +926,13 @@ __global__ __launch_bounds__(BLOCK) void myers_band_kernel(
             t.presence = meta & 0xffffu;
             t.last_sym = last_symbol >= 0 ? (uint32_t)last_symbol : ((meta >> 16) & 15u);
         }
-    }
-    const uint8_t* my_codes = rv.codes + rv.code_off[read_idx];
+        my_codes = rv.codes + rv.code_off[read_idx];
+    };
+    if (!PACK || __any(valid))
+        stage_rows();
 
     // frame of column f (0-based): bit b is read symbol f + Z0 + b; symbols < 0 are phantom rows
-    const int32_t Z0 = (int32_t)t.m - 32 * NB - (int32_t)FS;
+    int32_t Z0 = (int32_t)t.m - 32 * NB - (int32_t)FS;
     uint32_t VP[NB], VN[NB];
 #pragma unroll
     for (int w = 0; w < NB; ++w) {
@@ -894,20 +943,21 @@ __global__ __launch_bounds__(BLOCK) void myers_band_kernel(
 
     // ---- sliding phase: columns 1 .. FS ---------------------------------------------------------
     uint32_t cnt = 0;   // D0 bits seen under the frame's bottom row
-    if (FS) {
-        const uint32_t rowmask = in_vgpr(3u << (BLOCK == 256 ? 10 : (BLOCK == 128 ? 9 : 8)));
-        const uint32_t lane_addr =
-            (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint32_t*)pm_band + tid * 4u;
+    const uint32_t rowmask = in_vgpr(3u << (BLOCK == 256 ? 10 : (BLOCK == 128 ? 9 : 8)));
+    const uint32_t lane_addr =
+        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint32_t*)pm_band + tid * 4u;
+    // columns from + 1 .. to of the sliding phase (both multiples of 8), with a text stream of their own
+    auto slide = [&](const uint32_t from, const uint32_t to) {
         const uint32_t shift = (ref_pos & 7u) * 4u;
-        uint32_t didx = ref_pos >> 3;
+        uint32_t didx = (ref_pos >> 3) + (from >> 3);
         uint32_t R[TEXT_CHUNK + 1], NX[TEXT_CHUNK];
         load_text_first(g, didx, R);
         didx += TEXT_CHUNK + 1;
-        for (uint32_t base = 0; base < FS;) {
-            if (base + 8u * TEXT_CHUNK < FS)   // another chunk of sliding columns follows
+        for (uint32_t base = from; base < to;) {
+            if (base + 8u * TEXT_CHUNK < to)   // another chunk of sliding columns follows
                 load_text_chunk(g, didx, NX);
             didx += TEXT_CHUNK;
-            for (int gi = 0; gi < TEXT_CHUNK && base < FS; ++gi, base += 8) {
+            for (int gi = 0; gi < TEXT_CHUNK && base < to; ++gi, base += 8) {
                 const uint32_t syms = __builtin_amdgcn_alignbit(R[1], R[0], shift);
 #pragma unroll
                 for (int c = 0; c < TEXT_CHUNK; ++c)
@@ -967,6 +1017,116 @@ __global__ __launch_bounds__(BLOCK) void myers_band_kernel(
             for (int c = 0; c < TEXT_CHUNK; ++c)
                 R[c + 1] = nibble_swap(NX[c]);
         }
+    };
+
+    // where the hopeless are told from the rest (block-uniform)
+    uint32_t T1 = FS;
+    if (PACK && FS >= PACK_MIN) {
+        const int32_t want = test_at == INT32_MIN ? (int32_t)FS : (((int32_t)FS + test_at + 7) & ~7);
+        T1 = want >= (int32_t)FS ? FS : (want < (int32_t)PACK_MIN ? PACK_MIN : (uint32_t)want);
+    }
+    if (T1 && (!PACK || __any(valid)))
+        slide(0u, T1);
+
+    if (PACK && FS >= PACK_MIN) {
+        // ---- the smallest value in the frame of column T1, from its bottom cell (row m - FS - 1 + T1: that value is
+        // the corner's plus one per column, minus the free diagonal steps counted in cnt) up the vertical deltas; VP / VN
+        // are held in the next column's frame, one row down: bit b is the step into row bottom + b - 62
+        if (valid) {
+            int32_t cur = (int32_t)(t.m - FS - 1u + T1) - (int32_t)cnt, mn = cur;
+            // eight rows at a time, bottom up: bits 8 s - 1 .. 8 s + 6 are the steps between rows bottom - 8 (7 - s) - 8
+            // and bottom - 8 (7 - s); the topmost stretch has seven
+#pragma unroll
+            for (int sgm = 4 * NB - 1; sgm >= 0; --sgm) {
+                const int lo = sgm ? 8 * sgm - 1 : 0, hi = 8 * sgm + 6;   // bit range of the stretch, inside one dword or across two
+                uint32_t vp, vn;
+                if ((lo >> 5) == (hi >> 5)) {
+                    const uint32_t msk = ((hi - lo + 1) >= 32 ? ~0u : ((1u << (hi - lo + 1)) - 1u)) << (lo & 31);
+                    vp = VP[lo >> 5] & msk;
+                    vn = VN[lo >> 5] & msk;
+                } else {   // the stretch starts on a dword's top bit
+                    vp = (VP[lo >> 5] >> 31) | ((VP[hi >> 5] & 0x7fu) << 1);
+                    vn = (VN[lo >> 5] >> 31) | ((VN[hi >> 5] & 0x7fu) << 1);
+                }
+                const int32_t nxt = cur + (int32_t)__popc(vn) - (int32_t)__popc(vp);
+                const int32_t len = hi - lo + 1, diff = nxt > cur ? nxt - cur : cur - nxt;
+                const int32_t low = (nxt < cur ? nxt : cur) - (len - diff) / 2;
+                mn = low < mn ? low : mn;
+                cur = nxt;
+            }
+            if (mn > (int32_t)t.k) {
+                results[gid].edit_distance = t.k + 1u;
+                results[gid].pos = 0;
+                valid = false;
+            }
+        }
+        // ---- the block's survivors into its first lanes ----------------------------------------------
+        const uint64_t live = __ballot(valid);
+        if ((tid & 63u) == 0)
+            sh_cnt[tid >> 6] = (uint32_t)__popcll(live);
+        __syncthreads();   // (every wave is also through with the rows it read so far)
+        uint32_t total = 0, before = 0, waves_now = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            const uint32_t c = sh_cnt[w];
+            before += (uint32_t)w < (tid >> 6) ? c : 0u;
+            total += c;
+            waves_now += c ? 1u : 0u;
+        }
+        if ((total + 63u) / 64u < waves_now) {   // block-uniform: the move frees at least one wave
+            constexpr uint32_t F_GID = 0, F_READ = 1, F_REF = 2, F_LEN = 3, F_K = 4, F_CNT = 5, F_VP = 6, F_VN = 6 + NB;
+            static_assert(6 + 2 * NB <= 12, "the state must fit the rows of a three-dword read");
+            if (valid) {
+                const uint32_t p = before + __builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0));
+                pm_band[F_GID * BLOCK + p] = gid;
+                pm_band[F_READ * BLOCK + p] = read_idx;
+                pm_band[F_REF * BLOCK + p] = ref_pos;
+                pm_band[F_LEN * BLOCK + p] = t.m | (t.n_cols << 16);
+                pm_band[F_K * BLOCK + p] = t.k | ((uint32_t)t.rev << 16);
+                pm_band[F_CNT * BLOCK + p] = cnt;
+#pragma unroll
+                for (int w = 0; w < NB; ++w) {
+                    pm_band[(F_VP + w) * BLOCK + p] = VP[w];
+                    pm_band[(F_VN + w) * BLOCK + p] = VN[w];
+                }
+            }
+            __syncthreads();
+            valid = tid < total;
+            if (valid) {
+                gid = pm_band[F_GID * BLOCK + tid];
+                read_idx = pm_band[F_READ * BLOCK + tid];
+                ref_pos = pm_band[F_REF * BLOCK + tid];
+                const uint32_t ln = pm_band[F_LEN * BLOCK + tid], kk = pm_band[F_K * BLOCK + tid];
+                t.m = ln & 0xffffu;
+                t.n_cols = ln >> 16;
+                t.k = kk & 0xffffu;
+                t.rev = (kk >> 16) & 1u;
+                t.rule = rule0;
+                t.wn = (t.m - 1) / 64;
+                t.exit_t = t.n_cols + t.k;   // W + 1 - wn + k of the skewed variants; M64 does not read it
+                cnt = pm_band[F_CNT * BLOCK + tid];
+#pragma unroll
+                for (int w = 0; w < NB; ++w) {
+                    VP[w] = pm_band[(F_VP + w) * BLOCK + tid];
+                    VN[w] = pm_band[(F_VN + w) * BLOCK + tid];
+                }
+                Z0 = (int32_t)t.m - 32 * NB - (int32_t)FS;
+            } else {
+                t = Lane{};
+                t.m = 1;
+                ref_pos = 0;
+                read_idx = 0;
+            }
+            __syncthreads();   // everybody has its new state: the rows may go over it
+            if (__any(valid))
+                stage_rows();
+        }
+        if (!__any(valid))   // wave-uniform, and the last barrier is behind
+            return;
+        if (T1 < FS)
+            slide(T1, FS);
+    } else if (PACK && !__any(valid)) {
+        return;
     }
 
     // ---- fixed phase ----------------------------------------------------------------------------
@@ -1007,9 +1167,23 @@ static int launch_band(const GenomeView& g, const ReadsView& rv, const wamd_dist
 #define WAMD_BAND_BLOCK 128
 #endif
     constexpr int BLOCK = WAMD_BAND_BLOCK;   // small blocks: the LDS rows are what limits the waves per CU
+    {
+        // reads up to 256 symbols: blocks of four waves that pack their survivors
+#ifndef WAMD_NO_PACK   // (scripts/dist_variants.sh builds the comparison without it)
+        if (rv.words32 <= 8) {
+            constexpr int PB = 256;
+            const uint32_t blocks = (n + PB - 1) / PB;
+            const size_t lds = (size_t)rv.words32 * 4 * PB * sizeof(uint32_t) + 64;
+            hipLaunchKernelGGL((myers_band_kernel<NB, PB, true>), dim3(blocks), dim3(PB), lds, s, g, rv, d_tasks, n,
+                               last_symbol, max_text_len, d_results, d_flags, chained, only_deferred, deferred, n_dev);
+            WAMD_HIP(hipGetLastError());
+            return WAMD_OK;
+        }
+#endif
+    }
     const uint32_t blocks = (n + BLOCK - 1) / BLOCK;
     const size_t lds = (size_t)rv.words32 * 4 * BLOCK * sizeof(uint32_t);
-    hipLaunchKernelGGL((myers_band_kernel<NB, BLOCK>), dim3(blocks), dim3(BLOCK), lds, s, g, rv, d_tasks, n,
+    hipLaunchKernelGGL((myers_band_kernel<NB, BLOCK, false>), dim3(blocks), dim3(BLOCK), lds, s, g, rv, d_tasks, n,
                        last_symbol, max_text_len, d_results, d_flags, chained, only_deferred, deferred, n_dev);
     WAMD_HIP(hipGetLastError());
     return WAMD_OK;
