@@ -468,7 +468,7 @@ def run_extras(ctx, device, genome_symbols, stream, n_small, gather_cabi=False):
     out["S2_levdiag"] = {"shape": "CEditDist::LevDiag m=150 k=5 anchor [%d,%d)" % (fl, fr), "tasks": n,
                          "kernel_ms": ms, "candidates_per_s": n / ms * 1e3, "accepted_fraction": acc,
                          # per column of either side's band: 6 ops of match vector, 9 of recurrence, 2 of score
-                         "roofline": roof_valu(n, ((fl + 5) + (150 - fr + 5)) * 17, ms, "levdiag_band_kernel<5,128>"),
+                         "roofline": roof_valu(n, ((fl + 5) + (150 - fr + 5)) * 17, ms, "levdiag_band_kernel<5,256>"),
                          "hbm_bytes_per_candidate": 80 + q(150 + 2 * 5 + 1) + 16 + 4}
     reads.free()
     del d_t, d_r

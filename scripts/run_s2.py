@@ -9,6 +9,8 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from whisper_amd import api, synth  # noqa: E402
 
+if os.environ.get("WAMD_LIB"):
+    api.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", os.environ["WAMD_LIB"])
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 22
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 dev = torch.device("cuda", 0)
@@ -17,7 +19,7 @@ packed = synth.pack_nibbles(codes)
 ctx = api.Context(packed, ref_size=codes.numel(), cur_offset=0, device=0)
 stream = torch.cuda.ExternalStream(ctx.stream(), device=dev)
 fl, fr = synth.stage_segments(150, 5)[2]
-rd = synth.make_reads(codes, n, 150, 5, 77, rc_frac=0.0, protect=(fl, fr), chunk=1 << 17)
+rd = synth.make_reads(codes, n, 150, 5, 77, rc_frac=0.0, protect=(fl, fr), chunk=1 << 17, true_frac=float(os.environ.get("WAMD_TRUE_FRAC", "0.5")))
 blob, off, lens = synth.pack_reads(rd["codes"], 0)
 reads = ctx.upload_reads(blob.cpu().numpy(), off.cpu().numpy().astype(np.uint64), lens.cpu().numpy().astype(np.uint32),
                          api.READS_NIBBLE, orientations=1)

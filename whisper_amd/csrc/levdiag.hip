@@ -522,7 +522,12 @@ __device__ int ld_band_side(const GenomeView& g, const uint32_t* pm, int edge_bi
     return (!dead && st.best <= kk) ? st.best : kk + 1;
 }
 
-template <int NW, int BLOCK, bool PF>
+// PACK: between the two sides the block closes ranks.  A candidate's prefix side either ends it (more than k errors:
+// most unrelated loci, whose answer is then final) or leaves the suffix side to do; the lanes with a suffix to run move
+// into the block's first lanes - three words each (task, the prefix's errors, the odd codes seen) through the planes'
+// LDS, the task itself is read again, the new lanes stage their reads' planes - and waves left without a lane leave.
+// Three barriers, outside wave-divergent code (myers_band_kernel of myers_distance.hip does the same mid-band).
+template <int NW, int BLOCK, bool PF, bool PACK>
 __device__ __forceinline__ void levdiag_band_body(const GenomeView& g, const ReadsView& rv,
                                                              const wamd_levdiag_task* __restrict__ tasks, uint32_t n,
                                                              uint32_t ref_size, uint32_t cur_offset,
@@ -532,7 +537,7 @@ __device__ __forceinline__ void levdiag_band_body(const GenomeView& g, const Rea
     constexpr int ROWS = NW + 2 * LDB_PAD;
 
     const uint32_t tid = threadIdx.x;
-    const uint32_t gid = blockIdx.x * BLOCK + tid;
+    uint32_t gid = blockIdx.x * BLOCK + tid;
     bool valid = gid < n;
     uint32_t k = 0, fl = 0, fr = 0, m = 0, g0 = 0, read_idx = 0;
     if (valid) {
@@ -567,7 +572,8 @@ __device__ __forceinline__ void levdiag_band_body(const GenomeView& g, const Rea
     // ---- the read's pattern vectors -> three bit planes in LDS ---------------------------------------
     uint32_t* pm = pm_lds + tid;
     uint32_t read_odd = 0;   // bit c: the read holds code c >= 4
-    {
+    auto stage_planes = [&]() {
+        read_odd = 0;
         const uint32_t slot = (uint32_t)(rv.slot_direct < 0 ? 0 : rv.slot_direct);
         const uint4* src = reinterpret_cast<const uint4*>(rv.pm32) + ((uint64_t)read_idx * rv.n_orient + slot) * rv.pm32_stride;
 #pragma unroll
@@ -581,15 +587,16 @@ __device__ __forceinline__ void levdiag_band_body(const GenomeView& g, const Rea
         }
         if (valid)
             read_odd = rv.meta[(uint64_t)read_idx * rv.n_orient + slot] & 0xfff0u;
-    }
+    };
+    stage_planes();
     // The bare groups leave out two things.  One is the "is A/C/G/T" plane: fine while no read of the wave holds
     // another code.  The other is the masking of the phantom rows in a side's first columns: with k or more anchor
     // symbols next to the side the frame's rows above row 1 are those symbols, facing the text they equal, and the
     // matrix of the strings so extended has the side's values in the side's cells (a common prefix does not change
     // an edit distance) - and the same start vectors, k matching columns down the diagonal from its own corner.
-    const bool careful = __any(read_odd != 0u || (valid && fr - fl < k));
+    bool careful = __any(read_odd != 0u || (valid && fr - fl < k));
     // table bit of pattern symbol i: the vector is top-aligned in dwords LDB_PAD .. LDB_PAD + words32 - 1
-    const int bitbase = 32 * LDB_PAD + 32 * (int)rv.words32 - (int)m;
+    int bitbase = 32 * LDB_PAD + 32 * (int)rv.words32 - (int)m;
 
     bool alive = valid;
     uint32_t odd = 0;
@@ -642,6 +649,65 @@ __device__ __forceinline__ void levdiag_band_body(const GenomeView& g, const Rea
             }
         }
     }
+    if (PACK) {
+        // ---- who is through, who has a suffix side to run -------------------------------------------------
+        constexpr int WAVES = BLOCK / 64;
+        __shared__ uint32_t sh_cnt[WAVES];
+        const bool more = alive && fr < m;
+        if (valid && !more) {   // the answer is final: the prefix ended the candidate, or there is no suffix
+            const bool dfr = (odd & read_odd) != 0u;
+            results[gid] = dfr ? LD_DEFERRED : (alive ? (uint32_t)ep : k + 1);
+            if (deferred && dfr && *reinterpret_cast<volatile uint32_t*>(deferred) == 0)
+                *reinterpret_cast<volatile uint32_t*>(deferred) = 1u;
+            valid = false;
+        }
+        alive = valid;
+        const uint64_t live = __ballot(valid);
+        if ((tid & 63u) == 0)
+            sh_cnt[tid >> 6] = (uint32_t)__popcll(live);
+        __syncthreads();   // (every wave is also through with its planes)
+        uint32_t total = 0, before = 0, waves_now = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            const uint32_t c = sh_cnt[w];
+            before += (uint32_t)w < (tid >> 6) ? c : 0u;
+            total += c;
+            waves_now += c ? 1u : 0u;
+        }
+        if ((total + 63u) / 64u < waves_now) {   // block-uniform: the move frees at least one wave
+            if (valid) {
+                const uint32_t p = before + __builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0));
+                pm_lds[p] = gid;
+                pm_lds[BLOCK + p] = (uint32_t)ep;
+                pm_lds[2 * BLOCK + p] = odd;
+            }
+            __syncthreads();
+            valid = tid < total;
+            if (valid) {
+                gid = pm_lds[tid];
+                ep = (int)pm_lds[BLOCK + tid];
+                odd = pm_lds[2 * BLOCK + tid];
+                const wamd_levdiag_task t = tasks[gid];   // (held against the batch when it was first decoded)
+                k = t.max_mismatches;
+                fl = t.fixed_left;
+                fr = t.fixed_right;
+                read_idx = t.read_idx;
+                m = rv.lens[read_idx];
+                g0 = t.dir_gen_flag ? t.position_in_text - cur_offset - k : ref_size - t.position_in_text - m + cur_offset - k;
+            } else {
+                k = fl = fr = m = g0 = read_idx = 0;
+                ep = 0;
+                odd = 0;
+            }
+            alive = valid;
+            __syncthreads();   // everybody has its new task: the planes may go over the three words
+            if (__any(valid)) {
+                stage_planes();
+                careful = __any(read_odd != 0u || (valid && fr - fl < k));
+                bitbase = 32 * LDB_PAD + 32 * (int)rv.words32 - (int)m;
+            }
+        }
+    }
     // suffix: rows fr, fr + 1, ... against the text walking right from g0 + fr + k, budget k - ep (edit_dist.cpp:256)
     int es = 0;
     {
@@ -678,7 +744,7 @@ __global__ __launch_bounds__(BLOCK) void levdiag_band_kernel(GenomeView g, Reads
         if (blockIdx.x * BLOCK >= n)
             return;
     }
-    levdiag_band_body<NW, BLOCK, true>(g, rv, tasks, n, ref_size, cur_offset, results, flags, pm_lds, deferred);
+    levdiag_band_body<NW, BLOCK, true, (BLOCK > 128)>(g, rv, tasks, n, ref_size, cur_offset, results, flags, pm_lds, deferred);
 }
 template <int NW, int BLOCK>
 static int launch_ld_band(wamd_ctx* ctx, const wamd_reads* r, const wamd_levdiag_task* d_tasks, uint32_t n,
@@ -721,8 +787,11 @@ int launch_levdiag(wamd_ctx* ctx, const wamd_reads* r, const wamd_levdiag_task* 
         deferred = band_flags(ctx, s);
         if (deferred)
             WAMD_HIP(hipMemsetAsync(deferred, 0, sizeof(uint32_t), s));
-        int rc = r->words32 <= 5 ? launch_ld_band<5, 128>(ctx, r, d_tasks, n, d_results, s, n_dev, deferred)
-                                 : launch_ld_band<8, 128>(ctx, r, d_tasks, n, d_results, s, n_dev, deferred);
+#ifndef WAMD_LD_BLOCK
+#define WAMD_LD_BLOCK 256   // blocks of four waves pack their survivors between the sides; 128: the kernel without it
+#endif
+        int rc = r->words32 <= 5 ? launch_ld_band<5, WAMD_LD_BLOCK>(ctx, r, d_tasks, n, d_results, s, n_dev, deferred)
+                                 : launch_ld_band<8, WAMD_LD_BLOCK>(ctx, r, d_tasks, n, d_results, s, n_dev, deferred);
         if (rc)
             return rc;
     }
