@@ -88,6 +88,16 @@ def test_accepted_only(ctx, oracle, m, k, W, variant, enc, last):
     check(ctx, oracle, packed, blob, off, lens, enc, tasks, last, 0 if (W or 1 << 30) <= m or k == 0 else 800)
 
 
+@pytest.mark.parametrize("m,k,frac", [(150, 12, 0.12), (150, 12, 0.02), (150, 5, 0.1), (250, 17, 0.12), (250, 7, 0.05),
+                                      (100, 10, 0.1), (150, 12, 0.97)])
+def test_accepted_only_sparse_and_dense_batches(ctx, oracle, m, k, frac):
+    """The mixes at which a block of the banded kernels gives waves back: few related candidates among unrelated loci
+    (a mapper's batches: one, two or three of a block's four waves leave at the test column, the survivors change
+    lanes), and nearly all related (nobody leaves, nothing moves)."""
+    codes, packed, (blob, off, lens), tasks = common.distance_workload(m, k, 7000, seed=900 + m + k, true_frac=frac)
+    check(ctx, oracle, packed, blob, off, lens, 0, tasks, -1, 20)
+
+
 def test_accepted_only_mixed_waves(ctx, oracle):
     """Lengths, budgets and windows vary inside every wave: different tie-break rules, band
     fits and fixed-phase starts side by side (deferred lanes go down the chain)."""

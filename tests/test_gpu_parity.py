@@ -137,6 +137,25 @@ def test_levdiag_long_reads(ctx, oracle, m, ks):
             np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("frac,k", [(0.1, 5), (0.02, 3), (0.97, 6)])
+def test_levdiag_sparse_and_dense_batches(ctx, oracle, frac, k):
+    """Few related candidates among loci that only share the anchor (the prefix side ends most of them and the block
+    packs the rest between the sides), and nearly all related (nothing moves)."""
+    import torch
+    from whisper_amd import synth
+    codes, packed = common.genome()
+    for j, (fl, fr) in enumerate(common.stage_segments(150, k)):
+        rd = synth.make_reads(codes, 5000, 150, k, 1700 + 10 * k + j, rc_frac=0.0, protect=(fl, fr), true_frac=frac)
+        blob, off, lens = common.host_reads(rd, 0)
+        tasks = synth.levdiag_tasks(rd, k, fl, fr, 0)
+        rc, want = oracle.levdiag(packed, codes.numel(), 0, blob, off, lens, tasks)
+        reads = ctx.upload_reads(blob, off, lens, 0, orientations=1)
+        got = ctx.lev_diag(reads, tasks)
+        reads.free()
+        assert (want <= k).sum() > 20
+        np.testing.assert_array_equal(got, want)
+
+
 def test_levdiag_mixed_lengths(ctx, oracle):
     """One batch holding reads of 40 .. 250 symbols: the kernel is picked by the longest read."""
     import torch
