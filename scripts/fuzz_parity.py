@@ -40,7 +40,7 @@ def mixed_distance_batch(rng, gen, n_groups, per_group, max_m, enc, rescue_frac=
         kmax = max(1, min(m // 3, 44))
         k = int(rng.integers(0, kmax + 1))
         rd = synth.make_reads(codes, per_group, m, k, int(rng.integers(1, 1 << 30)),
-                              true_frac=float(rng.choice([0.25, 0.5, 0.9])))
+                              true_frac=float(rng.choice([0.05, 0.25, 0.5, 0.9])))
         p = rd["p"].numpy()
         rcf = rd["is_rc"].numpy().astype(np.uint8)
         kind = rng.random()
