@@ -295,7 +295,20 @@ def check_finish(ctx, oracle, rng, gen, report):
                                         ext_stride=768)
         assert rc == 0
         reads = ctx.upload_reads(blob, off, lens, 1, orientations=3)
-        got = ctx.finish_pairs(reads, tasks, api.default_finish_params(flank), ext_stride=768)
+        try:
+            got = ctx.finish_pairs(reads, tasks, api.default_finish_params(flank), ext_stride=768)
+        except api.WamdError:
+            # a record whose clipping runs past the read: the reference's unsigned lengths wrap (the oracle restates
+            # that: err_edit_distance 65533, a left clipping longer than the read), the library refuses the batch
+            #  - about one generated slot in a million
+            w = want[0]
+            wrapped = (w["err_edit_distance"] >= 0x8000) | (w["left_clipping"].astype(np.int64) + w["right_clipping"] > m + 1)
+            reads.free()
+            if not wrapped.any():
+                raise
+            print("   finish: batch refused for %d wrapping record(s), as documented" % int(wrapped.sum()), flush=True)
+            report("finish pairs refused (wrapping record)", len(tasks), np.zeros(0, int), tasks, want[0], want[0])
+            return
         reads.free()
         try:
             common.same_finish_output(got, want)
@@ -522,7 +535,11 @@ def main():
         todo = replay if replay else [(f, int(rng.integers(1, 1 << 30))) for f in fams]
         for f, bseed in todo:
             cur[0] = "%s:%d" % (f, int(bseed))
-            FAMILIES[f](ctx, oracle, np.random.default_rng(int(bseed)), gen, report)
+            try:
+                FAMILIES[f](ctx, oracle, np.random.default_rng(int(bseed)), gen, report)
+            except BaseException:
+                print("EXCEPTION in batch [%s] (--replay %s)" % (cur[0], cur[0]), flush=True)
+                raise
             flags = ctx.take_flags()
             if flags:
                 print("device flags 0x%x after %s" % (flags, f), flush=True)
