@@ -865,30 +865,14 @@ __global__ __launch_bounds__(BLOCK) void myers_band_kernel(
     FS = __builtin_amdgcn_readfirstlane((FS + 7u) & ~7u);
     const uint64_t cand = __ballot(selffit);
     uint32_t rule0 = __builtin_amdgcn_readfirstlane(__shfl((int)t.rule, cand ? __ffsll((long long)cand) - 1 : 0));
-    int32_t test_at = 0;   // PACK: the column of the test, relative to FS (block-uniform)
+    int32_t test_at = INT32_MIN;   // PACK: the column of the test, relative to FS (the wave's)
     if (PACK) {
         // the frame's top row at column f is row m - FS - 32 NB + f: it reaches 4 k at f = FS + (32 NB - m + 4 k)
         int32_t a = selffit ? 32 * NB - (int32_t)t.m + 4 * (int32_t)t.k : INT32_MIN;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1)
             a = max(a, __shfl_xor(a, o));
-        if ((tid & 63u) == 0) {
-            sh_fs[tid >> 6] = FS;
-            sh_rule[tid >> 6] = cand ? rule0 : 0xffu;
-            sh_at[tid >> 6] = (uint32_t)a;
-        }
-        __syncthreads();
-        uint32_t r = 0xffu;
-        test_at = INT32_MIN;
-#pragma unroll
-        for (int w = WAVES - 1; w >= 0; --w) {
-            FS = max(FS, sh_fs[w]);
-            r = sh_rule[w] != 0xffu ? sh_rule[w] : r;
-            test_at = max(test_at, (int32_t)sh_at[w]);
-        }
-        FS = __builtin_amdgcn_readfirstlane(FS);
-        rule0 = __builtin_amdgcn_readfirstlane(r);
-        test_at = __builtin_amdgcn_readfirstlane(test_at);
+        test_at = __builtin_amdgcn_readfirstlane(a);
     }
     const bool fit = selffit && t.rule == rule0 && FS + t.k + 2u <= t.m;
     if (valid && !fit) {
@@ -1019,7 +1003,7 @@ __global__ __launch_bounds__(BLOCK) void myers_band_kernel(
         }
     };
 
-    // where the hopeless are told from the rest (block-uniform)
+    // where the hopeless are told from the rest (the wave's own column)
     uint32_t T1 = FS;
     if (PACK && FS >= PACK_MIN) {
         const int32_t want = test_at == INT32_MIN ? (int32_t)FS : (((int32_t)FS + test_at + 7) & ~7);
@@ -1028,11 +1012,11 @@ __global__ __launch_bounds__(BLOCK) void myers_band_kernel(
     if (T1 && (!PACK || __any(valid)))
         slide(0u, T1);
 
-    if (PACK && FS >= PACK_MIN) {
+    if (PACK) {   // (every wave of the block comes through here, with lanes or without: the barriers are the block's)
         // ---- the smallest value in the frame of column T1, from its bottom cell (row m - FS - 1 + T1: that value is
         // the corner's plus one per column, minus the free diagonal steps counted in cnt) up the vertical deltas; VP / VN
         // are held in the next column's frame, one row down: bit b is the step into row bottom + b - 62
-        if (valid) {
+        if (valid && FS >= PACK_MIN) {
             int32_t cur = (int32_t)(t.m - FS - 1u + T1) - (int32_t)cnt, mn = cur;
             // eight rows at a time, bottom up: bits 8 s - 1 .. 8 s + 6 are the steps between rows bottom - 8 (7 - s) - 8
             // and bottom - 8 (7 - s); the topmost stretch has seven
@@ -1061,19 +1045,57 @@ __global__ __launch_bounds__(BLOCK) void myers_band_kernel(
             }
         }
         // ---- the block's survivors into its first lanes ----------------------------------------------
+        // FS, the test column and the tie-break rule are each wave's own (no barrier before the columns start); lanes
+        // can only change waves where the block's waves agree on them - they do in a batch of one read length and k
         const uint64_t live = __ballot(valid);
-        if ((tid & 63u) == 0)
+        if ((tid & 63u) == 0) {
             sh_cnt[tid >> 6] = (uint32_t)__popcll(live);
+            sh_fs[tid >> 6] = FS;
+            sh_at[tid >> 6] = T1;
+            sh_rule[tid >> 6] = rule0;
+        }
         __syncthreads();   // (every wave is also through with the rows it read so far)
         uint32_t total = 0, before = 0, waves_now = 0;
+        bool agree = true;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) {
             const uint32_t c = sh_cnt[w];
             before += (uint32_t)w < (tid >> 6) ? c : 0u;
             total += c;
             waves_now += c ? 1u : 0u;
+            // (a wave without a lane left has nothing to agree on)
+            agree = agree && (c == 0 || (sh_fs[w] == FS && sh_at[w] == T1 && sh_rule[w] == rule0) || live == 0);
         }
-        if ((total + 63u) / 64u < waves_now) {   // block-uniform: the move frees at least one wave
+        // every wave reaches the same verdict: a wave with lanes compares the others with itself, and two waves with
+        // lanes that differ see each other; a wave without lanes only needs to know whether to stay for the barriers
+        // (the 96-row band's state is half as large again and its test comes later: one wave freed does not pay there)
+        constexpr uint32_t MUST_FREE = NB >= 3 ? 2u : 1u;
+        bool go = agree && (total + 63u) / 64u + MUST_FREE <= waves_now;
+        if (live == 0) {   // an empty wave takes the verdict of the waves that have lanes: all pairs among them agree?
+            bool all_same = true;
+            uint32_t f0 = 0, a0 = 0, r0 = 0;
+            bool have = false;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) {
+                if (sh_cnt[w]) {
+                    if (!have) {
+                        f0 = sh_fs[w];
+                        a0 = sh_at[w];
+                        r0 = sh_rule[w];
+                        have = true;
+                    } else {
+                        all_same = all_same && sh_fs[w] == f0 && sh_at[w] == a0 && sh_rule[w] == r0;
+                    }
+                }
+            }
+            go = all_same && (total + 63u) / 64u + MUST_FREE <= waves_now;
+            if (go) {   // it may be given lanes: it needs the block's FS / rule / test column
+                FS = __builtin_amdgcn_readfirstlane(f0);
+                T1 = __builtin_amdgcn_readfirstlane(a0);
+                rule0 = __builtin_amdgcn_readfirstlane(r0);
+            }
+        }
+        if (go) {   // block-uniform: the waves agree and the move frees at least one of them
             constexpr uint32_t F_GID = 0, F_READ = 1, F_REF = 2, F_LEN = 3, F_K = 4, F_CNT = 5, F_VP = 6, F_VN = 6 + NB;
             static_assert(6 + 2 * NB <= 12, "the state must fit the rows of a three-dword read");
             if (valid) {
@@ -1125,8 +1147,6 @@ __global__ __launch_bounds__(BLOCK) void myers_band_kernel(
             return;
         if (T1 < FS)
             slide(T1, FS);
-    } else if (PACK && !__any(valid)) {
-        return;
     }
 
     // ---- fixed phase ----------------------------------------------------------------------------
